@@ -1,0 +1,198 @@
+/*
+ * ilcc_hip.h -- C-ABI of libilcc_hip.so: MI355X (gfx950) implementation of ilcc2's LiDAR
+ * chessboard-corner extraction path.
+ *
+ * The reference has no FFI; its boundary for this path is the class LidarCornersEst as driven
+ * by one ROS node (all citations relative to /root/reference/):
+ *
+ *   reference call (ilcc2/test/get_lidar_corners.cpp)                     C-ABI replacement
+ *   ------------------------------------------------------------------   ----------------------------
+ *   :112 new LidarCornersEst                                              ilcc_create
+ *   :114 set_chessboard_param(yaml)   (src/LidarCornersEst.cpp:20-46)     ilcc_set_chessboard_param
+ *   :183 setROI(cloud, click)         (src/LidarCornersEst.cpp:48-70)     \
+ *   :188 EuclideanCluster()           (:124-186, getPlane :190-221)        |
+ *   :191 PCA()                        (:366-372, :330-364, :224-328)       > ilcc_extract / _batch /
+ *   :194 get_corners(lidar_corner)    (:374-450, Optimization.cpp:94-160,  |   _batch_device
+ *                                      Optimization.h:31-107, :501-556)   /
+ *   :192-193,200-201 m_cloud_chessboard/_PCA/_optim/_corners members       ilcc_fetch_cloud
+ *   :197-198 save_corners2txt(m_cloud_corners, path) (:27-36)             ilcc_save_corners2txt
+ *   consumer: ImageCornersEst::read_lidar_corners (src/ImageCornersEst.cpp:281-299)
+ *                                                                         ilcc_read_lidar_corners
+ *
+ * Rules of the boundary: plain pointers and sizes only; the caller owns every input/output
+ * buffer; the library owns device memory inside the handle; no exception crosses the ABI; a
+ * batch call never aborts on a bad frame (per-frame status instead of the reference's bool
+ * returns / uncaught std::out_of_range).  A handle is not thread-safe: one handle per
+ * (thread, device); every call is synchronous on return unless stated otherwise.
+ * There is NO CPU fallback: without a HIP device ilcc_create fails.
+ */
+#ifndef ILCC_HIP_H_
+#define ILCC_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ILCC_MAX_CORNERS 256
+#define ILCC_ABI_VERSION 1
+
+/* per-frame / per-call status */
+enum {
+  ILCC_OK = 0,
+  ILCC_NO_ROI_POINTS = 1,   /* setROI left nothing */
+  ILCC_NO_CLUSTER = 2,      /* reference: cluster_indices.at(0) throws (LidarCornersEst.cpp:167) */
+  ILCC_NO_PLANE = 3,        /* reference: PCL_ERROR (LidarCornersEst.cpp:206-209) */
+  ILCC_DEGENERATE_HIST = 4, /* reference: UB in calHist (LidarCornersEst.cpp:235,266-282) */
+  ILCC_TOO_FEW_POINTS = 5,
+  ILCC_BAD_ARGUMENT = 6,
+  ILCC_CAPACITY = 7,        /* more frames / points than the handle was created for */
+  ILCC_HIP_ERROR = 8,
+  ILCC_IO_ERROR = 9
+};
+
+/* how (theta, ty, tz) is found */
+enum {
+  /* the reference's own trajectory: Ceres-style local solve from (0,0,0), pass A (out-of-board
+   * term on) then pass B (off) -- LidarCornersEst.cpp:398-409 */
+  ILCC_SOLVER_REFERENCE_LOCAL = 0,
+  /* exhaustive (theta,ty,tz) x colour-phase grid on the pass-A cost, one wavefront per candidate
+   * tile, then the same local A+B polish started from the grid argmin */
+  ILCC_SOLVER_GRID = 1
+};
+
+/* which clouds ilcc_fetch_cloud can return (topics of get_lidar_corners.cpp:120-124) */
+enum {
+  ILCC_CLOUD_ROI = 0,        /* m_cloud_ROI */
+  ILCC_CLOUD_CLUSTER = 1,    /* chosen Euclidean cluster (temp_cloud before getPlane) */
+  ILCC_CLOUD_CHESSBOARD = 2, /* m_cloud_chessboard  -> /ChessBoard */
+  ILCC_CLOUD_PCA = 3,        /* m_cloud_PCA         -> /pca_cloud */
+  ILCC_CLOUD_OPTIM = 4       /* m_cloud_optim       -> /Optim_cloud */
+};
+
+typedef struct ilcc_params {
+  /* setROI half extents x,y,z (LidarCornersEst.cpp:59,64,54) */
+  double roi_half[3];
+  /* EuclideanCluster (LidarCornersEst.cpp:131-133) */
+  double cluster_tol;
+  int32_t cluster_min;
+  int32_t cluster_max;
+  /* getPlane (LidarCornersEst.cpp:201); hypotheses of the counter-based sampler */
+  double ransac_thresh;
+  int32_t ransac_hyp;
+  uint32_t ransac_seed;
+  /* calHist / get_gray_zone (LidarCornersEst.cpp:226,371) */
+  int32_t hist_bins;
+  double gray_rate;
+  /* get_theta_t (Optimization.cpp:137) */
+  double huber_delta;
+  /* board: squares per side, board_w <= board_h (LidarCornersEst.cpp:30-39), side length */
+  double grid_length;
+  int32_t board_w;
+  int32_t board_h;
+  /* solver */
+  int32_t solver;      /* ILCC_SOLVER_* */
+  int32_t phase_mode;  /* REFERENCE_LOCAL only: 0 topleftWhite=false (reference's first turn),
+                          1 true, 2 both from zero, keep lower with-OOB cost (replaces key 'd') */
+  int32_t max_iterations; /* trust-region iterations per pass (Ceres default 50) */
+  /* exhaustive grid: theta_k = th_min + k th_step (rad), ty_a, tz_b likewise (m) */
+  int32_t n_th, n_ty, n_tz;
+  double th_min, th_step;
+  double ty_min, ty_step;
+  double tz_min, tz_step;
+} ilcc_params;
+
+typedef struct ilcc_result {
+  int32_t status;
+  int32_t n_points;            /* input points of the frame */
+  int32_t n_roi, n_cluster, n_plane;
+  int32_t n_black, n_gray, n_white;
+  int32_t n_corners;
+  int32_t phase;               /* topleftWhite chosen (0/1) */
+  int32_t iters_a, iters_b;
+  int32_t grid_index;          /* ((k*n_ty+a)*n_tz+b)*2+phase of the grid argmin, -1 if unused */
+  int32_t reserved0;
+  float grid_cost;
+  float plane[4];              /* refit plane nx,ny,nz,d of getPlane */
+  float pca[16];               /* row-major 4x4 pca_matrix (lidar -> plane frame) */
+  double gray_zone[2];
+  double theta_t[3];
+  double cost_a, cost_b;       /* final cost of pass A / pass B */
+  double sel_cost;             /* with-OOB cost at theta_t */
+  float corners[ILCC_MAX_CORNERS * 3]; /* x y z, outer loop short board axis, inner long axis */
+} ilcc_result;
+
+typedef struct ilcc_handle ilcc_handle;
+
+/* per-stage device time of the last batch call, ms (HIP events on the handle's stream) */
+typedef struct ilcc_timing {
+  float roi_crop, cluster, ransac_plane, plane_frame_hist, grid_cost, refine_corners, total;
+  uint32_t grid_cost_launches;   /* kernel launches accumulated since ilcc_reset_timing */
+  double grid_cost_ms_sum;       /* their summed HIP-event duration, ms */
+  uint64_t grid_cost_evals_sum;  /* point x candidate evaluations they performed (both phases = 1) */
+} ilcc_timing;
+
+int32_t ilcc_abi_version(void);
+const char* ilcc_strerror(int32_t status);
+const char* ilcc_last_error(const ilcc_handle* h);
+
+/* reference constants (every one is hard-coded in the reference, see field comments) */
+void ilcc_default_params(ilcc_params* p);
+
+/* LidarCornersEst::set_chessboard_param (LidarCornersEst.cpp:20-46): reads grid_length,
+ * corner_in_x, corner_in_y from an OpenCV-YAML file, squares = corners+1, sorted ascending. */
+int32_t ilcc_set_chessboard_param(ilcc_params* p, const char* cam_yaml);
+
+/* device < 0: current device.  max_frames / max_total_points bound one batch call. */
+ilcc_handle* ilcc_create(int32_t device, const ilcc_params* p, uint32_t max_frames,
+                         uint64_t max_total_points);
+void ilcc_destroy(ilcc_handle* h);
+int32_t ilcc_set_params(ilcc_handle* h, const ilcc_params* p);
+
+/* one frame, host buffers: xyzi = n x {x,y,z,intensity} float32 (pcl::PointXYZI payload) */
+int32_t ilcc_extract(ilcc_handle* h, const float* xyzi, uint32_t n, const float click[3],
+                     ilcc_result* out);
+
+/* batch, host buffers.  offsets[f]..offsets[f+1] = point range of frame f (n_frames+1 entries,
+ * offsets[0] = 0).  clicks = n_frames x 3.  out = n_frames records. */
+int32_t ilcc_extract_batch(ilcc_handle* h, const float* xyzi, const uint64_t* offsets,
+                           uint32_t n_frames, const float* clicks, ilcc_result* out);
+
+/* batch, inputs already resident in HBM (d_xyzi, d_clicks device pointers; offsets on host).
+ * out is a host buffer. */
+int32_t ilcc_extract_batch_device(ilcc_handle* h, const float* d_xyzi, const uint64_t* offsets,
+                                  uint32_t n_frames, const float* d_clicks, ilcc_result* out);
+
+/* copy one of the last batch's intermediate clouds of a frame (n x 4 float32) to the host.
+ * returns the point count (<= cap_points written), or a negative status. */
+int64_t ilcc_fetch_cloud(ilcc_handle* h, uint32_t frame, int32_t which, float* out_xyzi,
+                         uint64_t cap_points);
+/* non-gray points handed to the cost: y,z (plane frame) and label (0 black, 1 white) */
+int64_t ilcc_fetch_labelled(ilcc_handle* h, uint32_t frame, float* out_yz, uint8_t* out_label,
+                            uint64_t cap_points);
+
+/* the grid-cost kernel on caller-supplied labelled points (host buffers): full cost volume
+ * [n_th][n_ty][n_tz][2 phases] (cost_out may be NULL) and the argmin exactly as the pipeline
+ * selects it.  Test/diagnostic entry of the hot kernel. */
+int32_t ilcc_grid_cost(ilcc_handle* h, const float* yz, const uint8_t* label, uint32_t m,
+                       int32_t use_oob, float* cost_out, int32_t* best_index, float* best_cost);
+
+/* the local solver (Optimization::get_theta_t) on caller-supplied labelled points */
+int32_t ilcc_get_theta_t(ilcc_handle* h, const float* yz, const uint8_t* label, uint32_t m,
+                         int32_t topleft_white, int32_t use_oob, double theta_t[3], double* cost,
+                         int32_t* iterations);
+
+void ilcc_get_timing(const ilcc_handle* h, ilcc_timing* t);
+void ilcc_reset_timing(ilcc_handle* h);
+
+/* save_corners2txt (get_lidar_corners.cpp:27-36): "x y z\n" per corner, ostream default float
+ * formatting (6 significant digits), file truncated. */
+int32_t ilcc_save_corners2txt(const float* corners_xyz, uint32_t n_corners, const char* filename);
+/* ImageCornersEst::read_lidar_corners (ImageCornersEst.cpp:281-299): returns corners read */
+int32_t ilcc_read_lidar_corners(const char* filename, uint32_t num, double* out_xyz);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

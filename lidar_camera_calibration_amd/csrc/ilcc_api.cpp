@@ -1,0 +1,622 @@
+// ilcc_api.cpp -- host side of the C-ABI (include/ilcc_hip.h): handle, HBM buffers, the stage
+// pipeline on one HIP stream, HIP-event timing, and the two file contracts of the path.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <new>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "ilcc_internal.h"
+
+using namespace ilcc;
+
+struct ilcc_handle {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  ilcc_params p{};
+  uint32_t max_frames = 0;
+  uint64_t max_points = 0;
+  uint32_t max_theta = 0;
+  // device buffers
+  float4* d_xyzi = nullptr;   // staging for host-input calls
+  float* d_clicks = nullptr;
+  uint64_t* d_off = nullptr;
+  ilcc_result* d_res = nullptr;
+  float4 *d_roi = nullptr, *d_cluster = nullptr, *d_board = nullptr, *d_pca = nullptr, *d_optim = nullptr;
+  float2* d_yz = nullptr;
+  uint8_t* d_lab = nullptr;
+  uint32_t *d_nlab = nullptr, *d_counts = nullptr, *d_parent = nullptr, *d_count = nullptr;
+  GridPartial* d_partial = nullptr;
+  float *d_cth = nullptr, *d_sth = nullptr, *d_ay = nullptr, *d_az = nullptr;
+  double* d_solve = nullptr;   // 3 theta_t + 2 (cost, iterations) for the test entry
+  uint32_t crop_chunks_cap = 0;
+  // last batch
+  std::vector<uint64_t> off;
+  uint32_t n_frames = 0;
+  uint32_t grid_lds_points = 2048;
+  // timing
+  hipEvent_t ev[8]{};
+  ilcc_timing timing{};
+  std::string err;
+};
+
+namespace {
+
+thread_local std::string g_err;
+
+#define HIP_TRY(h, expr)                                                                   \
+  do {                                                                                     \
+    hipError_t e_ = (expr);                                                                \
+    if (e_ != hipSuccess) {                                                                \
+      (h)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                        \
+      return ILCC_HIP_ERROR;                                                               \
+    }                                                                                      \
+  } while (0)
+
+int32_t near_zero_index(double vmin, double step, int32_t n) {
+  long c = std::lround(-vmin / step);
+  if (c < 0) c = 0;
+  if (c > n - 1) c = n - 1;
+  return (int32_t)c;
+}
+
+bool params_ok(const ilcc_params& p, std::string& why) {
+  auto bad = [&](const char* m) {
+    why = m;
+    return false;
+  };
+  if (!(p.grid_length > 0)) return bad("grid_length must be > 0");
+  if (p.board_w < 2 || p.board_h < 2 || p.board_w > p.board_h) return bad("board_w/board_h: need 2 <= w <= h");
+  if ((p.board_w - 1) * (p.board_h - 1) > ILCC_MAX_CORNERS) return bad("too many corners");
+  if (p.hist_bins < 1 || p.hist_bins > 4096) return bad("hist_bins out of range");
+  if (!(p.gray_rate > 0) || !(p.huber_delta > 0)) return bad("gray_rate / huber_delta must be > 0");
+  if (p.ransac_hyp < 1 || p.ransac_hyp > 65536) return bad("ransac_hyp out of range");
+  if (!(p.cluster_tol > 0) || p.cluster_min < 1 || p.cluster_max < p.cluster_min) return bad("cluster params");
+  if (p.solver != ILCC_SOLVER_REFERENCE_LOCAL && p.solver != ILCC_SOLVER_GRID) return bad("solver");
+  if (p.phase_mode < 0 || p.phase_mode > 2) return bad("phase_mode");
+  if (p.max_iterations < 0 || p.max_iterations > 100000) return bad("max_iterations");
+  if (p.n_th < 1 || p.n_ty < 1 || p.n_tz < 1) return bad("grid sizes must be >= 1");
+  if ((uint64_t)p.n_th * p.n_ty * p.n_tz * 2ull >= 0xFFFFFFFFull) return bad("grid too large");
+  if (!(p.th_step > 0) || !(p.ty_step > 0) || !(p.tz_step > 0)) return bad("grid steps must be > 0");
+  return true;
+}
+
+int32_t upload_tables(ilcc_handle* h) {
+  const ilcc_params& p = h->p;
+  if ((uint32_t)p.n_th > h->max_theta || (uint32_t)p.n_ty > h->max_theta || (uint32_t)p.n_tz > h->max_theta) {
+    h->err = "grid axis longer than the handle's table capacity";
+    return ILCC_CAPACITY;
+  }
+  std::vector<float> cth(p.n_th), sth(p.n_th), ay(p.n_ty), az(p.n_tz);
+  const double g = p.grid_length;
+  for (int k = 0; k < p.n_th; ++k) {
+    const double th = p.th_min + k * p.th_step;
+    cth[k] = (float)(std::cos(th) / g);
+    sth[k] = (float)(std::sin(th) / g);
+  }
+  for (int a = 0; a < p.n_ty; ++a) ay[a] = (float)(((p.ty_min + a * p.ty_step) + p.board_w * g / 2.0) / g);
+  for (int b = 0; b < p.n_tz; ++b) az[b] = (float)(((p.tz_min + b * p.tz_step) + p.board_h * g / 2.0) / g);
+  HIP_TRY(h, hipMemcpyAsync(h->d_cth, cth.data(), sizeof(float) * p.n_th, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(h->d_sth, sth.data(), sizeof(float) * p.n_th, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(h->d_ay, ay.data(), sizeof(float) * p.n_ty, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(h->d_az, az.data(), sizeof(float) * p.n_tz, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return ILCC_OK;
+}
+
+Ctx make_ctx(ilcc_handle* h, const float4* d_xyzi, const float* d_clicks, uint32_t n_frames,
+             uint32_t crop_chunks) {
+  Ctx c{};
+  c.xyzi = d_xyzi;
+  c.off = h->d_off;
+  c.clicks = d_clicks;
+  c.n_frames = n_frames;
+  c.crop_chunks = crop_chunks;
+  c.res = h->d_res;
+  c.roi = h->d_roi;
+  c.cluster = h->d_cluster;
+  c.board = h->d_board;
+  c.pca = h->d_pca;
+  c.optim = h->d_optim;
+  c.yz = h->d_yz;
+  c.lab = h->d_lab;
+  c.n_lab = h->d_nlab;
+  c.crop_counts = h->d_counts;
+  c.uf_parent = h->d_parent;
+  c.uf_count = h->d_count;
+  c.partial = h->d_partial;
+  c.grid_blocks = (uint32_t)h->p.n_th;
+  c.grid_lds_points = h->grid_lds_points;
+  c.cth = h->d_cth;
+  c.sth = h->d_sth;
+  c.ay = h->d_ay;
+  c.az = h->d_az;
+  c.p = h->p;
+  c.c_th = near_zero_index(h->p.th_min, h->p.th_step, h->p.n_th);
+  c.c_ty = near_zero_index(h->p.ty_min, h->p.ty_step, h->p.n_ty);
+  c.c_tz = near_zero_index(h->p.tz_min, h->p.tz_step, h->p.n_tz);
+  return c;
+}
+
+int32_t check_offsets(ilcc_handle* h, const uint64_t* offsets, uint32_t n_frames) {
+  if (!offsets || n_frames == 0) {
+    h->err = "no frames";
+    return ILCC_BAD_ARGUMENT;
+  }
+  if (n_frames > h->max_frames) {
+    h->err = "n_frames exceeds the handle's max_frames";
+    return ILCC_CAPACITY;
+  }
+  if (offsets[0] != 0) {
+    h->err = "offsets[0] must be 0";
+    return ILCC_BAD_ARGUMENT;
+  }
+  for (uint32_t f = 0; f < n_frames; ++f)
+    if (offsets[f + 1] < offsets[f] || offsets[f + 1] - offsets[f] > 0x7FFFFFFFull) {
+      h->err = "offsets must be non-decreasing, frames < 2^31 points";
+      return ILCC_BAD_ARGUMENT;
+    }
+  if (offsets[n_frames] > h->max_points) {
+    h->err = "total points exceed the handle's max_total_points";
+    return ILCC_CAPACITY;
+  }
+  return ILCC_OK;
+}
+
+// the pipeline proper: everything on h->stream, inputs already in HBM
+int32_t run_pipeline(ilcc_handle* h, const float4* d_xyzi, const uint64_t* offsets, uint32_t n_frames,
+                     const float* d_clicks, ilcc_result* out) {
+  uint64_t max_n = 0;
+  for (uint32_t f = 0; f < n_frames; ++f) max_n = std::max<uint64_t>(max_n, offsets[f + 1] - offsets[f]);
+  uint32_t chunks = (uint32_t)((max_n + kCropChunk - 1) / kCropChunk);
+  if (chunks == 0) chunks = 1;
+  if ((uint64_t)chunks * n_frames > (uint64_t)h->crop_chunks_cap) {
+    h->err = "crop chunk table too small for this batch";
+    return ILCC_CAPACITY;
+  }
+  h->off.assign(offsets, offsets + n_frames + 1);
+  h->n_frames = n_frames;
+  hipStream_t s = h->stream;
+  HIP_TRY(h, hipMemcpyAsync(h->d_off, offsets, sizeof(uint64_t) * (n_frames + 1), hipMemcpyHostToDevice, s));
+  HIP_TRY(h, hipMemsetAsync(h->d_count, 0, sizeof(uint32_t) * offsets[n_frames], s));
+  const Ctx c = make_ctx(h, d_xyzi, d_clicks, n_frames, chunks);
+
+  HIP_TRY(h, hipEventRecord(h->ev[0], s));
+  launch_roi_crop(c, s);
+  HIP_TRY(h, hipEventRecord(h->ev[1], s));
+  launch_cluster(c, s);
+  HIP_TRY(h, hipEventRecord(h->ev[2], s));
+  launch_ransac_plane(c, s);
+  HIP_TRY(h, hipEventRecord(h->ev[3], s));
+  launch_plane_frame_hist(c, s);
+  HIP_TRY(h, hipEventRecord(h->ev[4], s));
+  const bool grid = h->p.solver == ILCC_SOLVER_GRID;
+  if (grid) launch_grid_cost(c, s, /*use_oob=*/1, nullptr);
+  HIP_TRY(h, hipEventRecord(h->ev[5], s));
+  launch_refine_corners(c, s);
+  HIP_TRY(h, hipEventRecord(h->ev[6], s));
+  HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipMemcpyAsync(out, h->d_res, sizeof(ilcc_result) * n_frames, hipMemcpyDeviceToHost, s));
+  HIP_TRY(h, hipStreamSynchronize(s));
+
+  float ms[6];
+  for (int k = 0; k < 6; ++k) HIP_TRY(h, hipEventElapsedTime(&ms[k], h->ev[k], h->ev[k + 1]));
+  float tot = 0;
+  HIP_TRY(h, hipEventElapsedTime(&tot, h->ev[0], h->ev[6]));
+  ilcc_timing& t = h->timing;
+  t.roi_crop = ms[0];
+  t.cluster = ms[1];
+  t.ransac_plane = ms[2];
+  t.plane_frame_hist = ms[3];
+  t.grid_cost = ms[4];
+  t.refine_corners = ms[5];
+  t.total = tot;
+  uint32_t max_lab = 0;
+  uint64_t evals = 0;
+  for (uint32_t f = 0; f < n_frames; ++f) {
+    if (out[f].status != ILCC_OK) continue;
+    const uint32_t m = (uint32_t)(out[f].n_black + out[f].n_white);
+    max_lab = std::max(max_lab, m);
+    evals += (uint64_t)m * (uint64_t)h->p.n_th * h->p.n_ty * h->p.n_tz;
+  }
+  if (grid) {
+    t.grid_cost_launches += 1;
+    t.grid_cost_ms_sum += ms[4];
+    t.grid_cost_evals_sum += evals;
+  }
+  // adapt the K6 LDS staging size to the labelled-point counts actually seen (next call)
+  uint32_t want = 1024;
+  while (want < max_lab && want < (uint32_t)kGridLdsPointsMax) want <<= 1;
+  if (want > h->grid_lds_points) h->grid_lds_points = want;
+  return ILCC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t ilcc_abi_version(void) { return ILCC_ABI_VERSION; }
+
+const char* ilcc_strerror(int32_t status) {
+  switch (status) {
+    case ILCC_OK: return "ok";
+    case ILCC_NO_ROI_POINTS: return "no points inside the ROI box around the click";
+    case ILCC_NO_CLUSTER: return "no Euclidean cluster of admissible size";
+    case ILCC_NO_PLANE: return "could not estimate a planar model";
+    case ILCC_DEGENERATE_HIST: return "intensity histogram is degenerate (no bin on one side of the mean)";
+    case ILCC_TOO_FEW_POINTS: return "too few points";
+    case ILCC_BAD_ARGUMENT: return "bad argument";
+    case ILCC_CAPACITY: return "handle capacity exceeded";
+    case ILCC_HIP_ERROR: return "HIP runtime error";
+    case ILCC_IO_ERROR: return "file I/O error";
+    default: return "unknown status";
+  }
+}
+
+const char* ilcc_last_error(const ilcc_handle* h) { return h ? h->err.c_str() : g_err.c_str(); }
+
+void ilcc_default_params(ilcc_params* p) {
+  std::memset(p, 0, sizeof(*p));
+  p->roi_half[0] = 1.0;
+  p->roi_half[1] = 1.5;
+  p->roi_half[2] = 2.0;
+  p->cluster_tol = 0.12;
+  p->cluster_min = 100;
+  p->cluster_max = 25000;
+  p->ransac_thresh = 0.03;
+  p->ransac_hyp = 128;
+  p->ransac_seed = 12345u;
+  p->hist_bins = 100;
+  p->gray_rate = 2.5;
+  p->huber_delta = 0.1;
+  p->grid_length = 0.15;
+  p->board_w = 6;
+  p->board_h = 8;
+  p->solver = ILCC_SOLVER_GRID;
+  p->phase_mode = 2;
+  p->max_iterations = 50;
+  const double kPi = 3.14159265358979323846;
+  p->n_th = 61;
+  p->th_step = 0.5 * kPi / 180.0;
+  p->th_min = -15.0 * kPi / 180.0;
+  p->n_ty = 40;
+  p->ty_step = 0.15 / 20.0;
+  p->ty_min = -0.15;
+  p->n_tz = 40;
+  p->tz_step = 0.15 / 20.0;
+  p->tz_min = -0.15;
+}
+
+// Minimal OpenCV-FileStorage YAML reader for the three scalar keys the path uses
+// (cv::FileStorage is not available; /root/reference/ilcc2/config/pointgrey.yaml:17-19).
+int32_t ilcc_set_chessboard_param(ilcc_params* p, const char* cam_yaml) {
+  if (!p || !cam_yaml) return ILCC_BAD_ARGUMENT;
+  std::ifstream in(cam_yaml);
+  if (!in.is_open()) {
+    g_err = std::string("can not open ") + cam_yaml;   // LidarCornersEst.cpp:27
+    return ILCC_IO_ERROR;
+  }
+  double grid_length = -1;
+  long cx = -1, cy = -1;
+  std::string line;
+  while (std::getline(in, line)) {
+    const size_t hash = line.find('#');
+    if (hash != std::string::npos) line.erase(hash);
+    const size_t colon = line.find(':');
+    if (colon == std::string::npos) continue;
+    std::string key = line.substr(0, colon), val = line.substr(colon + 1);
+    auto trim = [](std::string& s) {
+      const size_t a = s.find_first_not_of(" \t\r\n");
+      const size_t b = s.find_last_not_of(" \t\r\n");
+      s = (a == std::string::npos) ? std::string() : s.substr(a, b - a + 1);
+    };
+    trim(key);
+    trim(val);
+    if (val.empty()) continue;
+    char* endp = nullptr;
+    if (key == "grid_length") grid_length = std::strtod(val.c_str(), &endp);
+    else if (key == "corner_in_x") cx = (long)std::strtod(val.c_str(), &endp);
+    else if (key == "corner_in_y") cy = (long)std::strtod(val.c_str(), &endp);
+  }
+  if (!(grid_length > 0) || cx < 1 || cy < 1) {
+    g_err = "grid_length / corner_in_x / corner_in_y missing or invalid";
+    return ILCC_BAD_ARGUMENT;
+  }
+  int32_t w = (int32_t)cx + 1, hh = (int32_t)cy + 1;   // :31-32
+  if (w > hh) std::swap(w, hh);                        // :35-39
+  // keep the default grid's meaning (one cell either way, g/20 steps) when the square size changes
+  const double scale = grid_length / p->grid_length;
+  p->grid_length = grid_length;
+  p->board_w = w;
+  p->board_h = hh;
+  if (scale > 0 && scale != 1.0) {
+    p->ty_min *= scale;
+    p->ty_step *= scale;
+    p->tz_min *= scale;
+    p->tz_step *= scale;
+  }
+  return ILCC_OK;
+}
+
+ilcc_handle* ilcc_create(int32_t device, const ilcc_params* p, uint32_t max_frames, uint64_t max_total_points) {
+  g_err.clear();
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+    g_err = "no HIP device: libilcc_hip has no CPU fallback";
+    return nullptr;
+  }
+  if (!p || max_frames == 0 || max_total_points == 0) {
+    g_err = "bad arguments to ilcc_create";
+    return nullptr;
+  }
+  std::string why;
+  if (!params_ok(*p, why)) {
+    g_err = why;
+    return nullptr;
+  }
+  ilcc_handle* h = new (std::nothrow) ilcc_handle();
+  if (!h) return nullptr;
+  h->p = *p;
+  h->max_frames = max_frames;
+  h->max_points = max_total_points;
+  h->max_theta = 4096;
+  auto fail = [&](const char* what, hipError_t e) {
+    g_err = std::string(what) + ": " + hipGetErrorString(e);
+    ilcc_destroy(h);
+    return (ilcc_handle*)nullptr;
+  };
+  hipError_t e;
+  if (device >= 0) {
+    if ((e = hipSetDevice(device)) != hipSuccess) return fail("hipSetDevice", e);
+    h->device = device;
+  } else {
+    (void)hipGetDevice(&h->device);
+  }
+  if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
+  for (auto& ev : h->ev)
+    if ((e = hipEventCreate(&ev)) != hipSuccess) return fail("hipEventCreate", e);
+  const uint64_t np = max_total_points;
+  h->crop_chunks_cap = (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, np / kCropChunk + (uint64_t)max_frames + 1);
+#define ALLOC(ptr, bytes)                                                     \
+  if ((e = hipMalloc((void**)&(ptr), (size_t)(bytes))) != hipSuccess) return fail("hipMalloc " #ptr, e)
+  ALLOC(h->d_xyzi, sizeof(float4) * np);
+  ALLOC(h->d_clicks, sizeof(float) * 3 * max_frames);
+  ALLOC(h->d_off, sizeof(uint64_t) * (max_frames + 1));
+  ALLOC(h->d_res, sizeof(ilcc_result) * max_frames);
+  ALLOC(h->d_roi, sizeof(float4) * np);
+  ALLOC(h->d_cluster, sizeof(float4) * np);
+  ALLOC(h->d_board, sizeof(float4) * np);
+  ALLOC(h->d_pca, sizeof(float4) * np);
+  ALLOC(h->d_optim, sizeof(float4) * np);
+  ALLOC(h->d_yz, sizeof(float2) * np);
+  ALLOC(h->d_lab, np);
+  ALLOC(h->d_nlab, sizeof(uint32_t) * max_frames);
+  ALLOC(h->d_counts, sizeof(uint32_t) * h->crop_chunks_cap);
+  ALLOC(h->d_parent, sizeof(uint32_t) * np);
+  ALLOC(h->d_count, sizeof(uint32_t) * np);
+  ALLOC(h->d_partial, sizeof(GridPartial) * (size_t)max_frames * h->max_theta);
+  ALLOC(h->d_cth, sizeof(float) * h->max_theta);
+  ALLOC(h->d_sth, sizeof(float) * h->max_theta);
+  ALLOC(h->d_ay, sizeof(float) * h->max_theta);
+  ALLOC(h->d_az, sizeof(float) * h->max_theta);
+  ALLOC(h->d_solve, sizeof(double) * 8);
+#undef ALLOC
+  if (upload_tables(h) != ILCC_OK) {
+    g_err = h->err;
+    ilcc_destroy(h);
+    return nullptr;
+  }
+  return h;
+}
+
+void ilcc_destroy(ilcc_handle* h) {
+  if (!h) return;
+  void* bufs[] = {h->d_xyzi, h->d_clicks, h->d_off,    h->d_res,    h->d_roi,   h->d_cluster, h->d_board,
+                  h->d_pca,  h->d_optim,  h->d_yz,     h->d_lab,    h->d_nlab,  h->d_counts,  h->d_parent,
+                  h->d_count, h->d_partial, h->d_cth,  h->d_sth,    h->d_ay,    h->d_az,      h->d_solve};
+  for (void* b : bufs)
+    if (b) (void)hipFree(b);
+  for (auto& ev : h->ev)
+    if (ev) (void)hipEventDestroy(ev);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+int32_t ilcc_set_params(ilcc_handle* h, const ilcc_params* p) {
+  if (!h || !p) return ILCC_BAD_ARGUMENT;
+  std::string why;
+  if (!params_ok(*p, why)) {
+    h->err = why;
+    return ILCC_BAD_ARGUMENT;
+  }
+  const ilcc_params old = h->p;
+  h->p = *p;
+  const int32_t st = upload_tables(h);
+  if (st != ILCC_OK) h->p = old;
+  return st;
+}
+
+int32_t ilcc_extract_batch_device(ilcc_handle* h, const float* d_xyzi, const uint64_t* offsets,
+                                  uint32_t n_frames, const float* d_clicks, ilcc_result* out) {
+  if (!h || !d_xyzi || !d_clicks || !out) return ILCC_BAD_ARGUMENT;
+  HIP_TRY(h, hipSetDevice(h->device));
+  const int32_t st = check_offsets(h, offsets, n_frames);
+  if (st != ILCC_OK) return st;
+  return run_pipeline(h, reinterpret_cast<const float4*>(d_xyzi), offsets, n_frames, d_clicks, out);
+}
+
+int32_t ilcc_extract_batch(ilcc_handle* h, const float* xyzi, const uint64_t* offsets, uint32_t n_frames,
+                           const float* clicks, ilcc_result* out) {
+  if (!h || !xyzi || !clicks || !out) return ILCC_BAD_ARGUMENT;
+  HIP_TRY(h, hipSetDevice(h->device));
+  const int32_t st = check_offsets(h, offsets, n_frames);
+  if (st != ILCC_OK) return st;
+  if (offsets[n_frames] > 0)
+    HIP_TRY(h, hipMemcpyAsync(h->d_xyzi, xyzi, sizeof(float4) * offsets[n_frames], hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(h->d_clicks, clicks, sizeof(float) * 3 * n_frames, hipMemcpyHostToDevice, h->stream));
+  return run_pipeline(h, h->d_xyzi, offsets, n_frames, h->d_clicks, out);
+}
+
+int32_t ilcc_extract(ilcc_handle* h, const float* xyzi, uint32_t n, const float click[3], ilcc_result* out) {
+  const uint64_t off[2] = {0, n};
+  return ilcc_extract_batch(h, xyzi, off, 1, click, out);
+}
+
+int64_t ilcc_fetch_cloud(ilcc_handle* h, uint32_t frame, int32_t which, float* out_xyzi, uint64_t cap_points) {
+  if (!h || frame >= h->n_frames) return -(int64_t)ILCC_BAD_ARGUMENT;
+  ilcc_result r;
+  if (hipMemcpy(&r, h->d_res + frame, sizeof(r), hipMemcpyDeviceToHost) != hipSuccess) return -(int64_t)ILCC_HIP_ERROR;
+  const float4* src = nullptr;
+  int64_t n = 0;
+  switch (which) {
+    case ILCC_CLOUD_ROI: src = h->d_roi; n = r.n_roi; break;
+    case ILCC_CLOUD_CLUSTER: src = h->d_cluster; n = r.n_cluster; break;
+    case ILCC_CLOUD_CHESSBOARD: src = h->d_board; n = r.n_plane; break;
+    case ILCC_CLOUD_PCA: src = h->d_pca; n = (r.status == ILCC_OK || r.status == ILCC_DEGENERATE_HIST) ? r.n_plane : 0; break;
+    case ILCC_CLOUD_OPTIM: src = h->d_optim; n = (r.status == ILCC_OK) ? r.n_plane : 0; break;
+    default: return -(int64_t)ILCC_BAD_ARGUMENT;
+  }
+  const int64_t m = std::min<int64_t>(n, (int64_t)cap_points);
+  if (m > 0 && out_xyzi &&
+      hipMemcpy(out_xyzi, src + h->off[frame], sizeof(float4) * (size_t)m, hipMemcpyDeviceToHost) != hipSuccess)
+    return -(int64_t)ILCC_HIP_ERROR;
+  return n;
+}
+
+int64_t ilcc_fetch_labelled(ilcc_handle* h, uint32_t frame, float* out_yz, uint8_t* out_label, uint64_t cap_points) {
+  if (!h || frame >= h->n_frames) return -(int64_t)ILCC_BAD_ARGUMENT;
+  uint32_t n = 0;
+  if (hipMemcpy(&n, h->d_nlab + frame, sizeof(n), hipMemcpyDeviceToHost) != hipSuccess) return -(int64_t)ILCC_HIP_ERROR;
+  const uint64_t m = std::min<uint64_t>(n, cap_points);
+  if (m > 0) {
+    if (out_yz && hipMemcpy(out_yz, h->d_yz + h->off[frame], sizeof(float2) * m, hipMemcpyDeviceToHost) != hipSuccess)
+      return -(int64_t)ILCC_HIP_ERROR;
+    if (out_label && hipMemcpy(out_label, h->d_lab + h->off[frame], m, hipMemcpyDeviceToHost) != hipSuccess)
+      return -(int64_t)ILCC_HIP_ERROR;
+  }
+  return (int64_t)n;
+}
+
+// shared setup for the two single-kernel test entries: frame 0 = caller's labelled points
+static int32_t stage_labelled(ilcc_handle* h, const float* yz, const uint8_t* label, uint32_t m) {
+  if (!h || (m > 0 && (!yz || !label))) return ILCC_BAD_ARGUMENT;
+  if (m > h->max_points) {
+    h->err = "more points than the handle holds";
+    return ILCC_CAPACITY;
+  }
+  HIP_TRY(h, hipSetDevice(h->device));
+  hipStream_t s = h->stream;
+  const uint64_t off[2] = {0, m};
+  ilcc_result r;
+  std::memset(&r, 0, sizeof(r));
+  r.status = ILCC_OK;
+  HIP_TRY(h, hipMemcpyAsync(h->d_off, off, sizeof(off), hipMemcpyHostToDevice, s));
+  HIP_TRY(h, hipMemcpyAsync(h->d_res, &r, sizeof(r), hipMemcpyHostToDevice, s));
+  HIP_TRY(h, hipMemcpyAsync(h->d_nlab, &m, sizeof(m), hipMemcpyHostToDevice, s));
+  if (m > 0) {
+    HIP_TRY(h, hipMemcpyAsync(h->d_yz, yz, sizeof(float2) * m, hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(h->d_lab, label, m, hipMemcpyHostToDevice, s));
+  }
+  HIP_TRY(h, hipStreamSynchronize(s));
+  h->n_frames = 0;
+  return ILCC_OK;
+}
+
+int32_t ilcc_grid_cost(ilcc_handle* h, const float* yz, const uint8_t* label, uint32_t m, int32_t use_oob,
+                       float* cost_out, int32_t* best_index, float* best_cost) {
+  int32_t st = stage_labelled(h, yz, label, m);
+  if (st != ILCC_OK) return st;
+  hipStream_t s = h->stream;
+  const size_t vol = (size_t)h->p.n_th * h->p.n_ty * h->p.n_tz * 2;
+  float* d_vol = nullptr;
+  if (cost_out) HIP_TRY(h, hipMalloc((void**)&d_vol, sizeof(float) * vol));
+  uint32_t lds = 1024;
+  while (lds < m && lds < (uint32_t)kGridLdsPointsMax) lds <<= 1;
+  const uint32_t saved = h->grid_lds_points;
+  h->grid_lds_points = std::max(saved, lds);
+  const Ctx c = make_ctx(h, nullptr, nullptr, 1, 1);
+  h->grid_lds_points = saved;
+  launch_grid_cost(c, s, use_oob, d_vol);
+  std::vector<GridPartial> part(c.grid_blocks);
+  hipError_t e = hipMemcpyAsync(part.data(), h->d_partial, sizeof(GridPartial) * c.grid_blocks, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess && cost_out) e = hipMemcpyAsync(cost_out, d_vol, sizeof(float) * vol, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  if (d_vol) (void)hipFree(d_vol);
+  if (e != hipSuccess) {
+    h->err = std::string("ilcc_grid_cost: ") + hipGetErrorString(e);
+    return ILCC_HIP_ERROR;
+  }
+  GridPartial b = part[0];
+  for (uint32_t k = 1; k < c.grid_blocks; ++k) {
+    const GridPartial& t = part[k];
+    if (t.cost < b.cost || (t.cost == b.cost && (t.d2 < b.d2 || (t.d2 == b.d2 && t.flat < b.flat)))) b = t;
+  }
+  if (best_index) *best_index = (int32_t)b.flat;
+  if (best_cost) *best_cost = b.cost;
+  return ILCC_OK;
+}
+
+int32_t ilcc_get_theta_t(ilcc_handle* h, const float* yz, const uint8_t* label, uint32_t m, int32_t topleft_white,
+                         int32_t use_oob, double theta_t[3], double* cost, int32_t* iterations) {
+  if (!theta_t) return ILCC_BAD_ARGUMENT;
+  int32_t st = stage_labelled(h, yz, label, m);
+  if (st != ILCC_OK) return st;
+  hipStream_t s = h->stream;
+  HIP_TRY(h, hipMemcpyAsync(h->d_solve, theta_t, sizeof(double) * 3, hipMemcpyHostToDevice, s));
+  const Ctx c = make_ctx(h, nullptr, nullptr, 1, 1);
+  launch_local_solve(c, s, topleft_white, use_oob, h->d_solve, h->d_solve + 3);
+  double back[5];
+  HIP_TRY(h, hipMemcpyAsync(back, h->d_solve, sizeof(back), hipMemcpyDeviceToHost, s));
+  HIP_TRY(h, hipStreamSynchronize(s));
+  theta_t[0] = back[0];
+  theta_t[1] = back[1];
+  theta_t[2] = back[2];
+  if (cost) *cost = back[3];
+  if (iterations) *iterations = (int32_t)back[4];
+  return ILCC_OK;
+}
+
+void ilcc_get_timing(const ilcc_handle* h, ilcc_timing* t) {
+  if (h && t) *t = h->timing;
+}
+void ilcc_reset_timing(ilcc_handle* h) {
+  if (h) h->timing = ilcc_timing{};
+}
+
+// get_lidar_corners.cpp:27-36 -- ofstream(trunc), `x << " " << y << " " << z << endl` with the
+// stream's default float formatting (precision 6).
+int32_t ilcc_save_corners2txt(const float* corners_xyz, uint32_t n_corners, const char* filename) {
+  if (!corners_xyz || !filename) return ILCC_BAD_ARGUMENT;
+  std::ofstream outfile(filename, std::ios_base::trunc);
+  if (!outfile.is_open()) return ILCC_IO_ERROR;
+  for (uint32_t i = 0; i < n_corners; ++i)
+    outfile << corners_xyz[3 * i] << " " << corners_xyz[3 * i + 1] << " " << corners_xyz[3 * i + 2] << std::endl;
+  outfile.close();
+  return outfile.fail() ? ILCC_IO_ERROR : ILCC_OK;
+}
+
+// ImageCornersEst.cpp:281-299 -- `float x,y,z; infile >> x >> y >> z` until eof or num corners
+int32_t ilcc_read_lidar_corners(const char* filename, uint32_t num, double* out_xyz) {
+  if (!filename || !out_xyz) return -ILCC_BAD_ARGUMENT;
+  std::ifstream infile(filename);
+  if (!infile.is_open()) return -ILCC_IO_ERROR;
+  uint32_t counter = 0;
+  while (!infile.eof() && counter < num) {
+    float x = 0, y = 0, z = 0;
+    infile >> x >> y >> z;
+    if (infile.fail()) break;
+    out_xyz[3 * counter] = x;
+    out_xyz[3 * counter + 1] = y;
+    out_xyz[3 * counter + 2] = z;
+    ++counter;
+  }
+  return (int32_t)counter;
+}
+
+}  // extern "C"

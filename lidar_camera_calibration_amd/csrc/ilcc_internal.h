@@ -1,0 +1,127 @@
+// ilcc_internal.h -- device-side context, block/wave utilities shared by the stage kernels.
+// gfx950 only: wavefront = 64 lanes, 4 SIMD-32 per CU, 160 KiB LDS per CU.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ilcc_hip.h"
+
+#define ILCC_WAVE 64
+
+namespace ilcc {
+
+// block sizes (multiples of the 64-lane wavefront)
+constexpr int kCropThreads = 256;      // K1
+constexpr int kCropChunk = 4096;       // points per K1 block
+constexpr int kFrameThreads = 1024;    // K2..K5, K7: one workgroup per frame
+constexpr int kGridThreads = 256;      // K6: 4 wavefronts per workgroup
+constexpr int kTileA = 4;              // K6 candidate tile: ty values per wavefront pass
+constexpr int kTileB = 4;              // K6 candidate tile: tz values per wavefront pass
+constexpr int kGridLdsPointsMax = 16384;  // K6 LDS staging upper bound (9 B per point -> 144 KiB)
+constexpr int kSolveThreads = 256;     // K7: 4 wavefronts per frame
+constexpr int kClusterLdsParents = 16384;  // K2 union-find parents kept in LDS (64 KiB)
+
+struct GridPartial {   // per K6 workgroup best candidate
+  float cost;
+  uint32_t d2;         // squared index distance to the candidate nearest (0,0,0)
+  uint32_t flat;       // ((k*n_ty+a)*n_tz+b)*2+phase
+  uint32_t pad;
+};
+
+// everything a kernel needs, passed by value
+struct Ctx {
+  // inputs
+  const float4* xyzi;        // all frames, packed
+  const uint64_t* off;       // n_frames+1 point offsets (device copy)
+  const float* clicks;       // n_frames x 3
+  uint32_t n_frames;
+  uint32_t crop_chunks;      // K1 chunks per frame (max over frames)
+  // per-frame records
+  ilcc_result* res;
+  // stage buffers, all indexed with the input offsets (capacity of a frame = its input size)
+  float4* roi;
+  float4* cluster;
+  float4* board;             // m_cloud_chessboard
+  float4* pca;               // m_cloud_PCA
+  float4* optim;             // m_cloud_optim
+  float2* yz;                // labelled (non-gray) points, plane-frame y,z
+  uint8_t* lab;              // 0 black, 1 white
+  uint32_t* n_lab;           // per frame
+  uint32_t* crop_counts;     // n_frames x crop_chunks
+  uint32_t* uf_parent;       // K2 scratch (global fallback / labels)
+  uint32_t* uf_count;        // K2 component sizes
+  GridPartial* partial;      // n_frames x grid_blocks
+  uint32_t grid_blocks;      // K6 workgroups per frame
+  uint32_t grid_lds_points;  // K6 points staged in LDS per workgroup (multiple of 64)
+  // candidate tables (device)
+  const float* cth;          // cos(theta_k)/g
+  const float* sth;          // sin(theta_k)/g
+  const float* ay;           // (ty_a + W g/2)/g
+  const float* az;           // (tz_b + H g/2)/g
+  // parameters
+  ilcc_params p;
+  int32_t c_th, c_ty, c_tz;  // index of the candidate nearest zero on each axis
+};
+
+// ---------------------------------------------------------------- wave / block helpers
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (ILCC_WAVE - 1); }
+__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+  for (int o = ILCC_WAVE / 2; o > 0; o >>= 1) v += __shfl_down(v, o, ILCC_WAVE);
+  return v;  // valid in lane 0
+}
+
+// sum over the whole workgroup; result broadcast to every thread. scratch: >= 17 T in LDS.
+// Fixed combination order (lane tree, then wavefronts in index order) -> deterministic.
+template <typename T>
+__device__ __forceinline__ T block_sum(T v, T* scratch) {
+  v = wave_sum(v);
+  const int nw = (blockDim.x + ILCC_WAVE - 1) / ILCC_WAVE;
+  __syncthreads();
+  if (lane_id() == 0) scratch[wave_id()] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    T s = scratch[0];
+    for (int w = 1; w < nw; ++w) s += scratch[w];
+    scratch[16] = s;
+  }
+  __syncthreads();
+  return scratch[16];
+}
+
+// exclusive scan of 0/1 flags over the workgroup (thread order); returns rank, total via ref.
+// scratch: >= 17 uint32 in LDS.
+__device__ __forceinline__ uint32_t block_rank(bool flag, uint32_t* scratch, uint32_t& total) {
+  const unsigned long long m = __ballot(flag);
+  const int lane = lane_id();
+  const uint32_t in_wave = __popcll(m & ((1ull << lane) - 1ull));
+  const int nw = (blockDim.x + ILCC_WAVE - 1) / ILCC_WAVE;
+  __syncthreads();
+  if (lane == 0) scratch[wave_id()] = __popcll(m);
+  __syncthreads();
+  uint32_t base = 0, tot = 0;
+  for (int w = 0; w < nw; ++w) {
+    const uint32_t c = scratch[w];
+    if (w < wave_id()) base += c;
+    tot += c;
+  }
+  total = tot;
+  return base + in_wave;
+}
+
+// ---------------------------------------------------------------- launchers (one per stage TU)
+void launch_roi_crop(const Ctx& c, hipStream_t s);
+void launch_cluster(const Ctx& c, hipStream_t s);
+void launch_ransac_plane(const Ctx& c, hipStream_t s);
+void launch_plane_frame_hist(const Ctx& c, hipStream_t s);
+void launch_grid_cost(const Ctx& c, hipStream_t s, int32_t use_oob, float* cost_volume /*nullable*/);
+void launch_refine_corners(const Ctx& c, hipStream_t s);
+// stand-alone local solve on the labelled points of frame 0 (test entry)
+void launch_local_solve(const Ctx& c, hipStream_t s, int32_t tlw, int32_t use_oob, double* theta_t,
+                        double* cost_iters /*[2]: cost, iterations*/);
+
+}  // namespace ilcc

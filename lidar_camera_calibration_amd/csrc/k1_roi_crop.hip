@@ -1,0 +1,119 @@
+// K1 roi_crop_compact -- replaces the three pcl::PassThrough passes of LidarCornersEst::setROI
+// (/root/reference/ilcc2/src/LidarCornersEst.cpp:48-70).
+//
+// HBM-bound: every input point (16 B XYZI, float4, coalesced 1 KiB per wavefront load) is read
+// once per kernel; survivors (a few thousand per frame) are written in input order.
+// Two kernels: count per 4096-point chunk, then an order-preserving scatter whose base is the
+// prefix of the chunk counts.  The second read of the cloud is served by the 256 MiB
+// Infinity Cache for the batch sizes of BASELINE.json (128 x 460 KB = 59 MB).
+// Launch: grid = (chunks, frames) -> >= 1024 workgroups for a 128-frame VLP-16 batch.
+#include "ilcc_internal.h"
+
+namespace ilcc {
+
+struct Box {
+  float lo[3], hi[3];
+};
+
+// pcl::PassThrough::setFilterLimits narrows to float: (float)(double(click) -+ half)
+__device__ __forceinline__ Box make_box(const Ctx& c, uint32_t f) {
+  Box b;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const double cl = (double)c.clicks[3 * f + a];
+    b.lo[a] = (float)(cl - c.p.roi_half[a]);
+    b.hi[a] = (float)(cl + c.p.roi_half[a]);
+  }
+  return b;
+}
+
+__device__ __forceinline__ bool keep_point(const float4 q, const Box& b) {
+  // non-finite x/y/z are dropped by every PassThrough; limits are inclusive (:54,59,64)
+  const bool fin = isfinite(q.x) && isfinite(q.y) && isfinite(q.z);
+  const bool in = !(q.z < b.lo[2] || q.z > b.hi[2]) && !(q.x < b.lo[0] || q.x > b.hi[0]) &&
+                  !(q.y < b.lo[1] || q.y > b.hi[1]);
+  return fin && in;
+}
+
+__global__ __launch_bounds__(kCropThreads) void k1_roi_count(Ctx c) {
+  const uint32_t f = blockIdx.y, s = blockIdx.x;
+  const uint64_t beg = c.off[f], end = c.off[f + 1];
+  const uint64_t n = end - beg;
+  if (s == 0 && threadIdx.x == 0) {
+    // fresh per-frame record
+    ilcc_result* r = &c.res[f];
+    r->status = ILCC_OK;
+    r->n_points = (int32_t)n;
+    r->n_roi = r->n_cluster = r->n_plane = 0;
+    r->n_black = r->n_gray = r->n_white = 0;
+    r->n_corners = 0;
+    r->phase = 0;
+    r->iters_a = r->iters_b = 0;
+    r->grid_index = -1;
+    r->grid_cost = 0.f;
+    r->cost_a = r->cost_b = r->sel_cost = 0.0;
+    r->theta_t[0] = r->theta_t[1] = r->theta_t[2] = 0.0;
+    c.n_lab[f] = 0;
+  }
+  const uint64_t cbeg = (uint64_t)s * kCropChunk;
+  uint32_t cnt = 0;
+  if (cbeg < n) {
+    const Box b = make_box(c, f);
+    const uint64_t cend = (cbeg + kCropChunk < n) ? cbeg + kCropChunk : n;
+    const float4* __restrict__ src = c.xyzi + beg;
+#pragma unroll 4
+    for (uint64_t i = cbeg + threadIdx.x; i < cend; i += kCropThreads) {
+      const float4 q = src[i];
+      cnt += keep_point(q, b) ? 1u : 0u;
+    }
+  }
+  __shared__ uint32_t sc[17];
+  const uint32_t total = block_sum<uint32_t>(cnt, sc);
+  if (threadIdx.x == 0) c.crop_counts[(uint64_t)f * c.crop_chunks + s] = total;
+}
+
+__global__ __launch_bounds__(kCropThreads) void k1_roi_scatter(Ctx c) {
+  const uint32_t f = blockIdx.y, s = blockIdx.x;
+  const uint64_t beg = c.off[f], end = c.off[f + 1];
+  const uint64_t n = end - beg;
+  const uint32_t* counts = c.crop_counts + (uint64_t)f * c.crop_chunks;
+  uint32_t base = 0, all = 0;
+  for (uint32_t k = 0; k < c.crop_chunks; ++k) {
+    const uint32_t v = counts[k];
+    if (k < s) base += v;
+    all += v;
+  }
+  if (s == 0 && threadIdx.x == 0) {
+    c.res[f].n_roi = (int32_t)all;
+    if (all == 0) c.res[f].status = ILCC_NO_ROI_POINTS;
+  }
+  const uint64_t cbeg = (uint64_t)s * kCropChunk;
+  if (cbeg >= n) return;
+  const Box b = make_box(c, f);
+  const uint64_t cend = (cbeg + kCropChunk < n) ? cbeg + kCropChunk : n;
+  const float4* __restrict__ src = c.xyzi + beg;
+  float4* __restrict__ dst = c.roi + beg;
+  __shared__ uint32_t sc[17];
+  uint32_t running = base;
+  for (uint64_t t = cbeg; t < cend; t += kCropThreads) {  // uniform trip count per workgroup
+    const uint64_t i = t + threadIdx.x;
+    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+    bool keep = false;
+    if (i < cend) {
+      q = src[i];
+      keep = keep_point(q, b);
+    }
+    uint32_t tot;
+    const uint32_t rank = block_rank(keep, sc, tot);
+    if (keep) dst[running + rank] = q;
+    running += tot;
+  }
+}
+
+void launch_roi_crop(const Ctx& c, hipStream_t s) {
+  const dim3 grid(c.crop_chunks, c.n_frames);
+  hipLaunchKernelGGL(k1_roi_count, grid, dim3(kCropThreads), 0, s, c);
+  hipLaunchKernelGGL(k1_roi_scatter, grid, dim3(kCropThreads), 0, s, c);
+}
+
+}  // namespace ilcc

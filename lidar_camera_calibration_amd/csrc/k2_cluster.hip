@@ -1,0 +1,253 @@
+// K2 seeded_cluster -- replaces pcl::EuclideanClusterExtraction + nearestKSearch of
+// LidarCornersEst::EuclideanCluster (/root/reference/ilcc2/src/LidarCornersEst.cpp:124-153).
+//
+// One 1024-thread workgroup per frame.  Single-linkage components of the radius graph
+// (squared float distance dx*dx+dy*dy+dz*dz < (float)(tol*tol), FLANN's strict test) are
+// built with a lock-free union-find whose parents live in LDS (<= 16384 ROI points, else a
+// global scratch array); neighbours are found by tiled all-pairs: 1024 "j" points staged in
+// LDS per tile, every lane holds its own "i" point in registers, LDS reads are wave-uniform
+// (broadcast).  Roots are always the smallest member index, so the labelling is
+// deterministic.  Cluster choice follows the reference: components with
+// cluster_min <= size <= cluster_max, sorted by size (largest = index 0); the one containing
+// the exact 1-NN of the click wins, otherwise index 0.  Members are emitted in index order.
+#include "ilcc_internal.h"
+
+namespace ilcc {
+
+template <typename P>
+__device__ __forceinline__ uint32_t uf_find(P* parent, uint32_t x) {
+  for (;;) {
+    const uint32_t p = __hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (p == x) return x;
+    x = p;
+  }
+}
+
+template <typename P>
+__device__ __forceinline__ void uf_unite(P* parent, uint32_t a, uint32_t b) {
+  for (;;) {
+    a = uf_find(parent, a);
+    b = uf_find(parent, b);
+    if (a == b) return;
+    if (a < b) {
+      const uint32_t t = a;
+      a = b;
+      b = t;
+    }
+    // hook the larger root under the smaller one
+    const uint32_t old = atomicCAS(&parent[a], a, b);
+    if (old == a) return;
+  }
+}
+
+struct NnKey {
+  float d2;
+  uint32_t idx;
+};
+__device__ __forceinline__ bool nn_less(const NnKey& x, const NnKey& y) {
+  return x.d2 < y.d2 || (x.d2 == y.d2 && x.idx < y.idx);
+}
+
+template <bool LDS_PARENT>
+__device__ void cluster_frame(const Ctx& c, uint32_t f, uint32_t* lds_parent, float4* tile,
+                              uint32_t* sc) {
+  ilcc_result* r = &c.res[f];
+  if (r->status != ILCC_OK) return;
+  const uint32_t M = (uint32_t)r->n_roi;
+  const uint64_t beg = c.off[f];
+  const float4* __restrict__ P = c.roi + beg;
+  uint32_t* gparent = c.uf_parent + beg;
+  uint32_t* parent = LDS_PARENT ? lds_parent : gparent;
+  uint32_t* count = c.uf_count + beg;   // zeroed by the host before the launch
+  const float tol2 = (float)(c.p.cluster_tol * c.p.cluster_tol);
+  const uint32_t tid = threadIdx.x;
+
+  for (uint32_t i = tid; i < M; i += kFrameThreads) parent[i] = i;
+  __syncthreads();
+
+  // ---- all pairs (j < i), tiles of 1024
+  for (uint32_t ic = 0; ic < M; ic += kFrameThreads) {
+    const uint32_t i = ic + tid;
+    const bool vi = i < M;
+    const float4 pi = vi ? P[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (uint32_t jc = 0; jc <= ic; jc += kFrameThreads) {
+      __syncthreads();
+      if (jc + tid < M) tile[tid] = P[jc + tid];
+      __syncthreads();
+      uint32_t lim = (M - jc < (uint32_t)kFrameThreads) ? M - jc : (uint32_t)kFrameThreads;
+      if (jc == ic) lim = (tid < lim) ? tid : lim;   // only j < i inside the diagonal tile
+      if (!vi) lim = 0;
+      // wave-uniform upper bound so that LDS reads stay broadcast; lanes mask themselves out
+      uint32_t wlim = lim;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t t = __shfl_xor(wlim, o, ILCC_WAVE);
+        wlim = t > wlim ? t : wlim;
+      }
+      for (uint32_t jj = 0; jj < wlim; ++jj) {
+        const float4 q = tile[jj];
+        const float dx = q.x - pi.x, dy = q.y - pi.y, dz = q.z - pi.z;
+        float d2 = dx * dx;
+        d2 = d2 + dy * dy;
+        d2 = d2 + dz * dz;
+        if (jj < lim && d2 < tol2) uf_unite(parent, i, jc + jj);
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- flatten: label = root (smallest member index)
+  for (uint32_t base = 0; base < M; base += kFrameThreads) {
+    const uint32_t i = base + tid;
+    uint32_t root = 0;
+    if (i < M) root = uf_find(parent, i);
+    __syncthreads();
+    if (i < M) {
+      parent[i] = root;
+      if (LDS_PARENT) gparent[i] = root;   // labels kept in global for the fetch/debug path
+    }
+    __syncthreads();
+  }
+
+  // ---- component sizes (wave-aggregated atomics on the root's counter)
+  for (uint32_t base = 0; base < M; base += kFrameThreads) {
+    const uint32_t i = base + tid;
+    const bool v = i < M;
+    const uint32_t lab = v ? parent[i] : 0xFFFFFFFFu;
+    unsigned long long todo = __ballot(v);
+    while (todo) {
+      const int leader = __ffsll((long long)todo) - 1;
+      const uint32_t ll = __shfl(lab, leader, ILCC_WAVE);
+      const unsigned long long same = __ballot(v && lab == ll);
+      if (lane_id() == leader) atomicAdd(&count[ll], (uint32_t)__popcll(same));
+      todo &= ~same;
+    }
+  }
+  __syncthreads();
+
+  // ---- exact 1-NN of the click (float squared distance, ties -> lowest index)
+  const float cx = c.clicks[3 * f], cy = c.clicks[3 * f + 1], cz = c.clicks[3 * f + 2];
+  NnKey best{3.402823466e38f, 0xFFFFFFFFu};
+  for (uint32_t i = tid; i < M; i += kFrameThreads) {
+    const float4 q = P[i];
+    const float dx = q.x - cx, dy = q.y - cy, dz = q.z - cz;
+    float d2 = dx * dx;
+    d2 = d2 + dy * dy;
+    d2 = d2 + dz * dz;
+    const NnKey k{d2, i};
+    if (nn_less(k, best)) best = k;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    NnKey t;
+    t.d2 = __shfl_down(best.d2, o, ILCC_WAVE);
+    t.idx = __shfl_down(best.idx, o, ILCC_WAVE);
+    if (nn_less(t, best)) best = t;
+  }
+  float* scf = reinterpret_cast<float*>(sc);
+  if (lane_id() == 0) {
+    scf[wave_id()] = best.d2;
+    sc[16 + wave_id()] = best.idx;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    NnKey b{scf[0], sc[16]};
+    for (int w = 1; w < kFrameThreads / ILCC_WAVE; ++w) {
+      const NnKey k{scf[w], sc[16 + w]};
+      if (nn_less(k, b)) b = k;
+    }
+    sc[32] = b.idx;
+  }
+  __syncthreads();
+  const uint32_t nn = sc[32];
+  const uint32_t nn_label = parent[nn];
+
+  // ---- largest valid component (ties -> smallest root), i.e. sorted index 0
+  const uint32_t cmin = (uint32_t)c.p.cluster_min, cmax = (uint32_t)c.p.cluster_max;
+  uint32_t bsz = 0, broot = 0xFFFFFFFFu;
+  for (uint32_t i = tid; i < M; i += kFrameThreads) {
+    if (parent[i] != i) continue;
+    const uint32_t sz = __hip_atomic_load(&count[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (sz < cmin || sz > cmax) continue;
+    if (sz > bsz || (sz == bsz && i < broot)) {
+      bsz = sz;
+      broot = i;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const uint32_t s2 = __shfl_down(bsz, o, ILCC_WAVE);
+    const uint32_t r2 = __shfl_down(broot, o, ILCC_WAVE);
+    if (s2 > bsz || (s2 == bsz && r2 < broot)) {
+      bsz = s2;
+      broot = r2;
+    }
+  }
+  __syncthreads();
+  if (lane_id() == 0) {
+    sc[wave_id()] = bsz;
+    sc[16 + wave_id()] = broot;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t s0 = sc[0], r0 = sc[16];
+    for (int w = 1; w < kFrameThreads / ILCC_WAVE; ++w) {
+      const uint32_t s2 = sc[w], r2 = sc[16 + w];
+      if (s2 > s0 || (s2 == s0 && r2 < r0)) {
+        s0 = s2;
+        r0 = r2;
+      }
+    }
+    const uint32_t nsz = __hip_atomic_load(&count[nn_label], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t chosen = r0;                                   // plane_index = 0
+    if (nsz >= cmin && nsz <= cmax) chosen = nn_label;      // cluster containing the click's NN
+    sc[33] = chosen;
+    sc[34] = (s0 == 0) ? 0u : 1u;
+  }
+  __syncthreads();
+  const uint32_t chosen = sc[33];
+  const bool any = sc[34] != 0;
+  if (!any) {
+    if (tid == 0) r->status = ILCC_NO_CLUSTER;
+    return;
+  }
+
+  // ---- stable compaction of the chosen component
+  float4* __restrict__ dst = c.cluster + beg;
+  uint32_t running = 0;
+  for (uint32_t base = 0; base < M; base += kFrameThreads) {
+    const uint32_t i = base + tid;
+    const bool keep = (i < M) && parent[i] == chosen;
+    uint32_t tot;
+    const uint32_t rank = block_rank(keep, sc + 40, tot);
+    if (keep) dst[running + rank] = P[i];
+    running += tot;
+  }
+  if (tid == 0) r->n_cluster = (int32_t)running;
+}
+
+__global__ __launch_bounds__(kFrameThreads) void k2_seeded_cluster(Ctx c) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  float4* tile = reinterpret_cast<float4*>(smem);                          // 16 KiB
+  uint32_t* sc = reinterpret_cast<uint32_t*>(smem + sizeof(float4) * kFrameThreads);  // 64 words
+  uint32_t* lds_parent = sc + 64;                                           // 64 KiB
+  const uint32_t f = blockIdx.x;
+  const uint32_t M = (uint32_t)c.res[f].n_roi;
+  if (M <= (uint32_t)kClusterLdsParents)
+    cluster_frame<true>(c, f, lds_parent, tile, sc);
+  else
+    cluster_frame<false>(c, f, lds_parent, tile, sc);
+}
+
+void launch_cluster(const Ctx& c, hipStream_t s) {
+  const size_t lds = sizeof(float4) * kFrameThreads + 64 * sizeof(uint32_t) +
+                     sizeof(uint32_t) * kClusterLdsParents;
+  static bool attr_done = false;
+  if (!attr_done) {   // 80 KiB of dynamic LDS (> the 64 KiB default cap)
+    (void)hipFuncSetAttribute((const void*)k2_seeded_cluster, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(k2_seeded_cluster, dim3(c.n_frames), dim3(kFrameThreads), lds, s, c);
+}
+
+}  // namespace ilcc

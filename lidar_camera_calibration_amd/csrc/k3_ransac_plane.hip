@@ -1,0 +1,205 @@
+// K3 ransac_plane -- replaces pcl::SACSegmentation (SACMODEL_PLANE, SAC_RANSAC, threshold
+// 0.03 m, optimize coefficients) of LidarCornersEst::getPlane
+// (/root/reference/ilcc2/src/LidarCornersEst.cpp:190-221).
+//
+// One 1024-thread workgroup per frame (16 wavefronts).  Each wavefront scores whole
+// hypotheses: the three sample indices come from a counter-based hash (PCL's boost::mt19937
+// stream cannot be reproduced without PCL), every lane strides over the cluster points and
+// the inlier count (|n.p+d| < thr, strict, float, unfused) is reduced with ballot/popcount.
+// Winner = most inliers, ties -> lowest hypothesis index.  Then PCL's refinement:
+// PCA plane of the inliers (double accumulation, Jacobi eigen-solver) and re-selection of
+// the inliers with the refined plane, emitted in input order (= m_cloud_chessboard).
+#include "eig3.h"
+#include "ilcc_internal.h"
+
+namespace ilcc {
+
+__device__ __forceinline__ uint32_t hash_u32(uint32_t x) {
+  x ^= x >> 16;
+  x *= 0x7feb352dU;
+  x ^= x >> 15;
+  x *= 0x846ca68bU;
+  x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ uint32_t sample_index(uint32_t seed, uint32_t h, uint32_t k, uint32_t m) {
+  const uint32_t r = hash_u32(seed ^ hash_u32(h * 3u + k + 0x9E3779B9u));
+  return (uint32_t)(((uint64_t)r * (uint64_t)m) >> 32);
+}
+
+__device__ __forceinline__ bool plane_from_3(const float4 p0, const float4 p1, const float4 p2,
+                                             float pl[4]) {
+  const float ax = p1.x - p0.x, ay = p1.y - p0.y, az = p1.z - p0.z;
+  const float bx = p2.x - p0.x, by = p2.y - p0.y, bz = p2.z - p0.z;
+  float nx = ay * bz - az * by;
+  float ny = az * bx - ax * bz;
+  float nz = ax * by - ay * bx;
+  float n2 = nx * nx;
+  n2 = n2 + ny * ny;
+  n2 = n2 + nz * nz;
+  if (!(n2 > 1e-12f)) return false;
+  const float nrm = sqrtf(n2);
+  nx = nx / nrm;
+  ny = ny / nrm;
+  nz = nz / nrm;
+  float d = nx * p0.x;
+  d = d + ny * p0.y;
+  d = d + nz * p0.z;
+  pl[0] = nx;
+  pl[1] = ny;
+  pl[2] = nz;
+  pl[3] = -d;
+  return true;
+}
+
+__device__ __forceinline__ float plane_dist(const float pl[4], const float4 q) {
+  float s = pl[0] * q.x;
+  s = s + pl[1] * q.y;
+  s = s + pl[2] * q.z;
+  s = s + pl[3];
+  return fabsf(s);
+}
+
+__global__ __launch_bounds__(kFrameThreads) void k3_ransac_plane(Ctx c) {
+  __shared__ uint32_t sc[64];
+  __shared__ double scd[17];
+  __shared__ float s_plane[4];
+  const uint32_t f = blockIdx.x;
+  ilcc_result* r = &c.res[f];
+  if (r->status != ILCC_OK) return;
+  const uint32_t M = (uint32_t)r->n_cluster;
+  const uint64_t beg = c.off[f];
+  const float4* __restrict__ P = c.cluster + beg;
+  const uint32_t tid = threadIdx.x;
+  const int lane = lane_id(), wid = wave_id();
+  const float thr = (float)c.p.ransac_thresh;
+  if (M < 3) {
+    if (tid == 0) r->status = ILCC_NO_PLANE;
+    return;
+  }
+
+  // ---- score hypotheses, one per wavefront pass
+  uint32_t best_cnt = 0, best_h = 0xFFFFFFFFu;
+  for (uint32_t h = (uint32_t)wid; h < (uint32_t)c.p.ransac_hyp; h += kFrameThreads / ILCC_WAVE) {
+    const uint32_t i0 = sample_index(c.p.ransac_seed, h, 0, M);
+    const uint32_t i1 = sample_index(c.p.ransac_seed, h, 1, M);
+    const uint32_t i2 = sample_index(c.p.ransac_seed, h, 2, M);
+    float pl[4];
+    if (i0 == i1 || i0 == i2 || i1 == i2) continue;
+    if (!plane_from_3(P[i0], P[i1], P[i2], pl)) continue;
+    uint32_t cnt = 0;
+    for (uint32_t base = 0; base < M; base += ILCC_WAVE) {
+      const uint32_t i = base + lane;
+      const bool in = (i < M) && plane_dist(pl, P[i]) < thr;
+      cnt += (uint32_t)__popcll(__ballot(in));
+    }
+    if (cnt > best_cnt) {   // h ascending within a wavefront: ties keep the lowest h
+      best_cnt = cnt;
+      best_h = h;
+    }
+  }
+  if (lane == 0) {
+    sc[wid] = best_cnt;
+    sc[16 + wid] = best_h;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t bc = 0, bh = 0xFFFFFFFFu;
+    for (int w = 0; w < kFrameThreads / ILCC_WAVE; ++w)
+      if (sc[w] > bc || (sc[w] == bc && sc[w] > 0 && sc[16 + w] < bh)) {
+        bc = sc[w];
+        bh = sc[16 + w];
+      }
+    sc[32] = bc;
+    sc[33] = bh;
+    if (bc > 0) {
+      float pl[4];
+      plane_from_3(P[sample_index(c.p.ransac_seed, bh, 0, M)], P[sample_index(c.p.ransac_seed, bh, 1, M)],
+                   P[sample_index(c.p.ransac_seed, bh, 2, M)], pl);
+      for (int k = 0; k < 4; ++k) s_plane[k] = pl[k];
+    }
+  }
+  __syncthreads();
+  const uint32_t bc = sc[32];
+  if (bc == 0) {
+    if (tid == 0) r->status = ILCC_NO_PLANE;
+    return;
+  }
+  float pl[4] = {s_plane[0], s_plane[1], s_plane[2], s_plane[3]};
+
+  // ---- optimizeModelCoefficients: PCA plane of the inliers (needs > 3 of them)
+  if (bc > 3) {
+    double sx = 0, sy = 0, sz = 0;
+    for (uint32_t i = tid; i < M; i += kFrameThreads) {
+      const float4 q = P[i];
+      if (plane_dist(pl, q) < thr) {
+        sx += q.x;
+        sy += q.y;
+        sz += q.z;
+      }
+    }
+    const double cx = block_sum<double>(sx, scd) / bc;
+    const double cy = block_sum<double>(sy, scd) / bc;
+    const double cz = block_sum<double>(sz, scd) / bc;
+    double cv[6] = {0, 0, 0, 0, 0, 0};
+    for (uint32_t i = tid; i < M; i += kFrameThreads) {
+      const float4 q = P[i];
+      if (plane_dist(pl, q) < thr) {
+        const double dx = q.x - cx, dy = q.y - cy, dz = q.z - cz;
+        cv[0] += dx * dx;
+        cv[1] += dx * dy;
+        cv[2] += dx * dz;
+        cv[3] += dy * dy;
+        cv[4] += dy * dz;
+        cv[5] += dz * dz;
+      }
+    }
+    double cs[6];
+    for (int k = 0; k < 6; ++k) cs[k] = block_sum<double>(cv[k], scd) / bc;
+    if (tid == 0) {
+      const double cov[9] = {cs[0], cs[1], cs[2], cs[1], cs[3], cs[4], cs[2], cs[4], cs[5]};
+      double w[3], v[3][3];
+      eig3_sym(cov, w, v);
+      double n[3] = {v[0][0], v[0][1], v[0][2]};
+      if (n[0] * pl[0] + n[1] * pl[1] + n[2] * pl[2] < 0) {
+        n[0] = -n[0];
+        n[1] = -n[1];
+        n[2] = -n[2];
+      }
+      s_plane[0] = (float)n[0];
+      s_plane[1] = (float)n[1];
+      s_plane[2] = (float)n[2];
+      s_plane[3] = (float)(-(n[0] * cx + n[1] * cy + n[2] * cz));
+    }
+    __syncthreads();
+    for (int k = 0; k < 4; ++k) pl[k] = s_plane[k];
+  }
+
+  // ---- re-select inliers with the refined plane, stable order
+  float4* __restrict__ dst = c.board + beg;
+  uint32_t running = 0;
+  for (uint32_t base = 0; base < M; base += kFrameThreads) {
+    const uint32_t i = base + tid;
+    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+    bool keep = false;
+    if (i < M) {
+      q = P[i];
+      keep = plane_dist(pl, q) < thr;
+    }
+    uint32_t tot;
+    const uint32_t rank = block_rank(keep, sc + 40, tot);
+    if (keep) dst[running + rank] = q;
+    running += tot;
+  }
+  if (tid == 0) {
+    r->n_plane = (int32_t)running;
+    for (int k = 0; k < 4; ++k) r->plane[k] = pl[k];
+    if (running < 3) r->status = ILCC_NO_PLANE;
+  }
+}
+
+void launch_ransac_plane(const Ctx& c, hipStream_t s) {
+  hipLaunchKernelGGL(k3_ransac_plane, dim3(c.n_frames), dim3(kFrameThreads), 0, s, c);
+}
+
+}  // namespace ilcc

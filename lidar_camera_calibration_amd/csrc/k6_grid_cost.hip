@@ -1,0 +1,243 @@
+// K6 grid_cost -- the hot kernel.  Evaluates the ILCC intensity-grid objective of
+// Optimization::get_theta_t (/root/reference/ilcc2/src/Optimization.cpp:94-160), i.e.
+//     cost(theta,ty,tz,phase) = 1/2 * sum_k HuberLoss(0.1)( r_k^2 ),
+// r_k = VirtualboardError::operator() (/root/reference/ilcc2/include/ilcc2/Optimization.h:31-107)
+// for EVERY candidate of an exhaustive (theta, ty, tz) x colour-phase grid (the reference only
+// walks this surface locally with Ceres from (0,0,0)).
+//
+// Mapping (gfx950): workgroup = (frame, theta index), 4 wavefronts.  The frame's labelled
+// points (y, z in the plane frame + black/white label) are staged ONCE into LDS per workgroup.
+// One wavefront owns a tile of kTileA x kTileB (ty, tz) candidates at the workgroup's theta:
+// its 64 lanes stride over the points, each lane keeps 2 x 16 partial sums (both colour phases
+// of the 16 candidates), and the sums are reduced across the wavefront with shuffles once per
+// tile.  Sharing theta inside a tile means the rotation is done once per point, and the
+// i-dependent terms (nearest-edge distance, cell parity, out-of-board distance) are computed
+// once per ty and the j-dependent ones once per tz: ~10 VALU ops per (point, candidate) for
+// both phases instead of ~30 for a candidate-at-a-time evaluation.  No MFMA: there is no
+// dense contraction here.  The cost volume is never written (in-kernel argmin) unless the
+// diagnostic entry asks for it.
+//
+// Per point and candidate, with i = (y' + ty + W g/2)/g, j likewise (Optimization.h:45-46):
+//   in board (0<i<W, 0<j<H):  r = dist(i, nearest integer) + dist(j, nearest integer) when the
+//                             cell colour differs from the point's label, else 0   (:50-83)
+//   out of board:             r = min(|i|,|i-W|) + min(|j|,|j-H|) if useOutofBoard    (:85-104)
+//   1/2 rho(r^2) = q (r - q/2),  q = min(r, delta)                     (HuberLoss(0.1), :137)
+// The cell is white iff topleftWhite xor ((floor i + floor j) odd)  (:53-61), so a mismatch
+// under phase 0 is a match under phase 1: both phases come out of one pass.
+#include "ilcc_internal.h"
+
+namespace ilcc {
+
+struct Best {
+  float cost;
+  uint32_t d2;
+  uint32_t flat;
+};
+__device__ __forceinline__ bool better(float c, uint32_t d2, uint32_t flat, const Best& b) {
+  return c < b.cost || (c == b.cost && (d2 < b.d2 || (d2 == b.d2 && flat < b.flat)));
+}
+
+template <bool OOB, bool VOLUME, bool LDS_POINTS>
+__device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, float2* s_pts,
+                                               uint8_t* s_lab, Best* s_best) {
+  const uint32_t f = blockIdx.y;
+  const uint32_t k = blockIdx.x;   // theta index
+  const ilcc_result* r = &c.res[f];
+  const int lane = lane_id();
+  const int wid = __builtin_amdgcn_readfirstlane(wave_id());
+  GridPartial* out = &c.partial[(uint64_t)f * c.grid_blocks + blockIdx.x];
+  if (r->status != ILCC_OK) {
+    if (threadIdx.x == 0) {
+      out->cost = __builtin_inff();
+      out->d2 = 0xFFFFFFFFu;
+      out->flat = 0xFFFFFFFFu;
+    }
+    return;
+  }
+  const uint32_t M = c.n_lab[f];
+  const uint64_t beg = c.off[f];
+  const float2* __restrict__ gyz = c.yz + beg;
+  const uint8_t* __restrict__ glab = c.lab + beg;
+  const uint32_t Mpad = (M + ILCC_WAVE - 1) & ~(uint32_t)(ILCC_WAVE - 1);
+
+  if (LDS_POINTS) {
+    // stage once per workgroup; pad the last wavefront-row with harmless points
+    for (uint32_t i = threadIdx.x; i < Mpad; i += kGridThreads) {
+      float2 v = make_float2(0.f, 0.f);
+      uint8_t l = 0;
+      if (i < M) {
+        v = gyz[i];
+        l = glab[i];
+      }
+      s_pts[i] = v;
+      s_lab[i] = l;
+    }
+    __syncthreads();
+  }
+
+  const float cth = c.cth[k], sth = c.sth[k];
+  const float Wh = 0.5f * (float)c.p.board_w, Hh = 0.5f * (float)c.p.board_h;
+  const float delta = (float)c.p.huber_delta;
+  const int n_ty = c.p.n_ty, n_tz = c.p.n_tz;
+  const int nta = (n_ty + kTileA - 1) / kTileA, ntb = (n_tz + kTileB - 1) / kTileB;
+  const int n_tiles = nta * ntb;
+  const uint32_t dk = (uint32_t)((int)k - c.c_th) * (uint32_t)((int)k - c.c_th);
+
+  Best best{__builtin_inff(), 0xFFFFFFFFu, 0xFFFFFFFFu};
+
+  for (int t = wid; t < n_tiles; t += kGridThreads / ILCC_WAVE) {
+    const int a0 = (t / ntb) * kTileA, b0 = (t % ntb) * kTileB;
+    float ayv[kTileA], azv[kTileB];
+#pragma unroll
+    for (int a = 0; a < kTileA; ++a) ayv[a] = c.ay[min(a0 + a, n_ty - 1)];
+#pragma unroll
+    for (int b = 0; b < kTileB; ++b) azv[b] = c.az[min(b0 + b, n_tz - 1)];
+
+    float x0[kTileA][kTileB], x1[kTileA][kTileB];
+#pragma unroll
+    for (int a = 0; a < kTileA; ++a)
+#pragma unroll
+      for (int b = 0; b < kTileB; ++b) x0[a][b] = x1[a][b] = 0.f;
+
+    for (uint32_t base = 0; base < Mpad; base += ILCC_WAVE) {
+      const uint32_t idx = base + lane;
+      float2 p;
+      uint32_t lab;
+      if (LDS_POINTS) {
+        p = s_pts[idx];
+        lab = s_lab[idx];
+      } else {
+        p = idx < M ? gyz[idx] : make_float2(0.f, 0.f);
+        lab = idx < M ? glab[idx] : 0;
+      }
+      const float dl = idx < M ? delta : 0.f;   // padded lanes: q = min(r,0) = 0 -> no contribution
+      const bool white = lab != 0;
+      // Rx(theta) on (0,y,z), already divided by g (Optimization.h:37-46)
+      const float bi = fmaf(-sth, p.y, cth * p.x);
+      const float bj = fmaf(cth, p.y, sth * p.x);
+
+      float di[kTileA], ui[kTileA];
+      bool pa[kTileA], oa[kTileA];
+#pragma unroll
+      for (int a = 0; a < kTileA; ++a) {
+        const float i = bi + ayv[a];
+        di[a] = fabsf(i - rintf(i));               // distance to the nearest cell border
+        pa[a] = ((((int)floorf(i)) & 1) != 0) != white;   // parity xor label
+        const float tt = fabsf(i - Wh);
+        oa[a] = !(tt < Wh);                        // not (0 < i < W)
+        ui[a] = fabsf(tt - Wh);                    // min(|i|, |i-W|)
+      }
+      float dj[kTileB], uj[kTileB];
+      bool pb[kTileB], ob[kTileB];
+#pragma unroll
+      for (int b = 0; b < kTileB; ++b) {
+        const float j = bj + azv[b];
+        dj[b] = fabsf(j - rintf(j));
+        pb[b] = (((int)floorf(j)) & 1) != 0;
+        const float tt = fabsf(j - Hh);
+        ob[b] = !(tt < Hh);
+        uj[b] = fabsf(tt - Hh);
+      }
+#pragma unroll
+      for (int a = 0; a < kTileA; ++a)
+#pragma unroll
+        for (int b = 0; b < kTileB; ++b) {
+          const bool oob = oa[a] | ob[b];
+          const bool mis0 = pa[a] != pb[b];      // colour mismatch under phase 0 (topleftWhite=false)
+          float rr;
+          if (OOB)
+            rr = oob ? (ui[a] + uj[b]) : (di[a] + dj[b]);
+          else
+            rr = oob ? 0.f : (di[a] + dj[b]);
+          const float q = fminf(rr, dl);
+          const float h = q * fmaf(-0.5f, q, rr);
+          if (OOB) {
+            x0[a][b] += (oob | mis0) ? h : 0.f;
+            x1[a][b] += (oob | !mis0) ? h : 0.f;
+          } else {
+            x0[a][b] += mis0 ? h : 0.f;
+            x1[a][b] += mis0 ? 0.f : h;
+          }
+        }
+    }
+
+    // wavefront reduction (butterfly: every lane ends with the total)
+#pragma unroll
+    for (int a = 0; a < kTileA; ++a)
+#pragma unroll
+      for (int b = 0; b < kTileB; ++b) {
+        float v0 = x0[a][b], v1 = x1[a][b];
+#pragma unroll
+        for (int o = ILCC_WAVE / 2; o > 0; o >>= 1) {
+          v0 += __shfl_xor(v0, o, ILCC_WAVE);
+          v1 += __shfl_xor(v1, o, ILCC_WAVE);
+        }
+        const int ia = a0 + a, ib = b0 + b;
+        if (ia < n_ty && ib < n_tz) {
+          const uint32_t cell = ((uint32_t)k * (uint32_t)n_ty + (uint32_t)ia) * (uint32_t)n_tz + (uint32_t)ib;
+          const uint32_t d2 = dk + (uint32_t)((ia - c.c_ty) * (ia - c.c_ty)) +
+                              (uint32_t)((ib - c.c_tz) * (ib - c.c_tz));
+          if (better(v0, d2, 2u * cell, best)) best = Best{v0, d2, 2u * cell};
+          if (better(v1, d2, 2u * cell + 1u, best)) best = Best{v1, d2, 2u * cell + 1u};
+          if (VOLUME && lane == 0) {
+            float* vol = volume + (uint64_t)f * (uint64_t)c.p.n_th * n_ty * n_tz * 2u;
+            vol[2u * cell] = v0;
+            vol[2u * cell + 1u] = v1;
+          }
+        }
+      }
+  }
+
+  if (lane == 0) s_best[wid] = best;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    Best b = s_best[0];
+    for (int w = 1; w < kGridThreads / ILCC_WAVE; ++w)
+      if (better(s_best[w].cost, s_best[w].d2, s_best[w].flat, b)) b = s_best[w];
+    out->cost = b.cost;
+    out->d2 = b.d2;
+    out->flat = b.flat;
+  }
+}
+
+// dynamic LDS: [grid_lds_points float2][grid_lds_points u8]; frames with more labelled points
+// than the staged capacity read them through L1/L2 instead (same code, global pointers).
+template <bool OOB, bool VOLUME>
+__global__ __launch_bounds__(kGridThreads) void k6_grid_cost(Ctx c, float* volume) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  __shared__ Best s_best[kGridThreads / ILCC_WAVE];
+  float2* s_pts = reinterpret_cast<float2*>(smem);
+  uint8_t* s_lab = smem + sizeof(float2) * (size_t)c.grid_lds_points;
+  const uint32_t M = c.n_lab[blockIdx.y];
+  if (M <= c.grid_lds_points)
+    grid_cost_body<OOB, VOLUME, true>(c, volume, s_pts, s_lab, s_best);
+  else
+    grid_cost_body<OOB, VOLUME, false>(c, volume, s_pts, s_lab, s_best);
+}
+
+void launch_grid_cost(const Ctx& c, hipStream_t s, int32_t use_oob, float* cost_volume) {
+  const dim3 grid(c.grid_blocks, c.n_frames), block(kGridThreads);
+  const size_t lds = (sizeof(float2) + 1) * (size_t)c.grid_lds_points;
+  static bool attr_done = false;
+  if (!attr_done) {   // allow > 64 KiB of dynamic LDS (gfx950 has 160 KiB per CU)
+    const int cap = (int)((sizeof(float2) + 1) * (size_t)kGridLdsPointsMax);
+    (void)hipFuncSetAttribute((const void*)k6_grid_cost<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    (void)hipFuncSetAttribute((const void*)k6_grid_cost<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    (void)hipFuncSetAttribute((const void*)k6_grid_cost<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    (void)hipFuncSetAttribute((const void*)k6_grid_cost<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    attr_done = true;
+  }
+  if (use_oob) {
+    if (cost_volume)
+      hipLaunchKernelGGL((k6_grid_cost<true, true>), grid, block, lds, s, c, cost_volume);
+    else
+      hipLaunchKernelGGL((k6_grid_cost<true, false>), grid, block, lds, s, c, cost_volume);
+  } else {
+    if (cost_volume)
+      hipLaunchKernelGGL((k6_grid_cost<false, true>), grid, block, lds, s, c, cost_volume);
+    else
+      hipLaunchKernelGGL((k6_grid_cost<false, false>), grid, block, lds, s, c, cost_volume);
+  }
+}
+
+}  // namespace ilcc

@@ -1,0 +1,284 @@
+"""Host-side mirror of the reference's ``LidarCornersEst`` for the corner-extraction path.
+
+Same method names, argument meaning and error behaviour as
+``/root/reference/ilcc2/include/ilcc2/LidarCornersEst.h:12-84`` as far as the node
+``ilcc2/test/get_lidar_corners.cpp:112-201`` uses them, with the two PCL viewers / key presses
+replaced by automatic acceptance.  All arithmetic runs in libilcc_hip.so on the MI355X; this file
+is plumbing (numpy in, numpy out) over the C-ABI and never falls back to a CPU path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _native as N
+
+
+class IlccError(RuntimeError):
+    def __init__(self, status: int, detail: str = ""):
+        self.status = int(status)
+        msg = N.strerror(status)
+        super().__init__(f"{msg}: {detail}" if detail else msg)
+
+
+class LidarCornersEst:
+    """``LidarCornersEst`` over the HIP C-ABI.
+
+    The per-frame members of the reference (``m_cloud_ROI``, ``m_cloud_chessboard``,
+    ``m_cloud_PCA``, ``m_cloud_optim``, ``m_cloud_corners``) are exposed as numpy arrays
+    (n x 4 float32: x, y, z, intensity) after ``get_corners``.
+    """
+
+    def __init__(self, device: int = -1, max_frames: int = 1, max_points_per_frame: int = 150_000,
+                 params: Optional[N.Params] = None):
+        self._lib = N.lib()
+        self.params = params if params is not None else N.default_params()
+        self._device = device
+        self._max_frames = int(max_frames)
+        self._max_points = int(max_frames) * int(max_points_per_frame)
+        self._h = None
+        self._cloud = None
+        self._click = None
+        self._result: Optional[N.Result] = None
+        self.m_click_point = None
+        self.m_cloud_ROI = self.m_cloud_chessboard = self.m_cloud_PCA = None
+        self.m_cloud_optim = self.m_cloud_corners = None
+
+    # -- lifetime ---------------------------------------------------------------------------
+    def _handle(self):
+        if self._h is None:
+            h = self._lib.ilcc_create(self._device, C.byref(self.params), self._max_frames, self._max_points)
+            if not h:
+                raise IlccError(N.HIP_ERROR, self._lib.ilcc_last_error(None).decode())
+            self._h = h
+        return self._h
+
+    def close(self):
+        if self._h is not None:
+            self._lib.ilcc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, st: int):
+        if st != N.OK:
+            raise IlccError(st, self._lib.ilcc_last_error(self._h).decode() if self._h else "")
+
+    def set_params(self, params: N.Params):
+        self.params = params
+        if self._h is not None:
+            self._check(self._lib.ilcc_set_params(self._h, C.byref(self.params)))
+
+    # -- the reference's surface ------------------------------------------------------------
+    def register_viewer(self):
+        """LidarCornersEst.h:26-37 opens two PCLVisualizer windows; there is no display on a GPU
+        node, candidates are accepted automatically (keys 'o' and 'k')."""
+
+    def set_chessboard_param(self, cam_yaml: str) -> bool:
+        """LidarCornersEst.cpp:20-46: False (and a message) when the yaml cannot be opened."""
+        st = self._lib.ilcc_set_chessboard_param(C.byref(self.params), cam_yaml.encode())
+        if st != N.OK:
+            print("can not open " + cam_yaml)
+            return False
+        if self._h is not None:
+            self._check(self._lib.ilcc_set_params(self._h, C.byref(self.params)))
+        print("grid_length:", self.params.grid_length)
+        print("grid_in_x:", self.params.board_w)
+        print("grid_in_y:", self.params.board_h)
+        return True
+
+    def setROI(self, cloud: np.ndarray, point: Sequence[float]):
+        """LidarCornersEst.cpp:48-70.  ``cloud``: n x 4 float32 XYZI, ``point``: the rviz click."""
+        cloud = np.ascontiguousarray(cloud, dtype=np.float32)
+        if cloud.ndim != 2 or cloud.shape[1] != 4:
+            raise ValueError("cloud must be n x 4 (x, y, z, intensity)")
+        self._cloud = cloud
+        self._click = np.ascontiguousarray(point, dtype=np.float32).reshape(3)
+        self.m_click_point = self._click.copy()
+        self._result = None
+
+    def _run(self):
+        if self._result is None:
+            if self._cloud is None:
+                raise RuntimeError("setROI must be called first")
+            res = N.Result()
+            st = self._lib.ilcc_extract(self._handle(), N.fptr(self._cloud), len(self._cloud),
+                                        N.fptr(self._click), C.byref(res))
+            self._check(st)
+            self._result = res
+        return self._result
+
+    def _fetch(self, which: int) -> np.ndarray:
+        n = self._lib.ilcc_fetch_cloud(self._h, 0, which, None, 0)
+        if n < 0:
+            raise IlccError(-n)
+        out = np.zeros((max(n, 1), 4), dtype=np.float32)
+        self._lib.ilcc_fetch_cloud(self._h, 0, which, N.fptr(out), n)
+        return out[:n]
+
+    def EuclideanCluster(self) -> bool:
+        """LidarCornersEst.cpp:124-186.  False when no board plane is found (the reference returns
+        False on key 'r' and throws when there is no cluster at all)."""
+        res = self._run()
+        self.m_cloud_ROI = self._fetch(N.CLOUD_ROI)
+        if res.status in (N.NO_ROI_POINTS, N.NO_CLUSTER, N.NO_PLANE):
+            return False
+        self.m_cloud_chessboard = self._fetch(N.CLOUD_CHESSBOARD)
+        print("chessboard plane size:", len(self.m_cloud_chessboard))
+        return True
+
+    def PCA(self):
+        """LidarCornersEst.cpp:366-372 (transformbyPCA + get_gray_zone(…, 2.5))."""
+        res = self._run()
+        self.m_cloud_PCA = self._fetch(N.CLOUD_PCA)
+        self.pca_matrix = np.array(res.pca, dtype=np.float32).reshape(4, 4)
+        self.m_gray_zone = np.array(res.gray_zone)
+
+    def get_corners(self, corners: list) -> bool:
+        """LidarCornersEst.cpp:374-450: fills ``corners`` with (x, y, z) triples, False if rejected."""
+        res = self._run()
+        if res.status != N.OK:
+            print("reject this scan")
+            return False
+        c = res.corners_array()
+        self.m_cloud_optim = self._fetch(N.CLOUD_OPTIM)
+        self.m_cloud_corners = np.concatenate([c, np.full((len(c), 1), 50.0, np.float32)], 1)  # :531
+        corners.extend(map(tuple, c.astype(np.float64)))
+        return True
+
+    @property
+    def result(self) -> Optional[N.Result]:
+        return self._result
+
+
+class LidarCornersBatch:
+    """Batched entry: many independent frames per call (inputs on host or already in HBM)."""
+
+    def __init__(self, max_frames: int, max_points_per_frame: int, params: Optional[N.Params] = None,
+                 device: int = -1):
+        self._lib = N.lib()
+        self.params = params if params is not None else N.default_params()
+        self._h = self._lib.ilcc_create(device, C.byref(self.params), int(max_frames),
+                                        int(max_frames) * int(max_points_per_frame))
+        if not self._h:
+            raise IlccError(N.HIP_ERROR, self._lib.ilcc_last_error(None).decode())
+        self._res = (N.Result * int(max_frames))()
+
+    def close(self):
+        if self._h:
+            self._lib.ilcc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _err(self):
+        return self._lib.ilcc_last_error(self._h).decode()
+
+    def set_params(self, params: N.Params):
+        self.params = params
+        st = self._lib.ilcc_set_params(self._h, C.byref(params))
+        if st != N.OK:
+            raise IlccError(st, self._err())
+
+    def extract(self, clouds: np.ndarray, clicks: np.ndarray, offsets: Optional[np.ndarray] = None):
+        """clouds: [F,N,4] (or [total,4] with ``offsets`` [F+1]); clicks: [F,3].  Returns Result array."""
+        clouds = np.ascontiguousarray(clouds, dtype=np.float32)
+        clicks = np.ascontiguousarray(clicks, dtype=np.float32).reshape(-1, 3)
+        f = len(clicks)
+        if offsets is None:
+            n = clouds.shape[-2]
+            offsets = np.arange(f + 1, dtype=np.uint64) * np.uint64(n)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        st = self._lib.ilcc_extract_batch(self._h, N.fptr(clouds), offsets.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                          f, N.fptr(clicks), self._res)
+        if st != N.OK:
+            raise IlccError(st, self._err())
+        return self._res
+
+    def extract_device(self, d_xyzi_ptr: int, n_frames: int, n_points: int, d_clicks_ptr: int):
+        """Inputs resident in HBM: raw device pointers (e.g. ``tensor.data_ptr()``), fixed N per frame.
+        The producer's stream must be synchronised before the call."""
+        offsets = np.arange(n_frames + 1, dtype=np.uint64) * np.uint64(n_points)
+        st = self._lib.ilcc_extract_batch_device(self._h, C.c_void_p(d_xyzi_ptr),
+                                                 offsets.ctypes.data_as(C.POINTER(C.c_uint64)), n_frames,
+                                                 C.c_void_p(d_clicks_ptr), self._res)
+        if st != N.OK:
+            raise IlccError(st, self._err())
+        return self._res
+
+    def fetch_cloud(self, frame: int, which: int) -> np.ndarray:
+        n = self._lib.ilcc_fetch_cloud(self._h, frame, which, None, 0)
+        if n < 0:
+            raise IlccError(-n)
+        out = np.zeros((max(n, 1), 4), dtype=np.float32)
+        self._lib.ilcc_fetch_cloud(self._h, frame, which, N.fptr(out), n)
+        return out[:n]
+
+    def fetch_labelled(self, frame: int):
+        n = self._lib.ilcc_fetch_labelled(self._h, frame, None, None, 0)
+        if n < 0:
+            raise IlccError(-n)
+        yz = np.zeros((max(n, 1), 2), dtype=np.float32)
+        lab = np.zeros(max(n, 1), dtype=np.uint8)
+        self._lib.ilcc_fetch_labelled(self._h, frame, N.fptr(yz), lab.ctypes.data_as(C.POINTER(C.c_uint8)), n)
+        return yz[:n], lab[:n]
+
+    def grid_cost(self, yz: np.ndarray, label: np.ndarray, use_oob: bool = True, want_volume: bool = False):
+        yz = np.ascontiguousarray(yz, dtype=np.float32).reshape(-1, 2)
+        label = np.ascontiguousarray(label, dtype=np.uint8)
+        p = self.params
+        vol = np.zeros(p.n_th * p.n_ty * p.n_tz * 2, dtype=np.float32) if want_volume else None
+        bi, bc = C.c_int32(-1), C.c_float(0)
+        st = self._lib.ilcc_grid_cost(self._h, N.fptr(yz), label.ctypes.data_as(C.POINTER(C.c_uint8)), len(label),
+                                      int(use_oob), N.fptr(vol) if want_volume else None, C.byref(bi), C.byref(bc))
+        if st != N.OK:
+            raise IlccError(st, self._err())
+        return bi.value, bc.value, vol
+
+    def get_theta_t(self, yz: np.ndarray, label: np.ndarray, topleft_white: bool, use_oob: bool,
+                    theta_t0=(0.0, 0.0, 0.0)):
+        yz = np.ascontiguousarray(yz, dtype=np.float32).reshape(-1, 2)
+        label = np.ascontiguousarray(label, dtype=np.uint8)
+        t = np.array(theta_t0, dtype=np.float64)
+        cost, it = C.c_double(0), C.c_int32(0)
+        st = self._lib.ilcc_get_theta_t(self._h, N.fptr(yz), label.ctypes.data_as(C.POINTER(C.c_uint8)), len(label),
+                                        int(topleft_white), int(use_oob), t.ctypes.data_as(C.POINTER(C.c_double)),
+                                        C.byref(cost), C.byref(it))
+        if st != N.OK:
+            raise IlccError(st, self._err())
+        return t, cost.value, it.value
+
+    def timing(self) -> N.Timing:
+        t = N.Timing()
+        self._lib.ilcc_get_timing(self._h, C.byref(t))
+        return t
+
+    def reset_timing(self):
+        self._lib.ilcc_reset_timing(self._h)
+
+
+def save_corners2txt(corners_xyz: np.ndarray, filename: str):
+    """get_lidar_corners.cpp:27-36 through the C-ABI writer (identical number formatting)."""
+    c = np.ascontiguousarray(corners_xyz, dtype=np.float32).reshape(-1, 3)
+    st = N.lib().ilcc_save_corners2txt(N.fptr(c), len(c), filename.encode())
+    if st != N.OK:
+        raise IlccError(st, filename)
+
+
+def read_lidar_corners(filename: str, num: int) -> np.ndarray:
+    """ImageCornersEst::read_lidar_corners (ImageCornersEst.cpp:281-299)."""
+    out = np.zeros((num, 3), dtype=np.float64)
+    n = N.lib().ilcc_read_lidar_corners(filename.encode(), num, out.ctypes.data_as(C.POINTER(C.c_double)))
+    if n < 0:
+        raise IlccError(-n, filename)
+    return out[:n]

@@ -1,0 +1,251 @@
+"""ctypes binding of oracle/libilcc_oracle.so -- TEST INFRASTRUCTURE ONLY.
+
+May be imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg, never by
+the product package (lidar_camera_calibration_amd must fail loudly without its HIP library).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libilcc_oracle.so")
+MAX_CORNERS = 256
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("roi_half", C.c_double * 3),
+        ("cluster_tol", C.c_double),
+        ("cluster_min", C.c_int32),
+        ("cluster_max", C.c_int32),
+        ("ransac_thresh", C.c_double),
+        ("ransac_hyp", C.c_int32),
+        ("ransac_seed", C.c_uint32),
+        ("hist_bins", C.c_int32),
+        ("gray_rate", C.c_double),
+        ("huber_delta", C.c_double),
+        ("grid_length", C.c_double),
+        ("board_w", C.c_int32),
+        ("board_h", C.c_int32),
+        ("solver", C.c_int32),
+        ("accum_float", C.c_int32),
+        ("phase_mode", C.c_int32),
+        ("n_th", C.c_int32), ("n_ty", C.c_int32), ("n_tz", C.c_int32),
+        ("th_min", C.c_double), ("th_step", C.c_double),
+        ("ty_min", C.c_double), ("ty_step", C.c_double),
+        ("tz_min", C.c_double), ("tz_step", C.c_double),
+    ]
+
+
+class Result(C.Structure):
+    _fields_ = [
+        ("status", C.c_int32),
+        ("n_roi", C.c_int32), ("n_cluster", C.c_int32), ("n_plane", C.c_int32),
+        ("n_black", C.c_int32), ("n_gray", C.c_int32), ("n_white", C.c_int32),
+        ("n_corners", C.c_int32),
+        ("phase", C.c_int32),
+        ("iters_a", C.c_int32), ("iters_b", C.c_int32),
+        ("grid_index", C.c_int32),
+        ("gray_zone", C.c_double * 2),
+        ("theta_t", C.c_double * 3),
+        ("cost_a", C.c_double), ("cost_b", C.c_double),
+        ("sel_cost", C.c_double),
+        ("grid_cost", C.c_double),
+        ("pca", C.c_float * 16),
+        ("corners", C.c_float * (MAX_CORNERS * 3)),
+    ]
+
+
+SOLVER_REFERENCE_LOCAL = 0
+SOLVER_GRID = 1
+
+
+def build(force: bool = False) -> str:
+    if force or not os.path.exists(_LIB) or \
+            os.path.getmtime(_LIB) < os.path.getmtime(os.path.join(_HERE, "ilcc_oracle.c")):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB):
+            build()
+        L = C.CDLL(_LIB)
+        fp = C.POINTER(C.c_float)
+        ip = C.POINTER(C.c_int32)
+        dp = C.POINTER(C.c_double)
+        bp = C.POINTER(C.c_int8)
+        pp = C.POINTER(Params)
+        L.orc_default_params.argtypes = [pp]
+        L.orc_roi_crop.argtypes = [fp, C.c_int32, fp, pp, ip]
+        L.orc_roi_crop.restype = C.c_int32
+        L.orc_cluster.argtypes = [fp, C.c_int32, fp, pp, ip, ip]
+        L.orc_cluster.restype = C.c_int32
+        L.orc_ransac_plane.argtypes = [fp, C.c_int32, pp, ip, fp]
+        L.orc_ransac_plane.restype = C.c_int32
+        L.orc_plane_frame.argtypes = [fp, C.c_int32, pp, fp, fp]
+        L.orc_plane_frame.restype = C.c_int32
+        L.orc_gray_zone.argtypes = [fp, C.c_int32, pp, dp, dp]
+        L.orc_gray_zone.restype = C.c_int32
+        L.orc_residual.argtypes = [dp, C.c_double, C.c_double, C.c_int32, C.c_int32, C.c_double,
+                                   C.c_int32, C.c_int32, C.c_int32, dp]
+        L.orc_residual.restype = C.c_double
+        L.orc_cost.argtypes = [dp, fp, fp, bp, C.c_int32, pp, C.c_int32, C.c_int32]
+        L.orc_cost.restype = C.c_double
+        L.orc_get_theta_t.argtypes = [fp, C.c_int32, dp, pp, C.c_int32, C.c_int32, dp, dp]
+        L.orc_get_theta_t.restype = C.c_int32
+        L.orc_grid_search.argtypes = [fp, fp, bp, C.c_int32, pp, C.c_int32, dp, dp]
+        L.orc_grid_search.restype = C.c_int32
+        L.orc_corners.argtypes = [fp, dp, pp, fp]
+        L.orc_corners.restype = C.c_int32
+        L.orc_extract.argtypes = [fp, C.c_int32, fp, pp, C.POINTER(Result), fp, fp]
+        L.orc_extract.restype = C.c_int32
+        L.orc_format_float.argtypes = [C.c_float, C.c_char_p, C.c_int32]
+        L.orc_format_float.restype = C.c_int32
+        _lib = L
+    return _lib
+
+
+def default_params() -> Params:
+    p = Params()
+    lib().orc_default_params(C.byref(p))
+    return p
+
+
+def _f(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _d(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def roi_crop(xyzi, click, p):
+    x, xp = _f(xyzi)
+    c, cp = _f(click)
+    idx = np.empty(len(x), dtype=np.int32)
+    m = lib().orc_roi_crop(xp, len(x), cp, C.byref(p), idx.ctypes.data_as(C.POINTER(C.c_int32)))
+    return idx[:m].copy()
+
+
+def cluster(roi, click, p):
+    x, xp = _f(roi)
+    c, cp = _f(click)
+    idx = np.empty(max(len(x), 1), dtype=np.int32)
+    lab = np.empty(max(len(x), 1), dtype=np.int32)
+    m = lib().orc_cluster(xp, len(x), cp, C.byref(p), idx.ctypes.data_as(C.POINTER(C.c_int32)),
+                          lab.ctypes.data_as(C.POINTER(C.c_int32)))
+    return idx[:m].copy(), lab[:len(x)].copy()
+
+
+def ransac_plane(pts, p):
+    x, xp = _f(pts)
+    idx = np.empty(max(len(x), 1), dtype=np.int32)
+    pl = np.zeros(4, dtype=np.float32)
+    m = lib().orc_ransac_plane(xp, len(x), C.byref(p), idx.ctypes.data_as(C.POINTER(C.c_int32)),
+                               pl.ctypes.data_as(C.POINTER(C.c_float)))
+    return idx[:m].copy(), pl
+
+
+def plane_frame(pts, p):
+    x, xp = _f(pts)
+    pca = np.zeros(16, dtype=np.float32)
+    out = np.zeros((len(x), 4), dtype=np.float32)
+    st = lib().orc_plane_frame(xp, len(x), C.byref(p), pca.ctypes.data_as(C.POINTER(C.c_float)),
+                               out.ctypes.data_as(C.POINTER(C.c_float)))
+    return st, pca.reshape(4, 4), out
+
+
+def gray_zone(intensity, p):
+    x, xp = _f(intensity)
+    rl = np.zeros(2)
+    gz = np.zeros(2)
+    st = lib().orc_gray_zone(xp, len(x), C.byref(p), rl.ctypes.data_as(C.POINTER(C.c_double)),
+                             gz.ctypes.data_as(C.POINTER(C.c_double)))
+    return st, rl, gz
+
+
+def residual(theta_t, y, z, w, h, g, tlw, laser_white, use_oob, want_jac=False):
+    t, tp = _d(theta_t)
+    jac = np.zeros(3)
+    r = lib().orc_residual(tp, float(y), float(z), int(w), int(h), float(g), int(tlw),
+                           int(laser_white), int(use_oob),
+                           jac.ctypes.data_as(C.POINTER(C.c_double)) if want_jac else None)
+    return (r, jac) if want_jac else r
+
+
+def cost(theta_t, y, z, label, p, tlw, use_oob):
+    t, tp = _d(theta_t)
+    yy, yp = _f(y)
+    zz, zp = _f(z)
+    lab = np.ascontiguousarray(label, dtype=np.int8)
+    return lib().orc_cost(tp, yp, zp, lab.ctypes.data_as(C.POINTER(C.c_int8)), len(yy),
+                          C.byref(p), int(tlw), int(use_oob))
+
+
+def get_theta_t(pts_pca, gz, p, tlw, use_oob, theta_t0=(0.0, 0.0, 0.0)):
+    x, xp = _f(pts_pca)
+    g, gp = _d(gz)
+    t = np.array(theta_t0, dtype=np.float64)
+    c = C.c_double(0)
+    it = lib().orc_get_theta_t(xp, len(x), gp, C.byref(p), int(tlw), int(use_oob),
+                               t.ctypes.data_as(C.POINTER(C.c_double)), C.byref(c))
+    return t, c.value, it
+
+
+def grid_search(y, z, label, p, use_oob, want_volume=False):
+    yy, yp = _f(y)
+    zz, zp = _f(z)
+    lab = np.ascontiguousarray(label, dtype=np.int8)
+    bc = C.c_double(0)
+    vol = np.zeros(p.n_th * p.n_ty * p.n_tz * 2) if want_volume else None
+    flat = lib().orc_grid_search(yp, zp, lab.ctypes.data_as(C.POINTER(C.c_int8)), len(yy),
+                                 C.byref(p), int(use_oob), C.byref(bc),
+                                 vol.ctypes.data_as(C.POINTER(C.c_double)) if want_volume else None)
+    return flat, bc.value, vol
+
+
+def corners(pca, theta_t, p):
+    m, mp = _f(np.asarray(pca).reshape(-1))
+    t, tp = _d(theta_t)
+    out = np.zeros(MAX_CORNERS * 3, dtype=np.float32)
+    n = lib().orc_corners(mp, tp, C.byref(p), out.ctypes.data_as(C.POINTER(C.c_float)))
+    return out[:3 * n].reshape(n, 3).copy()
+
+
+def extract(xyzi, click, p, want_clouds=False):
+    x, xp = _f(xyzi)
+    c, cp = _f(click)
+    res = Result()
+    cb = pc = None
+    cbp = pcp = None
+    if want_clouds:
+        cb = np.zeros((len(x), 4), dtype=np.float32)
+        pc = np.zeros((len(x), 4), dtype=np.float32)
+        cbp = cb.ctypes.data_as(C.POINTER(C.c_float))
+        pcp = pc.ctypes.data_as(C.POINTER(C.c_float))
+    lib().orc_extract(xp, len(x), cp, C.byref(p), C.byref(res), cbp, pcp)
+    if want_clouds:
+        return res, cb[:res.n_plane].copy(), pc[:res.n_plane].copy()
+    return res
+
+
+def result_corners(res: Result) -> np.ndarray:
+    return np.ctypeslib.as_array(res.corners)[:3 * res.n_corners].reshape(-1, 3).copy()
+
+
+def format_float(v: float) -> str:
+    buf = C.create_string_buffer(64)
+    lib().orc_format_float(C.c_float(v), buf, 64)
+    return buf.value.decode()

@@ -1,0 +1,163 @@
+/*
+ * ilcc_oracle.h -- CPU restatement (plain C) of ilcc2's LiDAR chessboard-corner
+ * extraction path.  TEST INFRASTRUCTURE ONLY.
+ *
+ *   Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ *   load this library.  The product (libilcc_hip.so) never links, includes or
+ *   calls anything in oracle/.
+ *
+ * PARITY STATUS: **parity unpinned** for input->output.  The reference cannot be
+ * compiled here (needs PCL/Eigen/Ceres/OpenCV/ROS, all absent), ships no tests
+ * and its six input bags are stripped.  What IS pinned, and what
+ * tests/test_oracle_golden.py checks this file against:
+ *   - the cost functor's hand-derived known-answer table (SURVEY.md App. C,
+ *     derived from ilcc2/include/ilcc2/Optimization.h:31-107),
+ *   - the six bundled output files ilcc2/process_data/pointgrey_lidar_{1..6}.txt
+ *     (format, count, ordering, exact 0.15 m planar lattice),
+ *   - the writer format of ilcc2/test/get_lidar_corners.cpp:27-36.
+ * Third-party arithmetic (PCL 1.7/1.8, Eigen 3.3, Ceres 1.14 -- none pinned by the
+ * reference, ilcc2/CMakeLists.txt:18-37) is restated from the published
+ * algorithms; every function cites the reference call site it follows.
+ *
+ * All citations are relative to /root/reference/.
+ */
+#ifndef ILCC_ORACLE_H_
+#define ILCC_ORACLE_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_MAX_CORNERS 256
+
+/* status codes (shared meaning with include/ilcc_hip.h, but defined independently) */
+enum {
+  ORC_OK = 0,
+  ORC_NO_ROI_POINTS = 1,
+  ORC_NO_CLUSTER = 2,        /* reference: cluster_indices.at(0) throws, LidarCornersEst.cpp:167 */
+  ORC_NO_PLANE = 3,          /* reference: PCL_ERROR, LidarCornersEst.cpp:206-209 */
+  ORC_DEGENERATE_HIST = 4,   /* reference: UB (iter++ past rend), LidarCornersEst.cpp:266-282 */
+  ORC_TOO_FEW_POINTS = 5,
+  ORC_BAD_ARGUMENT = 6
+};
+
+/* solver selection for orc_extract */
+enum {
+  ORC_SOLVER_REFERENCE_LOCAL = 0, /* get_corners default trajectory: topleftWhite=false, pass A then B from 0 */
+  ORC_SOLVER_GRID = 1             /* exhaustive (theta,ty,tz) x phase grid, then local A+B from the argmin */
+};
+
+typedef struct orc_params {
+  /* setROI, LidarCornersEst.cpp:54,59,64 : half extents x,y,z */
+  double roi_half[3];
+  /* EuclideanCluster, LidarCornersEst.cpp:131-133 */
+  double cluster_tol;
+  int32_t cluster_min;
+  int32_t cluster_max;
+  /* getPlane, LidarCornersEst.cpp:201 */
+  double ransac_thresh;
+  int32_t ransac_hyp;       /* number of 3-point hypotheses (counter-based sampler, see .c) */
+  uint32_t ransac_seed;
+  /* calHist / get_gray_zone, LidarCornersEst.cpp:226,371 */
+  int32_t hist_bins;
+  double gray_rate;
+  /* get_theta_t, Optimization.cpp:137 */
+  double huber_delta;
+  /* board, LidarCornersEst.cpp:30-39 : squares, sorted so board_w <= board_h */
+  double grid_length;
+  int32_t board_w;
+  int32_t board_h;
+  /* solver */
+  int32_t solver;
+  int32_t accum_float;      /* 1: centroid/covariance accumulate in float like PCL; 0: double */
+  int32_t phase_mode;       /* REFERENCE_LOCAL: 0 topleftWhite=false (reference's first turn), 1 true,
+                               2 try both from zero, keep lower with-OOB cost (stands in for key 'd') */
+  /* grid (ORC_SOLVER_GRID): theta in [th_min, th_min+(n_th-1)*th_step], ty,tz likewise */
+  int32_t n_th, n_ty, n_tz;
+  double th_min, th_step;
+  double ty_min, ty_step;
+  double tz_min, tz_step;
+} orc_params;
+
+typedef struct orc_result {
+  int32_t status;
+  int32_t n_roi, n_cluster, n_plane;
+  int32_t n_black, n_gray, n_white;
+  int32_t n_corners;
+  int32_t phase;               /* topleftWhite used (0/1) */
+  int32_t iters_a, iters_b;    /* trust-region iterations of pass A / B */
+  int32_t grid_index;          /* winning candidate (ORC_SOLVER_GRID), else -1 */
+  double gray_zone[2];
+  double theta_t[3];
+  double cost_a, cost_b;       /* final cost of pass A (OOB on) and B (OOB off) */
+  double sel_cost;             /* with-OOB cost at the final theta_t (phase selection metric) */
+  double grid_cost;
+  float pca[16];               /* row-major 4x4, lidar -> plane frame (pca_matrix) */
+  float corners[ORC_MAX_CORNERS * 3];
+} orc_result;
+
+void orc_default_params(orc_params* p);
+
+/* ---- stage functions (each usable on its own from tests) ---- */
+
+/* a1 setROI: returns m, writes kept original indices (ascending) */
+int32_t orc_roi_crop(const float* xyzi, int32_t n, const float click[3], const orc_params* p,
+                     int32_t* out_idx);
+
+/* a2 EuclideanCluster (without the UI): in = roi points (m x 4 floats).
+ * returns size of the chosen cluster (0 if none), indices (into roi, ascending) in out_idx.
+ * labels_out (optional, m ints): component id per point (= smallest member index). */
+int32_t orc_cluster(const float* roi, int32_t m, const float click[3], const orc_params* p,
+                    int32_t* out_idx, int32_t* labels_out);
+
+/* a3 getPlane: in = cluster points (m x 4). returns inlier count, indices ascending.
+ * plane_out (optional): refit plane nx,ny,nz,d */
+int32_t orc_ransac_plane(const float* pts, int32_t m, const orc_params* p, int32_t* out_idx,
+                         float plane_out[4]);
+
+/* a4 transformbyPCA: in = plane points (m x 4); out pca[16] row-major, pts_pca (m x 4, intensity carried) */
+int32_t orc_plane_frame(const float* pts, int32_t m, const orc_params* p, float pca[16],
+                        float* pts_pca);
+
+/* a5 calHist + get_gray_zone */
+int32_t orc_gray_zone(const float* intensity, int32_t m, const orc_params* p, double rlrh[2],
+                      double gray_zone[2]);
+
+/* a6 VirtualboardError::operator() -- raw residual, optional raw jacobian d r / d(theta,ty,tz) */
+double orc_residual(const double theta_t[3], double y, double z, int32_t board_w, int32_t board_h,
+                    double g, int32_t topleft_white, int32_t laser_white, int32_t use_oob,
+                    double jac[3]);
+
+/* half * sum rho(r^2) over labelled points. label: 0 black, 1 white, anything else skipped */
+double orc_cost(const double theta_t[3], const float* y, const float* z, const int8_t* label,
+                int32_t m, const orc_params* p, int32_t topleft_white, int32_t use_oob);
+
+/* a7 get_theta_t : classify by gray zone and minimise (Ceres-1.14-like TRUST_REGION/SUBSPACE_DOGLEG).
+ * pts_pca: m x 4 (x,y,z,intensity). theta_t in/out. returns iterations used; final cost in *cost */
+int32_t orc_get_theta_t(const float* pts_pca, int32_t m, const double gray_zone[2],
+                        const orc_params* p, int32_t topleft_white, int32_t use_oob,
+                        double theta_t[3], double* cost);
+
+/* exhaustive grid (spec of the GPU search): both phases, chosen OOB flag; returns winning flat index
+ * ((k*n_ty + a)*n_tz + b)*2 + phase ; cost_out (optional) full volume [n_th*n_ty*n_tz*2] */
+int32_t orc_grid_search(const float* y, const float* z, const int8_t* label, int32_t m,
+                        const orc_params* p, int32_t use_oob, double* best_cost,
+                        double* cost_out);
+
+/* a9 getPCDcorners (inverse=false) */
+int32_t orc_corners(const float pca[16], const double theta_t[3], const orc_params* p,
+                    float* corners);
+
+/* whole path for one frame. debug clouds optional (NULL ok): each n x 4 floats, capacity n. */
+int32_t orc_extract(const float* xyzi, int32_t n, const float click[3], const orc_params* p,
+                    orc_result* out, float* cloud_chessboard, float* cloud_pca);
+
+/* a11 save_corners2txt formatting of one float (ostream default, precision 6) into buf */
+int32_t orc_format_float(float v, char* buf, int32_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
