@@ -33,6 +33,7 @@ struct ilcc_handle {
   uint8_t* d_lab = nullptr;
   uint32_t *d_nlab = nullptr, *d_counts = nullptr, *d_parent = nullptr, *d_count = nullptr;
   GridPartial* d_partial = nullptr;
+  SolveRec* d_solverec = nullptr;
   float *d_cth = nullptr, *d_sth = nullptr, *d_ay = nullptr, *d_az = nullptr;
   double* d_solve = nullptr;   // 3 theta_t + 2 (cost, iterations) for the test entry
   uint32_t crop_chunks_cap = 0;
@@ -131,6 +132,7 @@ Ctx make_ctx(ilcc_handle* h, const float4* d_xyzi, const float* d_clicks, uint32
   c.uf_parent = h->d_parent;
   c.uf_count = h->d_count;
   c.partial = h->d_partial;
+  c.solve_rec = h->d_solverec;
   c.grid_blocks = (uint32_t)h->p.n_th;
   c.grid_lds_points = h->grid_lds_points;
   c.cth = h->d_cth;
@@ -401,6 +403,7 @@ ilcc_handle* ilcc_create(int32_t device, const ilcc_params* p, uint32_t max_fram
   ALLOC(h->d_parent, sizeof(uint32_t) * np);
   ALLOC(h->d_count, sizeof(uint32_t) * np);
   ALLOC(h->d_partial, sizeof(GridPartial) * (size_t)max_frames * h->max_theta);
+  ALLOC(h->d_solverec, sizeof(SolveRec) * 2 * (size_t)max_frames);
   ALLOC(h->d_cth, sizeof(float) * h->max_theta);
   ALLOC(h->d_sth, sizeof(float) * h->max_theta);
   ALLOC(h->d_ay, sizeof(float) * h->max_theta);
@@ -419,7 +422,7 @@ void ilcc_destroy(ilcc_handle* h) {
   if (!h) return;
   void* bufs[] = {h->d_xyzi, h->d_clicks, h->d_off,    h->d_res,    h->d_roi,   h->d_cluster, h->d_board,
                   h->d_pca,  h->d_optim,  h->d_yz,     h->d_lab,    h->d_nlab,  h->d_counts,  h->d_parent,
-                  h->d_count, h->d_partial, h->d_cth,  h->d_sth,    h->d_ay,    h->d_az,      h->d_solve};
+                  h->d_count, h->d_partial, h->d_solverec, h->d_cth,  h->d_sth,    h->d_ay,    h->d_az,      h->d_solve};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   for (auto& ev : h->ev)

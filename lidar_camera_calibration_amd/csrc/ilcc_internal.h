@@ -29,6 +29,12 @@ struct GridPartial {   // per K6 workgroup best candidate
   uint32_t pad;
 };
 
+struct SolveRec {      // K7a result for one (frame, phase slot)
+  double x[3];
+  double cost_a, cost_b, sel;
+  int32_t iters_a, iters_b, phase, valid;
+};
+
 // everything a kernel needs, passed by value
 struct Ctx {
   // inputs
@@ -52,6 +58,7 @@ struct Ctx {
   uint32_t* uf_parent;       // K2 scratch (global fallback / labels)
   uint32_t* uf_count;        // K2 component sizes
   GridPartial* partial;      // n_frames x grid_blocks
+  SolveRec* solve_rec;       // n_frames x 2
   uint32_t grid_blocks;      // K6 workgroups per frame
   uint32_t grid_lds_points;  // K6 points staged in LDS per workgroup (multiple of 64)
   // candidate tables (device)

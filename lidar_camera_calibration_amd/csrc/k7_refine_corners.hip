@@ -1,5 +1,6 @@
-// K7 refine_and_corners -- one 256-thread workgroup per frame.
+// K7 refine_and_corners.
 //
+// K7a local_solve: ONE WAVEFRONT per (frame, colour phase).
 //  (1) picks the start: the argmin of the K6 per-workgroup partials (ILCC_SOLVER_GRID) or
 //      (0,0,0) (ILCC_SOLVER_REFERENCE_LOCAL, the reference's own start);
 //  (2) runs the reference's two local solves, pass A (useOutofBoard = true) then pass B (false)
@@ -7,9 +8,14 @@
 //      each a restatement of what ceres::Solve does for Optimization::get_theta_t
 //      (/root/reference/ilcc2/src/Optimization.cpp:94-160): TRUST_REGION, DOGLEG/SUBSPACE_DOGLEG,
 //      DENSE_NORMAL_CHOLESKY, HuberLoss(0.1) through Ceres' Corrector, Jacobi scaling, Ceres 1.14
-//      default tolerances.  Residuals/Jacobians are evaluated in double by all threads; the
-//      3-parameter trust-region bookkeeping runs on thread 0;
-//  (3) builds the corner lattice: LidarCornersEst::getPCDcorners (:501-556) with
+//      default tolerances.  The 64 lanes stride over the points (residual + Jacobian in double),
+//      sums are combined with a shuffle butterfly so every lane holds bitwise-identical totals,
+//      and the 3-parameter trust-region bookkeeping is executed redundantly by all lanes: no
+//      LDS hand-off, no barrier, no divergence.  A solve is a chain of ~100 dependent
+//      evaluations, so latency -- not throughput -- is what this layout minimises; frames and
+//      phases run concurrently on different CUs.
+// K7b corners: picks the phase with the lower with-OOB cost, then builds the corner lattice:
+//      LidarCornersEst::getPCDcorners (:501-556) with
 //      transf = pcl::getTransformation(0, ty, tz, theta, 0, 0) (:412), and the display cloud
 //      m_cloud_optim (:413).
 #include "ilcc_internal.h"
@@ -75,28 +81,32 @@ __device__ __forceinline__ void huber(double a, double s, double& rho0, double& 
   }
 }
 
-// ------------------------------------------------------------------ workgroup-wide evaluation
+// ------------------------------------------------------------------ wavefront-wide evaluation
 struct Problem {
-  const float2* yz;
+  const float2* yz;      // LDS or global
   const uint8_t* lab;
   uint32_t n;
   Board bd;
   bool tlw, oob;
 };
 
-constexpr int kNW = kSolveThreads / ILCC_WAVE;
+template <typename T>
+__device__ __forceinline__ T wave_allsum(T v) {
+#pragma unroll
+  for (int o = ILCC_WAVE / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, ILCC_WAVE);
+  return v;   // identical in every lane (each step adds the same two operands in both partners)
+}
 
 // sums[0] = cost ; if JAC: sums[1..3] = J^T r, sums[4..9] = upper J^T J (00,01,02,11,12,22),
-// all with Ceres' Corrector applied (rows scaled by sqrt(rho')).  Result valid on every thread.
+// with Ceres' Corrector applied (rows scaled by sqrt(rho')).  Same value in every lane.
 template <bool JAC>
-__device__ void evaluate(const Problem& q, const double x[3], double* s_red /*[kNW*10 + 10]*/,
-                         double sums[10]) {
+__device__ __forceinline__ void evaluate(const Problem& q, const double x[3], double sums[10]) {
   double sn, cs;
   sincos(x[0], &sn, &cs);
   double acc[10];
 #pragma unroll
   for (int k = 0; k < 10; ++k) acc[k] = 0.0;
-  for (uint32_t p = threadIdx.x; p < q.n; p += kSolveThreads) {
+  for (uint32_t p = lane_id(); p < q.n; p += ILCC_WAVE) {
     const float2 v = q.yz[p];
     double jac[3];
     const double res = residual<JAC>(x, cs, sn, (double)v.x, (double)v.y, q.bd, q.tlw, q.lab[p] != 0,
@@ -121,329 +131,306 @@ __device__ void evaluate(const Problem& q, const double x[3], double* s_red /*[k
   }
   constexpr int NV = JAC ? 10 : 1;
 #pragma unroll
-  for (int k = 0; k < NV; ++k) acc[k] = wave_sum(acc[k]);
-  __syncthreads();
-  if (lane_id() == 0)
-    for (int k = 0; k < NV; ++k) s_red[wave_id() * 10 + k] = acc[k];
-  __syncthreads();
-  if (threadIdx.x < NV) {
-    double t = s_red[threadIdx.x];
-    for (int w = 1; w < kNW; ++w) t += s_red[w * 10 + threadIdx.x];
-    s_red[kNW * 10 + threadIdx.x] = t;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < NV; ++k) sums[k] = s_red[kNW * 10 + k];
+  for (int k = 0; k < NV; ++k) sums[k] = wave_allsum(acc[k]);
 }
 
-// ------------------------------------------------------------------ thread-0 dogleg bookkeeping
+// ------------------------------------------------------------------ dogleg bookkeeping (per lane, uniform)
 struct Dog {
   double radius, mu;
   int reuse;
-  double diagonal[3], gradient[3], gn[3];
+  double d0, d1, d2;        // diagonal
+  double g0, g1, g2;        // scaled gradient
+  double n0, n1, n2;        // Gauss-Newton step (scaled space)
   double alpha, step_norm;
   int one_dim;
-  double basis[3][2], sg[2], sB[4];
-  double JtJ[9], Jtr[3];   // of the column-scaled Jacobian
+  double b00, b01, b10, b11, b20, b21;   // subspace basis (3x2)
+  double sg0, sg1, sB00, sB01, sB11;
+  double A00, A01, A02, A11, A12, A22;   // J^T J of the column-scaled Jacobian
+  double r0, r1, r2;                     // J^T r of the column-scaled Jacobian
 };
 
-__device__ inline bool chol3_solve(const double A[9], const double b[3], double x[3]) {
-  double L[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-  for (int i = 0; i < 3; ++i)
-    for (int j = 0; j <= i; ++j) {
-      double s = A[3 * i + j];
-      for (int k = 0; k < j; ++k) s -= L[i][k] * L[j][k];
-      if (i == j) {
-        if (!(s > 0.0)) return false;
-        L[i][i] = sqrt(s);
-      } else {
-        L[i][j] = s / L[j][j];
-      }
-    }
-  double yv[3];
-  for (int i = 0; i < 3; ++i) {
-    double s = b[i];
-    for (int k = 0; k < i; ++k) s -= L[i][k] * yv[k];
-    yv[i] = s / L[i][i];
-  }
-  for (int i = 2; i >= 0; --i) {
-    double s = yv[i];
-    for (int k = i + 1; k < 3; ++k) s -= L[k][i] * x[k];
-    x[i] = s / L[i][i];
-  }
-  for (int i = 0; i < 3; ++i)
-    if (!isfinite(x[i])) return false;
-  return true;
+// (A + diag(e)) x = b by Cholesky; false on a non-positive pivot (Eigen LLT NumericalIssue)
+__device__ __forceinline__ bool chol3_solve(double a00, double a01, double a02, double a11, double a12,
+                                            double a22, double b0, double b1, double b2, double& x0,
+                                            double& x1, double& x2) {
+  if (!(a00 > 0.0)) return false;
+  const double l00 = sqrt(a00);
+  const double l10 = a01 / l00, l20 = a02 / l00;
+  const double s11 = a11 - l10 * l10;
+  if (!(s11 > 0.0)) return false;
+  const double l11 = sqrt(s11);
+  const double l21 = (a12 - l20 * l10) / l11;
+  const double s22 = a22 - l20 * l20 - l21 * l21;
+  if (!(s22 > 0.0)) return false;
+  const double l22 = sqrt(s22);
+  const double y0 = b0 / l00;
+  const double y1 = (b1 - l10 * y0) / l11;
+  const double y2 = (b2 - l20 * y0 - l21 * y1) / l22;
+  x2 = y2 / l22;
+  x1 = (y1 - l21 * x2) / l11;
+  x0 = (y0 - l10 * x1 - l20 * x2) / l00;
+  return isfinite(x0) && isfinite(x1) && isfinite(x2);
 }
 
-// argmin of 1/2 y'By + g'y on |y| = radius (Ceres: quartic roots; here scan + Newton polish)
-__device__ inline void min_on_circle(const double B[4], const double g[2], double radius, double y[2]) {
-  const int NS = 720;
-  const double kPi = 3.14159265358979323846;
-  double best = 1.7976931348623157e308, bt = 0;
-  for (int k = 0; k < NS; ++k) {
-    const double t = 2.0 * kPi * k / NS;
-    const double a = radius * cos(t), b = radius * sin(t);
-    const double f = 0.5 * (B[0] * a * a + 2 * B[1] * a * b + B[3] * b * b) + g[0] * a + g[1] * b;
-    if (f < best) {
-      best = f;
-      bt = t;
+// argmin of 1/2 y'By + g'y on |y| = radius, B symmetric PSD 2x2 (Ceres: quartic roots; here
+// eigen-decomposition + Newton on the secular equation, More-Sorensen).
+__device__ __forceinline__ void min_on_circle(double B00, double B01, double B11, double gx, double gy,
+                                              double radius, double& yx, double& yy) {
+  const double d = 0.5 * (B00 - B11), e = B01;
+  const double h = sqrt(d * d + e * e), mean = 0.5 * (B00 + B11);
+  const double l1 = mean - h, l2 = mean + h;
+  double v2x, v2y;
+  if (h == 0.0) {
+    v2x = 1.0;
+    v2y = 0.0;
+  } else if (d >= 0.0) {
+    v2x = d + h;
+    v2y = e;
+  } else {
+    v2x = e;
+    v2y = h - d;
+  }
+  {
+    const double nv = sqrt(v2x * v2x + v2y * v2y);
+    if (nv > 0.0) {
+      v2x /= nv;
+      v2y /= nv;
+    } else {
+      v2x = 1.0;
+      v2y = 0.0;
     }
   }
-  double t = bt;
-  for (int it = 0; it < 50; ++it) {
-    const double c = cos(t), s = sin(t);
-    const double a = radius * c, b = radius * s, da = -radius * s, db = radius * c;
-    const double Ba = B[0] * a + B[1] * b, Bb = B[1] * a + B[3] * b;
-    const double f1 = Ba * da + Bb * db + g[0] * da + g[1] * db;
-    const double Bda = B[0] * da + B[1] * db, Bdb = B[1] * da + B[3] * db;
-    const double f2 = Bda * da + Bdb * db + Ba * (-a) + Bb * (-b) + g[0] * (-a) + g[1] * (-b);
-    if (!(f2 > 0)) break;
-    const double step = f1 / f2;
-    if (fabs(step) > kPi / NS) break;
-    t -= step;
-    if (fabs(step) < 1e-15) break;
+  const double v1x = -v2y, v1y = v2x;
+  const double g1 = v1x * gx + v1y * gy, g2 = v2x * gx + v2y * gy;
+  const double gn = sqrt(g1 * g1 + g2 * g2);
+  double lo = fmax(0.0, -l1);
+  lo = fmax(lo, gn / radius - l2);
+  const double hi = gn / radius - l1;
+  double lam = lo;
+  if (!(l1 + lam > 0.0)) lam = lo + 1e-12 * fmax(1.0, fabs(hi));
+  for (int it = 0; it < 60; ++it) {
+    const double a1 = l1 + lam, a2 = l2 + lam;
+    const double y1 = -g1 / a1, y2 = -g2 / a2;
+    const double ny = sqrt(y1 * y1 + y2 * y2);
+    const double qq = g1 * g1 / (a1 * a1 * a1) + g2 * g2 / (a2 * a2 * a2);
+    if (!(qq > 0.0) || !isfinite(ny)) break;
+    const double dl = (ny * ny / qq) * ((ny - radius) / radius);
+    double nl = lam + dl;
+    if (!(l1 + nl > 0.0)) nl = 0.5 * (lam + fmax(0.0, -l1));
+    if (fabs(nl - lam) <= 1e-15 * fmax(1.0, fabs(nl))) {
+      lam = nl;
+      break;
+    }
+    lam = nl;
   }
-  y[0] = radius * cos(t);
-  y[1] = radius * sin(t);
+  const double a1 = l1 + lam, a2 = l2 + lam;
+  double y1 = (a1 > 0.0) ? -g1 / a1 : 0.0, y2 = (a2 > 0.0) ? -g2 / a2 : 0.0;
+  double ny = sqrt(y1 * y1 + y2 * y2);
+  if (ny < radius * (1.0 - 1e-9) && !(a1 > 1e-300 * fmax(1.0, l2))) {
+    y1 = sqrt(fmax(0.0, radius * radius - y2 * y2));
+    ny = radius;
+  }
+  if (ny > 0.0) {
+    y1 *= radius / ny;
+    y2 *= radius / ny;
+  }
+  yx = v1x * y1 + v2x * y2;
+  yy = v1y * y1 + v2y * y2;
 }
 
-__device__ inline double norm3(const double v[3]) { return sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); }
+__device__ __forceinline__ double nrm3(double a, double b, double c) { return sqrt(a * a + b * b + c * c); }
 
-__device__ inline void dogleg_traditional(Dog& s, double step[3]) {
-  const double gnn = norm3(s.gn), gn_ = norm3(s.gradient);
+__device__ __forceinline__ void dogleg_traditional(Dog& s, double& s0, double& s1, double& s2) {
+  const double gnn = nrm3(s.n0, s.n1, s.n2), gn_ = nrm3(s.g0, s.g1, s.g2);
   if (gnn <= s.radius) {
-    for (int c = 0; c < 3; ++c) step[c] = s.gn[c] / s.diagonal[c];
+    s0 = s.n0 / s.d0;
+    s1 = s.n1 / s.d1;
+    s2 = s.n2 / s.d2;
     s.step_norm = gnn;
     return;
   }
   if (gn_ * s.alpha >= s.radius) {
-    for (int c = 0; c < 3; ++c) step[c] = -(s.radius / gn_) * s.gradient[c] / s.diagonal[c];
+    const double k = -(s.radius / gn_);
+    s0 = k * s.g0 / s.d0;
+    s1 = k * s.g1 / s.d1;
+    s2 = k * s.g2 / s.d2;
     s.step_norm = s.radius;
     return;
   }
-  double bdota = 0, a2 = 0, bma2 = 0;
-  for (int c = 0; c < 3; ++c) {
-    const double a = -s.alpha * s.gradient[c];
-    bdota += a * s.gn[c];
-    a2 += a * a;
-    bma2 += (s.gn[c] - a) * (s.gn[c] - a);
-  }
-  const double cc = bdota - a2;
-  const double d = sqrt(cc * cc + bma2 * (s.radius * s.radius - a2));
-  const double beta = (cc <= 0) ? (d - cc) / bma2 : (s.radius * s.radius - a2) / (d + cc);
-  for (int c = 0; c < 3; ++c) {
-    const double a = -s.alpha * s.gradient[c];
-    step[c] = (a + beta * (s.gn[c] - a)) / s.diagonal[c];
-  }
+  const double a0 = -s.alpha * s.g0, a1 = -s.alpha * s.g1, a2 = -s.alpha * s.g2;
+  const double bdota = a0 * s.n0 + a1 * s.n1 + a2 * s.n2;
+  const double a2n = a0 * a0 + a1 * a1 + a2 * a2;
+  const double bma2 = (s.n0 - a0) * (s.n0 - a0) + (s.n1 - a1) * (s.n1 - a1) + (s.n2 - a2) * (s.n2 - a2);
+  const double cc = bdota - a2n;
+  const double d = sqrt(cc * cc + bma2 * (s.radius * s.radius - a2n));
+  const double beta = (cc <= 0) ? (d - cc) / bma2 : (s.radius * s.radius - a2n) / (d + cc);
+  s0 = (a0 + beta * (s.n0 - a0)) / s.d0;
+  s1 = (a1 + beta * (s.n1 - a1)) / s.d1;
+  s2 = (a2 + beta * (s.n2 - a2)) / s.d2;
   s.step_norm = s.radius;
 }
 
-// DoglegStrategy::ComputeStep; JtJ/Jtr (scaled Jacobian) must be current when !reuse.
-__device__ inline bool dogleg_compute_step(Dog& s, double step[3]) {
+// quadratic form u' A v with the symmetric 3x3 stored in Dog
+__device__ __forceinline__ double qform(const Dog& s, double u0, double u1, double u2, double v0, double v1,
+                                        double v2) {
+  const double w0 = s.A00 * v0 + s.A01 * v1 + s.A02 * v2;
+  const double w1 = s.A01 * v0 + s.A11 * v1 + s.A12 * v2;
+  const double w2 = s.A02 * v0 + s.A12 * v1 + s.A22 * v2;
+  return u0 * w0 + u1 * w1 + u2 * w2;
+}
+
+// DoglegStrategy::ComputeStep; A / r (scaled Jacobian) must be current when !reuse.
+__device__ __forceinline__ bool dogleg_compute_step(Dog& s, double& s0, double& s1, double& s2) {
   if (!s.reuse) {
     s.reuse = 1;
-    for (int c = 0; c < 3; ++c) {
-      double d = s.JtJ[4 * c];
-      d = fmin(fmax(d, 1e-6), 1e32);
-      s.diagonal[c] = sqrt(d);
-      s.gradient[c] = s.Jtr[c] / s.diagonal[c];
-    }
+    s.d0 = sqrt(fmin(fmax(s.A00, 1e-6), 1e32));
+    s.d1 = sqrt(fmin(fmax(s.A11, 1e-6), 1e32));
+    s.d2 = sqrt(fmin(fmax(s.A22, 1e-6), 1e32));
+    s.g0 = s.r0 / s.d0;
+    s.g1 = s.r1 / s.d1;
+    s.g2 = s.r2 / s.d2;
     {
-      double sgv[3], num = 0, den = 0;
-      for (int c = 0; c < 3; ++c) {
-        sgv[c] = s.gradient[c] / s.diagonal[c];
-        num += s.gradient[c] * s.gradient[c];
-      }
-      for (int a = 0; a < 3; ++a)
-        for (int b = 0; b < 3; ++b) den += sgv[a] * s.JtJ[3 * a + b] * sgv[b];
-      s.alpha = num / den;
+      const double u0 = s.g0 / s.d0, u1 = s.g1 / s.d1, u2 = s.g2 / s.d2;
+      const double num = s.g0 * s.g0 + s.g1 * s.g1 + s.g2 * s.g2;
+      s.alpha = num / qform(s, u0, u1, u2, u0, u1, u2);
     }
     bool ok = false;
     while (s.mu < 1.0) {
-      double A[9];
-      for (int k = 0; k < 9; ++k) A[k] = s.JtJ[k];
-      for (int c = 0; c < 3; ++c) {
-        const double lm = s.diagonal[c] * sqrt(s.mu);
-        A[4 * c] += lm * lm;
-      }
-      if (chol3_solve(A, s.Jtr, s.gn)) {
+      const double sm = sqrt(s.mu);
+      const double e0 = s.d0 * sm, e1 = s.d1 * sm, e2 = s.d2 * sm;
+      if (chol3_solve(s.A00 + e0 * e0, s.A01, s.A02, s.A11 + e1 * e1, s.A12, s.A22 + e2 * e2, s.r0, s.r1, s.r2,
+                      s.n0, s.n1, s.n2)) {
         ok = true;
         break;
       }
       s.mu *= 10.0;
     }
     if (!ok) return false;
-    for (int c = 0; c < 3; ++c) s.gn[c] *= -s.diagonal[c];
+    s.n0 *= -s.d0;
+    s.n1 *= -s.d1;
+    s.n2 *= -s.d2;
     {
-      double v0[3], v1[3];
-      double n0 = 0, n1 = 0;
-      for (int c = 0; c < 3; ++c) {
-        n0 += s.gradient[c] * s.gradient[c];
-        n1 += s.gn[c] * s.gn[c];
-      }
-      const bool gfirst = n0 >= n1;
-      const double nf = sqrt(fmax(n0, n1));
-      double dot = 0;
-      for (int c = 0; c < 3; ++c) {
-        v0[c] = (gfirst ? s.gradient[c] : s.gn[c]) / nf;
-      }
-      for (int c = 0; c < 3; ++c) dot += (gfirst ? s.gn[c] : s.gradient[c]) * v0[c];
-      double nr = 0;
-      for (int c = 0; c < 3; ++c) {
-        v1[c] = (gfirst ? s.gn[c] : s.gradient[c]) - dot * v0[c];
-        nr += v1[c] * v1[c];
-      }
-      nr = sqrt(nr);
+      const double q0 = s.g0 * s.g0 + s.g1 * s.g1 + s.g2 * s.g2;
+      const double q1 = s.n0 * s.n0 + s.n1 * s.n1 + s.n2 * s.n2;
+      const bool gfirst = q0 >= q1;
+      const double nf = sqrt(fmax(q0, q1));
+      const double f0 = (gfirst ? s.g0 : s.n0), f1 = (gfirst ? s.g1 : s.n1), f2 = (gfirst ? s.g2 : s.n2);
+      const double t0 = (gfirst ? s.n0 : s.g0), t1 = (gfirst ? s.n1 : s.g1), t2 = (gfirst ? s.n2 : s.g2);
+      const double v00 = f0 / nf, v01 = f1 / nf, v02 = f2 / nf;
+      const double dot = t0 * v00 + t1 * v01 + t2 * v02;
+      double v10 = t0 - dot * v00, v11 = t1 - dot * v01, v12 = t2 - dot * v02;
+      const double nr = nrm3(v10, v11, v12);
       s.one_dim = !(nr > 3.0 * 2.220446049250313e-16 * nf);
       if (!s.one_dim) {
-        double u[2][3];
-        for (int c = 0; c < 3; ++c) {
-          v1[c] /= nr;
-          s.basis[c][0] = v0[c];
-          s.basis[c][1] = v1[c];
-          u[0][c] = v0[c] / s.diagonal[c];
-          u[1][c] = v1[c] / s.diagonal[c];
-        }
-        for (int a = 0; a < 2; ++a) {
-          s.sg[a] = 0;
-          for (int c = 0; c < 3; ++c) s.sg[a] += s.basis[c][a] * s.gradient[c];
-          for (int b = 0; b < 2; ++b) {
-            double acc = 0;
-            for (int c = 0; c < 3; ++c)
-              for (int d = 0; d < 3; ++d) acc += u[a][c] * s.JtJ[3 * c + d] * u[b][d];
-            s.sB[2 * a + b] = acc;
-          }
-        }
+        v10 /= nr;
+        v11 /= nr;
+        v12 /= nr;
+        s.b00 = v00;
+        s.b10 = v01;
+        s.b20 = v02;
+        s.b01 = v10;
+        s.b11 = v11;
+        s.b21 = v12;
+        const double ua0 = v00 / s.d0, ua1 = v01 / s.d1, ua2 = v02 / s.d2;
+        const double ub0 = v10 / s.d0, ub1 = v11 / s.d1, ub2 = v12 / s.d2;
+        s.sg0 = v00 * s.g0 + v01 * s.g1 + v02 * s.g2;
+        s.sg1 = v10 * s.g0 + v11 * s.g1 + v12 * s.g2;
+        s.sB00 = qform(s, ua0, ua1, ua2, ua0, ua1, ua2);
+        s.sB01 = qform(s, ua0, ua1, ua2, ub0, ub1, ub2);
+        s.sB11 = qform(s, ub0, ub1, ub2, ub0, ub1, ub2);
       }
     }
   }
-  const double gnn = norm3(s.gn);
+  const double gnn = nrm3(s.n0, s.n1, s.n2);
   if (gnn <= s.radius) {
-    for (int c = 0; c < 3; ++c) step[c] = s.gn[c] / s.diagonal[c];
+    s0 = s.n0 / s.d0;
+    s1 = s.n1 / s.d1;
+    s2 = s.n2 / s.d2;
     s.step_norm = gnn;
     return true;
   }
   if (s.one_dim) {
-    const double gn_ = norm3(s.gradient);
-    for (int c = 0; c < 3; ++c) step[c] = -(s.radius / gn_) * s.gradient[c] / s.diagonal[c];
+    const double k = -(s.radius / nrm3(s.g0, s.g1, s.g2));
+    s0 = k * s.g0 / s.d0;
+    s1 = k * s.g1 / s.d1;
+    s2 = k * s.g2 / s.d2;
     s.step_norm = s.radius;
     return true;
   }
-  double y2[2];
-  min_on_circle(s.sB, s.sg, s.radius, y2);
-  if (!isfinite(y2[0]) || !isfinite(y2[1])) {
-    dogleg_traditional(s, step);
+  double yx, yy;
+  min_on_circle(s.sB00, s.sB01, s.sB11, s.sg0, s.sg1, s.radius, yx, yy);
+  if (!isfinite(yx) || !isfinite(yy)) {
+    dogleg_traditional(s, s0, s1, s2);
     return true;
   }
-  for (int c = 0; c < 3; ++c) step[c] = (s.basis[c][0] * y2[0] + s.basis[c][1] * y2[1]) / s.diagonal[c];
+  s0 = (s.b00 * yx + s.b01 * yy) / s.d0;
+  s1 = (s.b10 * yx + s.b11 * yy) / s.d1;
+  s2 = (s.b20 * yx + s.b21 * yy) / s.d2;
   s.step_norm = s.radius;
   return true;
 }
 
-// shared control block written by thread 0, read by everyone
-struct Control {
-  int action;          // 0: stop, 1: evaluate candidate, 2: retry step without evaluation
-  double cand[3];
-  double x[3];
-};
-
-struct SolveShared {
-  Dog dog;
-  Control ctl;
-  double red[kNW * 10 + 10];
-  double scale[3];
-  double x_cost, x_norm, model_cost_change;
-  double grad[3];
-  int iter, invalid;
-};
-
-// TrustRegionMinimizer::Minimize for 3 parameters.  x in/out (all threads hold the same copy).
-__device__ int trust_region_minimize(const Problem& q, double x[3], double& final_cost, int max_iter,
-                                     SolveShared& S) {
-  const bool t0 = threadIdx.x == 0;
+// TrustRegionMinimizer::Minimize for 3 parameters; every lane runs the same control flow.
+__device__ int trust_region_minimize(const Problem& q, double x[3], double& final_cost, int max_iter) {
   if (q.n == 0) {
     final_cost = 0.0;
     return 0;
   }
   double sums[10];
-  evaluate<true>(q, x, S.red, sums);
-  if (t0) {
-    S.dog.radius = 1e4;
-    S.dog.mu = 1e-8;
-    S.dog.reuse = 0;
-    S.x_cost = sums[0];
-    S.x_norm = norm3(x);
-    for (int c = 0; c < 3; ++c) S.grad[c] = sums[1 + c];
-    // jacobi scaling from the initial Jacobian, kept for the whole solve
-    S.scale[0] = 1.0 / (1.0 + sqrt(sums[4]));
-    S.scale[1] = 1.0 / (1.0 + sqrt(sums[7]));
-    S.scale[2] = 1.0 / (1.0 + sqrt(sums[9]));
-    S.iter = 0;
-    S.invalid = 0;
-  }
-  bool have_fresh = true;   // sums hold the evaluation at the current x
+  evaluate<true>(q, x, sums);
+  Dog s;
+  s.radius = 1e4;
+  s.mu = 1e-8;
+  s.reuse = 0;
+  s.step_norm = 0.0;
+  s.one_dim = 0;
+  double x_cost = sums[0];
+  double x_norm = nrm3(x[0], x[1], x[2]);
+  double gr0 = sums[1], gr1 = sums[2], gr2 = sums[3];
+  // jacobi scaling from the initial Jacobian, kept for the whole solve
+  const double sc0 = 1.0 / (1.0 + sqrt(sums[4])), sc1 = 1.0 / (1.0 + sqrt(sums[7])),
+               sc2 = 1.0 / (1.0 + sqrt(sums[9]));
+  int iter = 0, invalid = 0;
+  bool fresh = true;
   for (;;) {
-    if (t0) {
-      Control& C = S.ctl;
-      C.action = 0;
-      if (have_fresh) {
-        const double* sc = S.scale;
-        const double u[6] = {sums[4], sums[5], sums[6], sums[7], sums[8], sums[9]};
-        S.dog.JtJ[0] = u[0] * sc[0] * sc[0];
-        S.dog.JtJ[1] = S.dog.JtJ[3] = u[1] * sc[0] * sc[1];
-        S.dog.JtJ[2] = S.dog.JtJ[6] = u[2] * sc[0] * sc[2];
-        S.dog.JtJ[4] = u[3] * sc[1] * sc[1];
-        S.dog.JtJ[5] = S.dog.JtJ[7] = u[4] * sc[1] * sc[2];
-        S.dog.JtJ[8] = u[5] * sc[2] * sc[2];
-        for (int c = 0; c < 3; ++c) S.dog.Jtr[c] = S.grad[c] * sc[c];
-      }
-      // FinalizeIterationAndCheckIfMinimizerCanContinue
-      const double gmax = fmax(fabs(S.grad[0]), fmax(fabs(S.grad[1]), fabs(S.grad[2])));
-      bool go = S.iter < max_iter && !(gmax <= 1e-10) && !(S.dog.radius <= 1e-32);
-      while (go) {
-        ++S.iter;
-        double step[3];
-        bool valid = dogleg_compute_step(S.dog, step);
-        double mcc = 0;
-        if (valid) {
-          // model_cost_change = -(J step)^T (r + J step / 2) = -(g^T step + step^T JtJ step / 2)
-          double gs = 0, sBs = 0;
-          for (int a = 0; a < 3; ++a) {
-            gs += S.dog.Jtr[a] * step[a];
-            for (int b = 0; b < 3; ++b) sBs += step[a] * S.dog.JtJ[3 * a + b] * step[b];
-          }
-          mcc = -(gs + 0.5 * sBs);
-          valid = mcc > 0.0;
-        }
-        if (!valid) {
-          if (++S.invalid >= 5) {
-            go = false;
-            break;
-          }
-          S.dog.mu *= 10.0;
-          S.dog.reuse = 0;
-          if (!(S.iter < max_iter)) go = false;
-          continue;
-        }
-        S.invalid = 0;
-        S.model_cost_change = mcc;
-        for (int c = 0; c < 3; ++c) C.cand[c] = x[c] + step[c] * S.scale[c];
-        C.action = 1;
-        break;
-      }
+    if (fresh) {
+      s.A00 = sums[4] * sc0 * sc0;
+      s.A01 = sums[5] * sc0 * sc1;
+      s.A02 = sums[6] * sc0 * sc2;
+      s.A11 = sums[7] * sc1 * sc1;
+      s.A12 = sums[8] * sc1 * sc2;
+      s.A22 = sums[9] * sc2 * sc2;
+      s.r0 = gr0 * sc0;
+      s.r1 = gr1 * sc1;
+      s.r2 = gr2 * sc2;
+      fresh = false;
     }
-    __syncthreads();
-    if (S.ctl.action == 0) break;
-    double cand[3] = {S.ctl.cand[0], S.ctl.cand[1], S.ctl.cand[2]};
+    // FinalizeIterationAndCheckIfMinimizerCanContinue
+    if (iter >= max_iter) break;
+    if (fmax(fabs(gr0), fmax(fabs(gr1), fabs(gr2))) <= 1e-10) break;
+    if (s.radius <= 1e-32) break;
+    ++iter;
+    double st0 = 0, st1 = 0, st2 = 0;
+    bool valid = dogleg_compute_step(s, st0, st1, st2);
+    double mcc = 0;
+    if (valid) {
+      // model_cost_change = -(J step)'(r + J step/2) = -(g' step + step' JtJ step / 2)
+      const double gs = s.r0 * st0 + s.r1 * st1 + s.r2 * st2;
+      mcc = -(gs + 0.5 * qform(s, st0, st1, st2, st0, st1, st2));
+      valid = mcc > 0.0;
+    }
+    if (!valid) {
+      if (++invalid >= 5) break;
+      s.mu *= 10.0;   // StepIsInvalid
+      s.reuse = 0;
+      continue;
+    }
+    invalid = 0;
+    const double cand[3] = {x[0] + st0 * sc0, x[1] + st1 * sc1, x[2] + st2 * sc2};
     double cs[10];
-    evaluate<false>(q, cand, S.red, cs);
+    evaluate<false>(q, cand, cs);
     const double cand_cost = cs[0];
-    // decisions are pure functions of shared values: every thread takes the same branch
-    const double dx0 = x[0] - cand[0], dx1 = x[1] - cand[1], dx2 = x[2] - cand[2];
-    const double step_norm = sqrt(dx0 * dx0 + dx1 * dx1 + dx2 * dx2);
-    const double x_cost = S.x_cost, x_norm = S.x_norm, mcc = S.model_cost_change;
-    __syncthreads();
+    const double step_norm = nrm3(x[0] - cand[0], x[1] - cand[1], x[2] - cand[2]);
     if (step_norm <= 1e-8 * (x_norm + 1e-8)) break;            // ParameterToleranceReached
     const double cost_change = x_cost - cand_cost;
     if (fabs(cost_change) <= 1e-6 * x_cost) break;             // FunctionToleranceReached
@@ -452,42 +439,133 @@ __device__ int trust_region_minimize(const Problem& q, double x[3], double& fina
       x[0] = cand[0];
       x[1] = cand[1];
       x[2] = cand[2];
-      evaluate<true>(q, x, S.red, sums);
-      have_fresh = true;
-      if (t0) {
-        S.x_cost = sums[0];
-        S.x_norm = norm3(x);
-        for (int c = 0; c < 3; ++c) S.grad[c] = sums[1 + c];
-        if (rel < 0.25) S.dog.radius *= 0.5;
-        if (rel > 0.75) S.dog.radius = fmax(S.dog.radius, 3.0 * S.dog.step_norm);
-        if (S.dog.radius > 1e16) S.dog.radius = 1e16;
-        S.dog.mu = fmax(1e-8, 2.0 * S.dog.mu / 10.0);
-        S.dog.reuse = 0;
-      }
+      x_norm = nrm3(x[0], x[1], x[2]);
+      evaluate<true>(q, x, sums);
+      x_cost = sums[0];
+      gr0 = sums[1];
+      gr1 = sums[2];
+      gr2 = sums[3];
+      fresh = true;
+      if (rel < 0.25) s.radius *= 0.5;                         // DoglegStrategy::StepAccepted
+      if (rel > 0.75) s.radius = fmax(s.radius, 3.0 * s.step_norm);
+      if (s.radius > 1e16) s.radius = 1e16;
+      s.mu = fmax(1e-8, 2.0 * s.mu / 10.0);
+      s.reuse = 0;
     } else {                                                   // StepRejected
-      have_fresh = false;
-      if (t0) {
-        S.dog.radius *= 0.5;
-        S.dog.reuse = 1;
-      }
+      s.radius *= 0.5;
+      s.reuse = 1;
     }
   }
-  __syncthreads();
-  final_cost = S.x_cost;
-  const int it = S.iter;
-  __syncthreads();
-  return it;
+  final_cost = x_cost;
+  return iter;
 }
 
-__device__ double cost_only(const Problem& q, const double x[3], SolveShared& S) {
+// ------------------------------------------------------------------ K7a
+__device__ __forceinline__ bool partial_less(const GridPartial& a, const GridPartial& b) {
+  return a.cost < b.cost || (a.cost == b.cost && (a.d2 < b.d2 || (a.d2 == b.d2 && a.flat < b.flat)));
+}
+
+template <bool LDS_POINTS>
+__device__ void solve_body(const Ctx& c, SolveRec* rec, float2* s_yz, uint8_t* s_lab) {
+  const uint32_t f = blockIdx.x, slot = blockIdx.y;
+  ilcc_result* r = &c.res[f];
+  SolveRec* out = &rec[2 * f + slot];
+  const int lane = lane_id();
+  const uint64_t beg = c.off[f];
+  const uint32_t n = c.n_lab[f];
+
+  Problem q;
+  q.n = n;
+  q.bd = Board{(double)c.p.board_w, (double)c.p.board_h, c.p.grid_length, c.p.huber_delta};
+  if (LDS_POINTS) {
+    for (uint32_t i = lane; i < n; i += ILCC_WAVE) {
+      s_yz[i] = c.yz[beg + i];
+      s_lab[i] = c.lab[beg + i];
+    }
+    __syncthreads();
+    q.yz = s_yz;
+    q.lab = s_lab;
+  } else {
+    q.yz = c.yz + beg;
+    q.lab = c.lab + beg;
+  }
+
+  double x[3] = {0.0, 0.0, 0.0};
+  int phase = (int)slot;
+  if (c.p.solver == ILCC_SOLVER_GRID) {
+    // argmin over this frame's K6 partials: cost, then index distance to zero, then flat index
+    const GridPartial* gp = c.partial + (uint64_t)f * c.grid_blocks;
+    GridPartial b{__builtin_inff(), 0xFFFFFFFFu, 0xFFFFFFFFu, 0u};
+    for (uint32_t k = lane; k < c.grid_blocks; k += ILCC_WAVE) {
+      const GridPartial t = gp[k];
+      if (partial_less(t, b)) b = t;
+    }
+#pragma unroll
+    for (int o = ILCC_WAVE / 2; o > 0; o >>= 1) {
+      GridPartial t;
+      t.cost = __shfl_xor(b.cost, o, ILCC_WAVE);
+      t.d2 = __shfl_xor(b.d2, o, ILCC_WAVE);
+      t.flat = __shfl_xor(b.flat, o, ILCC_WAVE);
+      if (partial_less(t, b)) b = t;
+    }
+    if (lane == 0) {
+      r->grid_index = (int32_t)b.flat;
+      r->grid_cost = b.cost;
+    }
+    if (b.flat == 0xFFFFFFFFu) {
+      if (lane == 0) out->valid = 0;
+      return;
+    }
+    const uint32_t cell = b.flat >> 1;
+    const uint32_t bz = cell % (uint32_t)c.p.n_tz, ay = (cell / (uint32_t)c.p.n_tz) % (uint32_t)c.p.n_ty,
+                   k = cell / ((uint32_t)c.p.n_tz * (uint32_t)c.p.n_ty);
+    x[0] = c.p.th_min + k * c.p.th_step;
+    x[1] = c.p.ty_min + ay * c.p.ty_step;
+    x[2] = c.p.tz_min + bz * c.p.tz_step;
+    phase = (int)(b.flat & 1u);
+  } else if (c.p.phase_mode != 2) {
+    phase = (c.p.phase_mode == 1) ? 1 : 0;
+  }
+
+  double ca = 0, cb = 0;
+  q.tlw = phase != 0;
+  q.oob = true;    // pass A (LidarCornersEst.cpp:403-405)
+  const int ia = trust_region_minimize(q, x, ca, c.p.max_iterations);
+  q.oob = false;   // pass B (:406-408)
+  const int ib = trust_region_minimize(q, x, cb, c.p.max_iterations);
+  q.oob = true;
   double cs[10];
-  evaluate<false>(q, x, S.red, cs);
-  const double v = cs[0];
-  __syncthreads();
-  return v;
+  evaluate<false>(q, x, cs);
+  if (lane == 0) {
+    out->x[0] = x[0];
+    out->x[1] = x[1];
+    out->x[2] = x[2];
+    out->cost_a = ca;
+    out->cost_b = cb;
+    out->sel = cs[0];
+    out->iters_a = ia;
+    out->iters_b = ib;
+    out->phase = phase;
+    out->valid = 1;
+  }
 }
 
-// ------------------------------------------------------------------ corners (getPCDcorners)
+__global__ __launch_bounds__(ILCC_WAVE) void k7a_local_solve(Ctx c, SolveRec* rec) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const uint32_t f = blockIdx.x;
+  if (c.res[f].status != ILCC_OK) {
+    if (threadIdx.x == 0) rec[2 * f + blockIdx.y].valid = 0;
+    return;
+  }
+  float2* s_yz = reinterpret_cast<float2*>(smem);
+  uint8_t* s_lab = smem + sizeof(float2) * (size_t)c.grid_lds_points;
+  if (c.n_lab[f] <= c.grid_lds_points)
+    solve_body<true>(c, rec, s_yz, s_lab);
+  else
+    solve_body<false>(c, rec, s_yz, s_lab);
+}
+
+// ------------------------------------------------------------------ K7b corners (getPCDcorners)
 __device__ __forceinline__ void inv_rigid_apply(const float* T, const float in[3], float out[3]) {
   const float dx = in[0] - T[3], dy = in[1] - T[7], dz = in[2] - T[11];
 #pragma unroll
@@ -499,99 +577,37 @@ __device__ __forceinline__ void inv_rigid_apply(const float* T, const float in[3
   }
 }
 
-__global__ __launch_bounds__(kSolveThreads) void k7_refine_corners(Ctx c) {
-  __shared__ SolveShared S;
+__global__ __launch_bounds__(kSolveThreads) void k7b_corners(Ctx c, const SolveRec* rec, int n_slots) {
   __shared__ float s_T[16];
-  __shared__ uint32_t s_pick[4];
   const uint32_t f = blockIdx.x;
   ilcc_result* r = &c.res[f];
   if (r->status != ILCC_OK) return;
-  const uint64_t beg = c.off[f];
   const uint32_t tid = threadIdx.x;
-
-  Problem q;
-  q.yz = c.yz + beg;
-  q.lab = c.lab + beg;
-  q.n = c.n_lab[f];
-  q.bd = Board{(double)c.p.board_w, (double)c.p.board_h, c.p.grid_length, c.p.huber_delta};
-
-  double start[3] = {0.0, 0.0, 0.0};
-  int ph_lo = 0, ph_hi = 0;
-  if (c.p.solver == ILCC_SOLVER_GRID) {
-    // argmin over this frame's K6 partials: cost, then index distance to zero, then flat index
-    if (tid == 0) {
-      const GridPartial* gp = c.partial + (uint64_t)f * c.grid_blocks;
-      GridPartial b = gp[0];
-      for (uint32_t k = 1; k < c.grid_blocks; ++k) {
-        const GridPartial t = gp[k];
-        if (t.cost < b.cost || (t.cost == b.cost && (t.d2 < b.d2 || (t.d2 == b.d2 && t.flat < b.flat)))) b = t;
-      }
-      s_pick[0] = b.flat;
-      r->grid_index = (int32_t)b.flat;
-      r->grid_cost = b.cost;
-    }
-    __syncthreads();
-    const uint32_t flat = s_pick[0];
-    if (flat == 0xFFFFFFFFu) {
-      if (tid == 0) r->status = ILCC_BAD_ARGUMENT;
-      return;
-    }
-    const uint32_t cell = flat >> 1;
-    const uint32_t bz = cell % (uint32_t)c.p.n_tz, ay = (cell / (uint32_t)c.p.n_tz) % (uint32_t)c.p.n_ty,
-                   k = cell / ((uint32_t)c.p.n_tz * (uint32_t)c.p.n_ty);
-    start[0] = c.p.th_min + k * c.p.th_step;
-    start[1] = c.p.ty_min + ay * c.p.ty_step;
-    start[2] = c.p.tz_min + bz * c.p.tz_step;
-    ph_lo = ph_hi = (int)(flat & 1u);
-  } else {
-    if (c.p.phase_mode == 2) {
-      ph_lo = 0;
-      ph_hi = 1;
-    } else {
-      ph_lo = ph_hi = (c.p.phase_mode == 1) ? 1 : 0;
-    }
+  const uint64_t beg = c.off[f];
+  // phase selection: lower with-OOB cost, ties -> phase 0 (the reference's first hypothesis)
+  SolveRec best = rec[2 * f];
+  if (n_slots > 1) {
+    const SolveRec o = rec[2 * f + 1];
+    if (o.valid && (!best.valid || o.sel < best.sel)) best = o;
   }
-
-  double best_sel = 1.7976931348623157e308;
-  double bx[3] = {0, 0, 0}, bca = 0, bcb = 0;
-  int bph = ph_lo, bia = 0, bib = 0;
-  for (int ph = ph_lo; ph <= ph_hi; ++ph) {
-    double x[3] = {start[0], start[1], start[2]};
-    double ca = 0, cb = 0;
-    q.tlw = ph != 0;
-    q.oob = true;    // pass A (LidarCornersEst.cpp:403-405)
-    const int ia = trust_region_minimize(q, x, ca, c.p.max_iterations, S);
-    q.oob = false;   // pass B (:406-408)
-    const int ib = trust_region_minimize(q, x, cb, c.p.max_iterations, S);
-    q.oob = true;
-    const double sel = cost_only(q, x, S);
-    if (sel < best_sel) {
-      best_sel = sel;
-      bx[0] = x[0];
-      bx[1] = x[1];
-      bx[2] = x[2];
-      bca = ca;
-      bcb = cb;
-      bph = ph;
-      bia = ia;
-      bib = ib;
-    }
+  if (!best.valid) {
+    if (tid == 0) r->status = ILCC_BAD_ARGUMENT;
+    return;
   }
-
   // transf = pcl::getTransformation(0, ty, tz, theta, 0, 0): float Affine3f (:412)
   if (tid == 0) {
-    r->theta_t[0] = bx[0];
-    r->theta_t[1] = bx[1];
-    r->theta_t[2] = bx[2];
-    r->cost_a = bca;
-    r->cost_b = bcb;
-    r->sel_cost = best_sel;
-    r->phase = bph;
-    r->iters_a = bia;
-    r->iters_b = bib;
-    const float roll = (float)bx[0];
+    r->theta_t[0] = best.x[0];
+    r->theta_t[1] = best.x[1];
+    r->theta_t[2] = best.x[2];
+    r->cost_a = best.cost_a;
+    r->cost_b = best.cost_b;
+    r->sel_cost = best.sel;
+    r->phase = best.phase;
+    r->iters_a = best.iters_a;
+    r->iters_b = best.iters_b;
+    const float roll = (float)best.x[0];
     const float E = cosf(roll), F = sinf(roll);
-    const float T[16] = {1, 0, 0, 0, 0, E, -F, (float)bx[1], 0, F, E, (float)bx[2], 0, 0, 0, 1};
+    const float T[16] = {1, 0, 0, 0, 0, E, -F, (float)best.x[1], 0, F, E, (float)best.x[2], 0, 0, 0, 1};
     for (int k = 0; k < 16; ++k) s_T[k] = T[k];
   }
   __syncthreads();
@@ -632,10 +648,9 @@ __global__ __launch_bounds__(kSolveThreads) void k7_refine_corners(Ctx c) {
   }
 }
 
-// test entry: one solve on frame 0's labelled points
-__global__ __launch_bounds__(kSolveThreads) void k7_local_solve(Ctx c, int tlw, int use_oob,
-                                                                double* theta_t, double* cost_iters) {
-  __shared__ SolveShared S;
+// test entry: one solve on frame 0's labelled points (global memory)
+__global__ __launch_bounds__(ILCC_WAVE) void k7_local_solve_test(Ctx c, int tlw, int use_oob, double* theta_t,
+                                                                 double* cost_iters) {
   Problem q;
   q.yz = c.yz;
   q.lab = c.lab;
@@ -644,9 +659,8 @@ __global__ __launch_bounds__(kSolveThreads) void k7_local_solve(Ctx c, int tlw, 
   q.tlw = tlw != 0;
   q.oob = use_oob != 0;
   double x[3] = {theta_t[0], theta_t[1], theta_t[2]};
-  __syncthreads();
   double cost = 0;
-  const int it = trust_region_minimize(q, x, cost, c.p.max_iterations, S);
+  const int it = trust_region_minimize(q, x, cost, c.p.max_iterations);
   if (threadIdx.x == 0) {
     theta_t[0] = x[0];
     theta_t[1] = x[1];
@@ -657,13 +671,21 @@ __global__ __launch_bounds__(kSolveThreads) void k7_local_solve(Ctx c, int tlw, 
 }
 
 void launch_refine_corners(const Ctx& c, hipStream_t s) {
-  hipLaunchKernelGGL(k7_refine_corners, dim3(c.n_frames), dim3(kSolveThreads), 0, s, c);
+  const int n_slots = (c.p.solver == ILCC_SOLVER_REFERENCE_LOCAL && c.p.phase_mode == 2) ? 2 : 1;
+  const size_t lds = (sizeof(float2) + 1) * (size_t)c.grid_lds_points;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)k7a_local_solve, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)((sizeof(float2) + 1) * (size_t)kGridLdsPointsMax));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(k7a_local_solve, dim3(c.n_frames, n_slots), dim3(ILCC_WAVE), lds, s, c, c.solve_rec);
+  hipLaunchKernelGGL(k7b_corners, dim3(c.n_frames), dim3(kSolveThreads), 0, s, c, c.solve_rec, n_slots);
 }
 
 void launch_local_solve(const Ctx& c, hipStream_t s, int32_t tlw, int32_t use_oob, double* theta_t,
                         double* cost_iters) {
-  hipLaunchKernelGGL(k7_local_solve, dim3(1), dim3(kSolveThreads), 0, s, c, tlw, use_oob, theta_t,
-                     cost_iters);
+  hipLaunchKernelGGL(k7_local_solve_test, dim3(1), dim3(ILCC_WAVE), 0, s, c, tlw, use_oob, theta_t, cost_iters);
 }
 
 }  // namespace ilcc

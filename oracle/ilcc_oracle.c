@@ -737,38 +737,76 @@ static int chol3_solve(const double A[9], const double b[3], double x[3]) {
   return 1;
 }
 
-/* minimise 0.5 y'By + g'y on |y| = radius (2-D).  Ceres solves a quartic
- * (DoglegStrategy::FindMinimumOnTrustRegionBoundary); any exact method gives the same point:
- * dense scan of the angle + Newton polish. */
+/* minimise 0.5 y'By + g'y on |y| = radius (2-D, B symmetric positive semi-definite).
+ * Ceres solves a quartic (DoglegStrategy::FindMinimumOnTrustRegionBoundary); the minimiser is
+ * the same point whichever exact method finds it.  Here: eigen-decomposition of B and Newton
+ * on the secular equation 1/|y(lam)| = 1/radius (More-Sorensen), y(lam) = -(B + lam I)^-1 g.
+ * The HIP kernel uses the same routine. */
 static void min_on_circle(const double B[4], const double g[2], double radius, double y[2]) {
-  const int NS = 720;
-  double best = DBL_MAX, bt = 0;
-  for (int k = 0; k < NS; ++k) {
-    const double t = 2.0 * M_PI * k / NS;
-    const double a = radius * cos(t), b = radius * sin(t);
-    const double f = 0.5 * (B[0] * a * a + 2 * B[1] * a * b + B[3] * b * b) + g[0] * a + g[1] * b;
-    if (f < best) {
-      best = f;
-      bt = t;
+  const double d = 0.5 * (B[0] - B[3]), e = B[1];
+  const double h = sqrt(d * d + e * e), mean = 0.5 * (B[0] + B[3]);
+  const double l1 = mean - h, l2 = mean + h;
+  /* unit eigenvector of l2 */
+  double v2x, v2y;
+  if (h == 0.0) {
+    v2x = 1.0;
+    v2y = 0.0;
+  } else if (d >= 0.0) {
+    v2x = d + h;
+    v2y = e;
+  } else {
+    v2x = e;
+    v2y = h - d;
+  }
+  {
+    const double nv = sqrt(v2x * v2x + v2y * v2y);
+    if (nv > 0.0) {
+      v2x /= nv;
+      v2y /= nv;
+    } else {
+      v2x = 1.0;
+      v2y = 0.0;
     }
   }
-  double t = bt;
-  for (int it = 0; it < 50; ++it) {
-    const double c = cos(t), s = sin(t);
-    const double a = radius * c, b = radius * s, da = -radius * s, db = radius * c;
-    /* f'(t), f''(t) */
-    const double Ba = B[0] * a + B[1] * b, Bb = B[1] * a + B[3] * b;
-    const double f1 = Ba * da + Bb * db + g[0] * da + g[1] * db;
-    const double Bda = B[0] * da + B[1] * db, Bdb = B[1] * da + B[3] * db;
-    const double f2 = Bda * da + Bdb * db + Ba * (-a) + Bb * (-b) + g[0] * (-a) + g[1] * (-b);
-    if (!(f2 > 0)) break;
-    const double step = f1 / f2;
-    if (fabs(step) > M_PI / NS) break; /* left the bracket: keep scan result */
-    t -= step;
-    if (fabs(step) < 1e-15) break;
+  const double v1x = -v2y, v1y = v2x;
+  const double g1 = v1x * g[0] + v1y * g[1], g2 = v2x * g[0] + v2y * g[1];
+  const double gn = sqrt(g1 * g1 + g2 * g2);
+  double lo = fmax(0.0, -l1);
+  lo = fmax(lo, gn / radius - l2);
+  const double hi = gn / radius - l1;
+  double lam = lo;
+  if (!(l1 + lam > 0.0)) lam = lo + 1e-12 * fmax(1.0, fabs(hi));
+  for (int it = 0; it < 60; ++it) {
+    const double a1 = l1 + lam, a2 = l2 + lam;
+    const double y1 = -g1 / a1, y2 = -g2 / a2;
+    const double ny = sqrt(y1 * y1 + y2 * y2);
+    const double qq = g1 * g1 / (a1 * a1 * a1) + g2 * g2 / (a2 * a2 * a2);
+    if (!(qq > 0.0) || !isfinite(ny)) break;
+    const double dl = (ny * ny / qq) * ((ny - radius) / radius);
+    double nl = lam + dl;
+    if (!(l1 + nl > 0.0)) nl = 0.5 * (lam + fmax(0.0, -l1)); /* safeguard: stay right of the pole */
+    if (fabs(nl - lam) <= 1e-15 * fmax(1.0, fabs(nl))) {
+      lam = nl;
+      break;
+    }
+    lam = nl;
   }
-  y[0] = radius * cos(t);
-  y[1] = radius * sin(t);
+  {
+    const double a1 = l1 + lam, a2 = l2 + lam;
+    double y1 = (a1 > 0.0) ? -g1 / a1 : 0.0, y2 = (a2 > 0.0) ? -g2 / a2 : 0.0;
+    double ny = sqrt(y1 * y1 + y2 * y2);
+    if (ny < radius * (1.0 - 1e-9) && !(a1 > 1e-300 * fmax(1.0, l2))) {
+      /* hard case: g has no component along the soft eigenvector; move along it to the boundary */
+      y1 = sqrt(fmax(0.0, radius * radius - y2 * y2));
+      ny = radius;
+    }
+    if (ny > 0.0) { /* land exactly on the circle */
+      y1 *= radius / ny;
+      y2 *= radius / ny;
+    }
+    y[0] = v1x * y1 + v2x * y2;
+    y[1] = v1y * y1 + v2y * y2;
+  }
 }
 
 typedef struct {
