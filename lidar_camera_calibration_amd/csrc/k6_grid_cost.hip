@@ -28,6 +28,10 @@
 
 namespace ilcc {
 
+typedef unsigned long long lanemask_t;
+__device__ __forceinline__ lanemask_t ballot(bool b) { return __builtin_amdgcn_ballot_w64(b); }
+__device__ __forceinline__ bool unballot(lanemask_t m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
+
 struct Best {
   float cost;
   uint32_t d2;
@@ -92,6 +96,11 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
     for (int a = 0; a < kTileA; ++a) ayv[a] = c.ay[min(a0 + a, n_ty - 1)];
 #pragma unroll
     for (int b = 0; b < kTileB; ++b) azv[b] = c.az[min(b0 + b, n_tz - 1)];
+    float ayh[kTileA], azh[kTileB];
+#pragma unroll
+    for (int a = 0; a < kTileA; ++a) ayh[a] = 0.5f * ayv[a];
+#pragma unroll
+    for (int b = 0; b < kTileB; ++b) azh[b] = 0.5f * azv[b];
 
     float x0[kTileA][kTileB], x1[kTileA][kTileB];
 #pragma unroll
@@ -111,52 +120,58 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
         lab = idx < M ? glab[idx] : 0;
       }
       const float dl = idx < M ? delta : 0.f;   // padded lanes: q = min(r,0) = 0 -> no contribution
-      const bool white = lab != 0;
+      // Lane predicates are kept as 64-bit wave masks in SGPR pairs (ballot), combined with SALU
+      // ops per candidate and fed straight back to v_cndmask (inverse ballot): the VALU only
+      // sees the float work.
+      const lanemask_t white = ballot(lab != 0);
       // Rx(theta) on (0,y,z), already divided by g (Optimization.h:37-46)
       const float bi = fmaf(-sth, p.y, cth * p.x);
       const float bj = fmaf(cth, p.y, sth * p.x);
+      const float bih = 0.5f * bi, bjh = 0.5f * bj;
 
       float di[kTileA], ui[kTileA];
-      bool pa[kTileA], oa[kTileA];
+      lanemask_t pa[kTileA], oa[kTileA];
 #pragma unroll
       for (int a = 0; a < kTileA; ++a) {
         const float i = bi + ayv[a];
-        di[a] = fabsf(i - rintf(i));               // distance to the nearest cell border
-        pa[a] = ((((int)floorf(i)) & 1) != 0) != white;   // parity xor label
-        const float tt = fabsf(i - Wh);
-        oa[a] = !(tt < Wh);                        // not (0 < i < W)
-        ui[a] = fabsf(tt - Wh);                    // min(|i|, |i-W|)
+        di[a] = i - rintf(i);                       // |.| = distance to the nearest cell border
+        // floor(i) odd  <=>  fract(i/2) >= 1/2 ; xor label -> colour mismatch contribution of i
+        pa[a] = ballot(__builtin_amdgcn_fractf(bih + ayh[a]) >= 0.5f) ^ white;
+        const float tt = i - Wh;
+        oa[a] = ballot(!(fabsf(tt) < Wh));          // not (0 < i < W)
+        ui[a] = fabsf(tt) - Wh;                     // |.| = min(|i|, |i-W|)
       }
       float dj[kTileB], uj[kTileB];
-      bool pb[kTileB], ob[kTileB];
+      lanemask_t pb[kTileB], ob[kTileB];
 #pragma unroll
       for (int b = 0; b < kTileB; ++b) {
         const float j = bj + azv[b];
-        dj[b] = fabsf(j - rintf(j));
-        pb[b] = (((int)floorf(j)) & 1) != 0;
-        const float tt = fabsf(j - Hh);
-        ob[b] = !(tt < Hh);
-        uj[b] = fabsf(tt - Hh);
+        dj[b] = j - rintf(j);
+        pb[b] = ballot(__builtin_amdgcn_fractf(bjh + azh[b]) >= 0.5f);
+        const float tt = j - Hh;
+        ob[b] = ballot(!(fabsf(tt) < Hh));
+        uj[b] = fabsf(tt) - Hh;
       }
 #pragma unroll
       for (int a = 0; a < kTileA; ++a)
 #pragma unroll
         for (int b = 0; b < kTileB; ++b) {
-          const bool oob = oa[a] | ob[b];
-          const bool mis0 = pa[a] != pb[b];      // colour mismatch under phase 0 (topleftWhite=false)
+          const lanemask_t oob = oa[a] | ob[b];
+          const lanemask_t mis0 = pa[a] ^ pb[b];   // colour mismatch under phase 0 (topleftWhite=false)
+          const float rin = fabsf(di[a]) + fabsf(dj[b]);
           float rr;
           if (OOB)
-            rr = oob ? (ui[a] + uj[b]) : (di[a] + dj[b]);
+            rr = unballot(oob) ? (fabsf(ui[a]) + fabsf(uj[b])) : rin;
           else
-            rr = oob ? 0.f : (di[a] + dj[b]);
+            rr = unballot(oob) ? 0.f : rin;
           const float q = fminf(rr, dl);
           const float h = q * fmaf(-0.5f, q, rr);
           if (OOB) {
-            x0[a][b] += (oob | mis0) ? h : 0.f;
-            x1[a][b] += (oob | !mis0) ? h : 0.f;
+            x0[a][b] += unballot(oob | mis0) ? h : 0.f;
+            x1[a][b] += unballot(oob | ~mis0) ? h : 0.f;
           } else {
-            x0[a][b] += mis0 ? h : 0.f;
-            x1[a][b] += mis0 ? 0.f : h;
+            x0[a][b] += unballot(mis0) ? h : 0.f;
+            x1[a][b] += unballot(mis0) ? 0.f : h;
           }
         }
     }

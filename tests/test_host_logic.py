@@ -1,0 +1,164 @@
+"""CPU tests of the host side: C-ABI surface, file contracts, yaml reader, sharding (gloo, 2 ranks)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from lidar_camera_calibration_amd import _native as N
+from lidar_camera_calibration_amd import sharding, synth
+from lidar_camera_calibration_amd.lidar_corners_est import (LidarCornersEst, read_lidar_corners,
+                                                           save_corners2txt)
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _has_gpu():
+    import torch
+    return torch.cuda.is_available()
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "ilcc_hip.h")).read()
+    declared = set(re.findall(r"\b(ilcc_[a-z0-9_]+)\s*\(", header))
+    declared -= {"ilcc_handle", "ilcc_params", "ilcc_result", "ilcc_timing"}
+    assert declared == set(N.EXPORTS)
+    lib = N.lib()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.ilcc_abi_version() == 1
+
+
+def test_struct_layouts_match_the_library():
+    """ctypes mirrors vs the compiled structs: default params round-trip through C."""
+    p = N.default_params()
+    assert tuple(p.roi_half) == (1.0, 1.5, 2.0)
+    assert (p.cluster_tol, p.cluster_min, p.cluster_max) == (0.12, 100, 25000)
+    assert p.ransac_thresh == 0.03 and p.hist_bins == 100 and p.gray_rate == 2.5 and p.huber_delta == 0.1
+    assert (p.grid_length, p.board_w, p.board_h) == (0.15, 6, 8)
+    assert p.solver == N.SOLVER_GRID and p.phase_mode == 2 and p.max_iterations == 50
+    assert (p.n_th, p.n_ty, p.n_tz) == (61, 40, 40)
+    assert p.tz_step == pytest.approx(0.0075) and p.tz_min == pytest.approx(-0.15)
+    assert C.sizeof(N.Result) == 14 * 4 + 4 + 16 + 64 + 4 + 16 + 24 + 24 + 3 * 4 * 256  # no hidden padding surprises
+
+
+def test_defaults_agree_with_the_oracle(ob):
+    p, o = N.default_params(), ob.default_params()
+    for f in ("cluster_tol", "cluster_min", "cluster_max", "ransac_thresh", "ransac_hyp", "ransac_seed",
+              "hist_bins", "gray_rate", "huber_delta", "grid_length", "board_w", "board_h", "phase_mode",
+              "n_th", "n_ty", "n_tz", "th_min", "th_step", "ty_min", "ty_step", "tz_min", "tz_step"):
+        assert getattr(p, f) == getattr(o, f), f
+    assert tuple(p.roi_half) == tuple(o.roi_half)
+
+
+def test_strerror_and_no_device_failure():
+    lib = N.lib()
+    assert lib.ilcc_strerror(N.OK) == b"ok"
+    assert b"cluster" in lib.ilcc_strerror(N.NO_CLUSTER)
+    if _has_gpu():
+        pytest.skip("device present")
+    p = N.default_params()
+    assert not lib.ilcc_create(-1, C.byref(p), 1, 1000)
+    assert b"no CPU fallback" in lib.ilcc_last_error(None)
+    with pytest.raises(Exception):
+        est = LidarCornersEst()
+        est.setROI(np.zeros((10, 4), np.float32), [0, 0, 0])
+        est.EuclideanCluster()
+
+
+def test_set_chessboard_param_reads_reference_yaml(golden_dir, tmp_path, capsys):
+    p = N.default_params()
+    assert N.lib().ilcc_set_chessboard_param(C.byref(p), os.path.join(golden_dir, "pointgrey.yaml").encode()) == 0
+    assert (p.grid_length, p.board_w, p.board_h) == (0.15, 6, 8)      # 5+1, 7+1 sorted ascending
+    y = tmp_path / "b.yaml"
+    y.write_text("%YAML:1.0\ngrid_length: 0.10\ncorner_in_x: 11   # comment\ncorner_in_y: 8\n")
+    assert N.lib().ilcc_set_chessboard_param(C.byref(p), str(y).encode()) == 0
+    assert (p.grid_length, p.board_w, p.board_h) == (0.10, 9, 12)
+    assert p.ty_step == pytest.approx(0.005) and p.ty_min == pytest.approx(-0.10)   # grid follows g
+    assert N.lib().ilcc_set_chessboard_param(C.byref(p), b"/nonexistent.yaml") == N.IO_ERROR
+    bad = tmp_path / "bad.yaml"
+    bad.write_text("grid_length: 0.1\n")
+    assert N.lib().ilcc_set_chessboard_param(C.byref(p), str(bad).encode()) == N.BAD_ARGUMENT
+    est = LidarCornersEst.__new__(LidarCornersEst)
+    est._lib, est.params, est._h = N.lib(), N.default_params(), None
+    assert est.set_chessboard_param("/nonexistent.yaml") is False
+    assert "can not open" in capsys.readouterr().out
+    assert est.set_chessboard_param(os.path.join(golden_dir, "pointgrey.yaml")) is True
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 6])
+def test_corner_file_writer_is_byte_identical_to_reference_files(golden_dir, tmp_path, n):
+    """save_corners2txt through the C-ABI regenerates the reference's own files byte for byte, and
+    read_lidar_corners (the consumer, ImageCornersEst.cpp:281-299) reads them back."""
+    src = os.path.join(golden_dir, "pointgrey_lidar_%d.txt" % n)
+    corners = np.loadtxt(src, dtype=np.float32)
+    out = tmp_path / ("pointgrey_lidar_%d.txt" % n)
+    save_corners2txt(corners, str(out))
+    assert out.read_bytes() == open(src, "rb").read()
+    back = read_lidar_corners(str(out), 35)
+    assert back.shape == (35, 3) and np.array_equal(back.astype(np.float32), corners)
+    assert len(read_lidar_corners(str(out), 10)) == 10
+    assert len(read_lidar_corners(str(out), 100)) == 35
+
+
+def test_synth_generator_is_deterministic_and_shaped():
+    board = synth.Board()
+    a, ka, ga, _ = synth.make_batch(2, seed=7)
+    b, kb, gb, _ = synth.make_batch(2, seed=7)
+    assert a.shape == (2, 28800, 4) and a.dtype == np.float32 and np.array_equal(a, b) and np.array_equal(ka, kb)
+    assert ga.shape == (2, 35, 3)
+    assert np.isfinite(a).all() and a[..., 3].min() >= 0 and a[..., 3].max() <= 255
+    c, _, _, _ = synth.make_batch(1, synth.hdl64(), synth.Board(9, 12, 0.10), seed=1)
+    assert c.shape == (1, 131072, 4)
+    pose = synth.pose_from_fixture(0)
+    assert synth.corner_error(synth.true_corners(pose, board)[::-1], synth.true_corners(pose, board), board) < 1e-12
+
+
+def test_shard_ranges_and_record_packing():
+    assert [sharding.shard_range(10, 4, r) for r in range(4)] == [(0, 3), (3, 6), (6, 9), (9, 10)]
+    assert [sharding.shard_range(2, 4, r) for r in range(4)] == [(0, 1), (1, 2), (2, 2), (2, 2)]
+    res = (N.Result * 2)()
+    res[0].status, res[0].n_corners, res[0].phase = 0, 35, 1
+    for k in range(105):
+        res[0].corners[k] = k * 0.5
+    res[1].status = N.NO_CLUSTER
+    rec = sharding.pack_records(res, 2, 35)
+    assert rec.shape == (2, 16 + 105) and rec[0, 1] == 35 and rec[1, 0] == N.NO_CLUSTER
+    cs = sharding.unpack_corners(rec)
+    assert cs[0].shape == (35, 3) and cs[0][34, 2] == 52.0 and cs[1].shape == (0, 3)
+
+
+def _gloo_worker(rank, world, port, clouds, clicks, out_dir):
+    import torch.distributed as dist
+    from oracle import binding as ob_          # stand-in producer for the CPU test only
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    p = ob_.default_params()
+    p.solver = ob_.SOLVER_REFERENCE_LOCAL
+
+    def producer(cl, ck):
+        return [ob_.extract(cl[i], ck[i], p) for i in range(len(ck))]
+    g = sharding.run_sharded(producer, clouds, clicks, world, rank, 35)
+    if rank == 0:
+        np.save(os.path.join(out_dir, "gathered.npy"), g)
+    else:
+        assert g is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gather_matches_single_process(ob, tmp_path):
+    """world_size 2 over gloo: contiguous shards, one gather, records identical to a 1-rank run
+    (3 frames -> ranks own 2 + 1, the short shard is padded and the padding dropped)."""
+    import torch.multiprocessing as mp
+    clouds, clicks, _, _ = synth.make_batch(3, fixture_poses=True)
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_gloo_worker, args=(2, port, clouds, clicks, str(tmp_path)), nprocs=2, join=True)
+    got = np.load(tmp_path / "gathered.npy")
+    p = ob.default_params()
+    p.solver = ob.SOLVER_REFERENCE_LOCAL
+    want = sharding.pack_records([ob.extract(clouds[i], clicks[i], p) for i in range(3)], 3, 35)
+    assert got.shape == want.shape == (3, 16 + 105)
+    assert np.array_equal(got, want)

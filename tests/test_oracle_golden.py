@@ -1,0 +1,397 @@
+"""CPU tests: the oracle (oracle/ilcc_oracle.c) against everything the reference pins for this path.
+
+The reference ships no tests and cannot be built here (parity unpinned for input->output); what it
+does pin are (a) the cost functor's arithmetic (Optimization.h:31-107, hand-derived KATs), (b) the six
+output files process_data/pointgrey_lidar_{1..6}.txt and (c) the writer format.  Independent
+restatements in numpy/python back the remaining stage checks.
+"""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+from lidar_camera_calibration_amd import synth
+
+
+def load_fixture(golden_dir, n):
+    path = os.path.join(golden_dir, "pointgrey_lidar_%d.txt" % n)
+    return np.loadtxt(path, dtype=np.float64), open(path).read()
+
+
+# ----------------------------------------------------------------------------- cost functor
+def test_functor_known_answers(ob, golden_dir):
+    kat = json.load(open(os.path.join(golden_dir, "functor_kat.json")))
+    p = ob.default_params()
+    assert (p.board_w, p.board_h) == (kat["board_w"], kat["board_h"])
+    for row in kat["rows"]:
+        r = ob.residual(row["theta_t"], row["y"], row["z"], kat["board_w"], kat["board_h"], kat["grid_length"],
+                        row["topleft_white"], row["laser_white"], row["use_oob"])
+        assert r == pytest.approx(row["r"], abs=1e-12), row
+        c = ob.cost(row["theta_t"], [row["y"]], [row["z"]], [1 if row["laser_white"] else 0], p,
+                    row["topleft_white"], row["use_oob"])
+        # orc_cost takes the plane-frame coordinates as float32 (m_cloud_PCA is a float cloud)
+        assert c == pytest.approx(row["half_rho"], abs=2e-7), row
+
+
+def test_functor_survey_appendix_c_values(ob):
+    # the rows quoted in SURVEY.md Appendix C
+    r = lambda *a: ob.residual(*a)
+    assert r([0, 0, 0], 0.01, 0.02, 6, 8, 0.15, 0, 1, 1) == 0.0
+    assert r([0, 0, 0], 0.01, 0.02, 6, 8, 0.15, 0, 0, 1) == pytest.approx(0.2, abs=1e-12)
+    assert r([0, 0, 0], 0.50, 0.10, 6, 8, 0.15, 0, 1, 1) == pytest.approx(3.0 + 2.0 / 3.0, abs=1e-12)
+    assert r([0, 0, 0], 0.50, 0.10, 6, 8, 0.15, 0, 1, 0) == 0.0
+    assert r([0, 0, 0], 0.50, 0.70, 6, 8, 0.15, 0, 0, 1) == pytest.approx(1.0, abs=1e-12)
+    assert r([0.1, 0.02, -0.03], 0.10, 0.20, 6, 8, 0.15, 0, 1, 1) == pytest.approx(0.529670, abs=1e-6)
+
+
+def test_functor_properties(ob):
+    rng = np.random.default_rng(1)
+    W, H, g = 6, 8, 0.15
+    for _ in range(300):
+        y, z = rng.uniform(-0.4, 0.4), rng.uniform(-0.55, 0.55)
+        th = [rng.uniform(-0.2, 0.2), rng.uniform(-0.1, 0.1), rng.uniform(-0.1, 0.1)]
+        tlw, lw = int(rng.integers(2)), int(rng.integers(2))
+        r0 = ob.residual(th, y, z, W, H, g, tlw, lw, 0)
+        # phase flip: exactly one of the two phases is a mismatch inside the board
+        r1 = ob.residual(th, y, z, W, H, g, 1 - tlw, lw, 0)
+        assert (r0 == 0.0) != (r1 == 0.0) or (r0 == 0.0 and r1 == 0.0)
+        # 180 degree in-plane turn preserves colours for an even x even board
+        r180 = ob.residual([th[0] + math.pi, -th[1], -th[2]], -y, -z, W, H, g, tlw, lw, 0)
+        yy = math.cos(th[0]) * y - math.sin(th[0]) * z + th[1]
+        zz = math.sin(th[0]) * y + math.cos(th[0]) * z + th[2]
+        # rotate the transformed point by pi about the board centre: (yy,zz)->(-yy,-zz)
+        ra = ob.residual([0, 0, 0], yy, zz, W, H, g, tlw, lw, 0)
+        rb = ob.residual([0, 0, 0], -yy, -zz, W, H, g, tlw, lw, 0)
+        assert ra == pytest.approx(rb, abs=1e-9)
+        assert r180 >= 0
+        # period 2g without the out-of-board term (while staying inside the board)
+        if abs(yy) < 0.1 and abs(zz) < 0.25:
+            assert ob.residual([0, 0, 0], yy + 2 * g, zz, W, H, g, tlw, lw, 0) == pytest.approx(ra, abs=1e-9)
+            assert ob.residual([0, 0, 0], yy, zz - 2 * g, W, H, g, tlw, lw, 0) == pytest.approx(ra, abs=1e-9)
+
+
+def test_functor_continuous_across_cell_borders(ob):
+    W, H, g = 6, 8, 0.15
+    eps = 1e-9
+    for k in range(-2, 3):
+        for lw in (0, 1):
+            border = k * g
+            a = ob.residual([0, 0, 0], border - eps, 0.031, W, H, g, 0, lw, 1)
+            b = ob.residual([0, 0, 0], border + eps, 0.031, W, H, g, 0, lw, 1)
+            # a mismatch residual tends to the j-part alone at a border; a match is 0 on one side
+            assert min(a, b) == 0.0 or abs(a - b) < 1e-6
+
+
+def test_functor_jacobian_matches_finite_differences(ob):
+    rng = np.random.default_rng(2)
+    W, H, g = 6, 8, 0.15
+    checked = 0
+    for _ in range(400):
+        y, z = rng.uniform(-0.6, 0.6), rng.uniform(-0.8, 0.8)
+        th = np.array([rng.uniform(-0.2, 0.2), rng.uniform(-0.1, 0.1), rng.uniform(-0.1, 0.1)])
+        tlw, lw = int(rng.integers(2)), int(rng.integers(2))
+        r, jac = ob.residual(th, y, z, W, H, g, tlw, lw, 1, want_jac=True)
+        h = 1e-7
+        ok = True
+        num = np.zeros(3)
+        for c in range(3):
+            tp, tm = th.copy(), th.copy()
+            tp[c] += h
+            tm[c] -= h
+            rp = ob.residual(tp, y, z, W, H, g, tlw, lw, 1)
+            rm = ob.residual(tm, y, z, W, H, g, tlw, lw, 1)
+            num[c] = (rp - rm) / (2 * h)
+            # skip points within h of a kink (cell border / centre line / board edge)
+            if abs((rp - r) - (r - rm)) > 1e-9:
+                ok = False
+        if ok and r > 0:
+            assert np.allclose(jac, num, atol=1e-5), (jac, num)
+            checked += 1
+    assert checked > 100
+
+
+# ----------------------------------------------------------------------------- bundled corner files
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 6])
+def test_fixture_files_are_exact_lattices(golden_dir, n):
+    pts, _ = load_fixture(golden_dir, n)
+    assert pts.shape == (35, 3)
+    grid = pts.reshape(5, 7, 3)                      # 5 outer groups x 7 inner
+    e_in = np.diff(grid, axis=1).reshape(-1, 3)
+    e_out = np.diff(grid, axis=0).reshape(-1, 3)
+    assert np.allclose(np.linalg.norm(e_in, axis=1), 0.15, atol=2e-5)
+    assert np.allclose(np.linalg.norm(e_out, axis=1), 0.15, atol=2e-5)
+    assert abs(float(e_in.mean(0) @ e_out.mean(0))) < 1e-5
+    c, eo, ei = synth.FIXTURE_POSES[n - 1]
+    assert np.allclose(grid[2, 3], c, atol=1e-5)
+    assert np.allclose(e_out.mean(0), eo, atol=2e-5)
+    assert np.allclose(e_in.mean(0), ei, atol=2e-5)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 6])
+def test_oracle_corner_lattice_reproduces_fixture(ob, golden_dir, n):
+    """orc_corners (getPCDcorners) fed with the plane frame of a bundled result must regenerate that
+    file: pins ordering (short axis outer), spacing and the two inverse transforms."""
+    pts, _ = load_fixture(golden_dir, n)
+    grid = pts.reshape(5, 7, 3)
+    centre = pts.mean(0)                               # lattice centre = corner (2,3)
+    e1 = np.diff(grid, axis=0).reshape(-1, 3).mean(0)  # outer = plane-frame y
+    e2 = np.diff(grid, axis=1).reshape(-1, 3).mean(0)  # inner = plane-frame z
+    e1 = e1 / np.linalg.norm(e1)
+    e2 = e2 - e1 * float(e1 @ e2)
+    e2 = e2 / np.linalg.norm(e2)
+    e0 = np.cross(e1, e2)
+    R = np.stack([e0, e1, e2])
+    pca = np.eye(4)
+    pca[:3, :3] = R
+    pca[:3, 3] = -R @ centre
+    p = ob.default_params()
+    out = ob.corners(pca.astype(np.float32), [0.0, 0.0, 0.0], p)
+    assert out.shape == (35, 3)
+    assert np.abs(out - pts).max() < 5e-5      # files carry 6 significant digits
+    # and with a non-trivial (theta, ty, tz) folded into the plane frame instead
+    th, ty, tz = 0.2, 0.03, -0.05
+    T = np.eye(4)
+    T[1:3, 1:3] = [[math.cos(th), -math.sin(th)], [math.sin(th), math.cos(th)]]
+    T[1, 3], T[2, 3] = ty, tz
+    pca2 = np.linalg.inv(T) @ pca
+    out2 = ob.corners(pca2.astype(np.float32), [th, ty, tz], p)
+    assert np.abs(out2 - pts).max() < 1e-4
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 6])
+def test_writer_format_regenerates_fixture_text(ob, golden_dir, n):
+    pts, text = load_fixture(golden_dir, n)
+    lines = []
+    for x, y, z in pts.astype(np.float32):
+        lines.append(" ".join(ob.format_float(float(v)) for v in (x, y, z)))
+    assert "\n".join(lines) + "\n" == text
+
+
+def test_writer_format_kat(ob):
+    assert ob.format_float(np.float32(0.00304251)) == "0.00304251"
+    assert ob.format_float(np.float32(0.000851726)) == "0.000851726"
+    assert ob.format_float(np.float32(8.51726e-05)) == "8.51726e-05"
+    assert ob.format_float(np.float32(2.105)) == "2.105"
+
+
+# ----------------------------------------------------------------------------- stages vs independent restatements
+def test_roi_crop_matches_numpy(ob):
+    rng = np.random.default_rng(3)
+    p = ob.default_params()
+    pts = rng.uniform(-5, 5, (5000, 4)).astype(np.float32)
+    pts[10, 0] = np.nan
+    pts[11, 2] = np.inf
+    click = np.array([0.3, -0.2, 0.1], dtype=np.float32)
+    lo = (click.astype(np.float64) - np.array(p.roi_half[:])).astype(np.float32)
+    hi = (click.astype(np.float64) + np.array(p.roi_half[:])).astype(np.float32)
+    pts[12, 0] = hi[0]                                   # limits are inclusive
+    pts[12, 1:3] = click[1:3]
+    keep = np.isfinite(pts[:, :3]).all(1)
+    for a in range(3):
+        keep &= ~((pts[:, a] < lo[a]) | (pts[:, a] > hi[a]))
+    idx = ob.roi_crop(pts, click, p)
+    assert np.array_equal(idx, np.nonzero(keep)[0])
+    assert 12 in idx and 10 not in idx and 11 not in idx
+    assert len(ob.roi_crop(pts[:0], click, p)) == 0
+
+
+def _components(points, tol2):
+    n = len(points)
+    parent = list(range(n))
+
+    def find(x):
+        while parent[x] != x:
+            parent[x] = parent[parent[x]]
+            x = parent[x]
+        return x
+    p32 = points[:, :3].astype(np.float32)
+    for i in range(n):
+        d = p32 - p32[i]
+        d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+        for j in np.nonzero(d2 < tol2)[0]:
+            a, b = find(i), find(int(j))
+            if a != b:
+                parent[max(a, b)] = min(a, b)
+    return np.array([find(i) for i in range(n)])
+
+
+def test_cluster_matches_bruteforce_components(ob):
+    rng = np.random.default_rng(4)
+    p = ob.default_params()
+    p.cluster_min = 5
+    blobs = [rng.normal(c, 0.05, (n, 3)) for c, n in (((0, 0, 0), 120), ((1, 0, 0), 60), ((0, 1.5, 0), 8),
+                                                        ((3, 3, 3), 3))]
+    pts = np.concatenate(blobs).astype(np.float32)
+    pts = np.concatenate([pts, np.zeros((len(pts), 1), np.float32)], 1)
+    rng.shuffle(pts)
+    tol2 = np.float32(p.cluster_tol * p.cluster_tol)
+    labels = _components(pts, tol2)
+    click = np.array([1.0, 0.02, 0.0], np.float32)
+    idx, lab = ob.cluster(pts, click, p)
+    assert np.array_equal(lab, labels)
+    nn = int(np.argmin(((pts[:, :3] - click) ** 2).sum(1)))
+    assert np.array_equal(idx, np.nonzero(labels == labels[nn])[0])
+    # NN lands in a too-small component -> falls back to the largest valid cluster (index 0)
+    click2 = np.array([3.0, 3.0, 3.0], np.float32)
+    idx2, _ = ob.cluster(pts, click2, p)
+    sizes = np.bincount(labels)
+    assert len(idx2) == sizes.max()
+    # nothing admissible
+    p.cluster_min = 1000
+    idx3, _ = ob.cluster(pts, click, p)
+    assert len(idx3) == 0
+
+
+def test_ransac_plane_recovers_plane_and_refits(ob):
+    rng = np.random.default_rng(5)
+    p = ob.default_params()
+    n = np.array([0.6, -0.5, 0.62])
+    n /= np.linalg.norm(n)
+    basis = np.linalg.svd(n[None])[2][1:]
+    inl = (rng.uniform(-0.6, 0.6, (800, 2)) @ basis) + 2.5 * n + rng.normal(0, 0.008, (800, 1)) * n
+    out = rng.uniform(-1, 1, (60, 3)) + 2.5 * n
+    pts = np.concatenate([inl, out]).astype(np.float32)
+    pts = np.concatenate([pts, np.ones((len(pts), 1), np.float32)], 1)
+    idx, pl = ob.ransac_plane(pts, p)
+    d = np.abs(pts[:, :3].astype(np.float64) @ pl[:3] + pl[3])
+    assert np.array_equal(idx, np.nonzero(d.astype(np.float32) < np.float32(0.03))[0]) or \
+        abs(len(idx) - int((d < 0.03).sum())) <= 2
+    assert abs(abs(float(pl[:3] @ n)) - 1) < 1e-4
+    assert len(idx) >= 800
+    assert len(ob.ransac_plane(pts[:2], p)[0]) == 0
+
+
+def _gray_zone_python(intensity, bins, rate):
+    """calHist/get_gray_zone restated with a python dict standing in for std::map<count, bin>."""
+    d = np.sort(np.asarray(intensity, dtype=np.float64))
+    mn, mx = d[0], d[-1]
+    factor = bins / (mx - mn)
+    hist = [0] * (bins + 1)
+    for v in d:
+        b = int(math.floor((v - mn) * factor + 0.5))        # round half away from zero (v - mn >= 0)
+        hist[b] += 1
+    mean = float(np.add.reduce(d)) if False else sum(d.tolist()) / len(d)
+    width = (mx - mn) / bins
+    m = {}
+    for i in range(bins):
+        m.setdefault(hist[i], i)
+    low = high = None
+    for count in sorted(m, reverse=True):
+        edge = width * m[count] + mn
+        if edge > mean and high is None:
+            high = edge
+        if edge < mean and low is None:
+            low = edge
+        if low is not None and high is not None:
+            break
+    if low is None or high is None:
+        return None
+    return ((rate - 1) * low + high) / rate, (low + (rate - 1) * high) / rate
+
+
+def test_gray_zone_matches_python_restatement(ob):
+    rng = np.random.default_rng(6)
+    p = ob.default_params()
+    for trial in range(20):
+        n = int(rng.integers(900, 3000))
+        inten = np.concatenate([rng.normal(12, 4, n // 2), rng.normal(100, 8, n - n // 2),
+                                rng.uniform(12, 100, n // 10)]).clip(0, 255).astype(np.float32)
+        st, rl, gz = ob.gray_zone(inten, p)
+        ref = _gray_zone_python(inten, p.hist_bins, p.gray_rate)
+        if ref is None:
+            assert st == 4
+        else:
+            assert st == 0
+            assert gz[0] == pytest.approx(ref[0], rel=1e-12) and gz[1] == pytest.approx(ref[1], rel=1e-12)
+            assert gz[0] == pytest.approx(0.6 * rl[0] + 0.4 * rl[1], rel=1e-12)
+    assert ob.gray_zone(np.full(10, 7.0, np.float32), p)[0] == 4        # max == min: reference divides by 0
+
+
+def test_plane_frame_is_rigid_and_ordered(ob):
+    rng = np.random.default_rng(7)
+    p = ob.default_params()
+    pose = synth.pose_from_fixture(3)
+    uv = rng.uniform(-1, 1, (1500, 2)) * [0.45, 0.6]
+    pts = pose.centre + uv[:, :1] * pose.u + uv[:, 1:] * pose.v + rng.normal(0, 0.005, (1500, 1)) * pose.normal
+    cloud = np.concatenate([pts, rng.uniform(0, 100, (1500, 1))], 1).astype(np.float32)
+    st, pca, out = ob.plane_frame(cloud, p)
+    assert st == 0
+    R = pca[:3, :3].astype(np.float64)
+    assert np.allclose(R @ R.T, np.eye(3), atol=1e-6) and np.linalg.det(R) > 0
+    assert np.allclose(out[:, 3], cloud[:, 3])
+    v = out[:, :3].astype(np.float64).var(0)
+    assert v[0] < v[1] < v[2]                               # x normal, y mid, z max variance
+    assert abs(out[:, :3].mean(0)).max() < 1e-5
+    assert float(R[0] @ pose.centre) < 0                    # normal towards the sensor
+    assert abs(abs(R[1] @ pose.u) - 1) < 2e-2 and abs(abs(R[2] @ pose.v) - 1) < 2e-2
+    p.accum_float = 1
+    st2, pca2, out2 = ob.plane_frame(cloud, p)
+    assert np.abs(out2[:, :3] - out[:, :3]).max() < 1e-4    # float vs double accumulation
+
+
+def test_grid_search_selection_rule(ob):
+    p = ob.default_params()
+    p.n_th, p.n_ty, p.n_tz = 5, 6, 6
+    p.th_min, p.th_step = -0.02, 0.01
+    p.ty_min = p.tz_min = -0.03
+    p.ty_step = p.tz_step = 0.01
+    # no points: every candidate costs 0 -> nearest-to-zero candidate, phase 0
+    flat, c, vol = ob.grid_search(np.zeros(0), np.zeros(0), np.zeros(0, np.int8), p, 1, want_volume=True)
+    assert c == 0.0 and np.all(vol == 0.0)
+    assert flat == ((2 * 6 + 3) * 6 + 3) * 2
+    # volume equals orc_cost candidate by candidate
+    rng = np.random.default_rng(8)
+    y, z = rng.uniform(-0.4, 0.4, 50).astype(np.float32), rng.uniform(-0.55, 0.55, 50).astype(np.float32)
+    lab = rng.integers(0, 2, 50).astype(np.int8)
+    flat, c, vol = ob.grid_search(y, z, lab, p, 1, want_volume=True)
+    for k, a, b, ph in ((0, 0, 0, 0), (4, 5, 5, 1), (2, 3, 1, 1)):
+        th = [p.th_min + k * p.th_step, p.ty_min + a * p.ty_step, p.tz_min + b * p.tz_step]
+        assert vol[((k * 6 + a) * 6 + b) * 2 + ph] == pytest.approx(ob.cost(th, y, z, lab, p, ph, 1), abs=1e-12)
+    assert c == vol.min() and vol[flat] == c
+
+
+def test_local_solver_reaches_zero_cost_on_clean_board(ob):
+    """Noise-free checker samples, displaced by a known small motion: pass A+B must return to a
+    zero-cost pose (every labelled point on a square of its own colour)."""
+    p = ob.default_params()
+    g = p.grid_length
+    ys, zs = np.meshgrid(np.arange(-0.42, 0.43, 0.03), np.arange(-0.57, 0.58, 0.03), indexing="ij")
+    y, z = ys.ravel(), zs.ravel()
+    i = np.floor((y + 3 * g) / g).astype(int)
+    j = np.floor((z + 4 * g) / g).astype(int)
+    fi = (y + 3 * g) / g - i
+    fj = (z + 4 * g) / g - j
+    keep = (np.minimum(fi, 1 - fi) > 0.12) & (np.minimum(fj, 1 - fj) > 0.12)   # a gray-zone-like margin
+    white = ((i + j) % 2 == 1)            # topleftWhite = False
+    th0, ty0, tz0 = 0.03, 0.012, -0.02    # true board -> cloud motion
+    yy = math.cos(-th0) * (y - ty0) - math.sin(-th0) * (z - tz0)
+    zz = math.sin(-th0) * (y - ty0) + math.cos(-th0) * (z - tz0)
+    pts = np.stack([np.zeros_like(yy), yy, zz, np.where(white, 100.0, 10.0)], 1)[keep].astype(np.float32)
+    t, cost, it = ob.get_theta_t(pts, [40.0, 60.0], p, 0, 1)
+    t, cost_b, it_b = ob.get_theta_t(pts, [40.0, 60.0], p, 0, 0, t)
+    assert cost < 1e-12 and cost_b < 1e-12
+    # any pose inside the zero-cost plateau (margin 0.12 cell = 18 mm) is a fixed point of the solver
+    assert abs(t[0] - th0) < 0.03 and abs(t[1] - ty0) < 0.018 and abs(t[2] - tz0) < 0.018
+    assert it <= 50
+
+
+# ----------------------------------------------------------------------------- closed loop at the fixture poses
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 6])
+def test_config1_synthetic_frame_at_fixture_pose(ob, golden_dir, n, tmp_path):
+    """BASELINE config 1/3 on the CPU path: synthetic VLP-16 frame with the board where bundled file n
+    has it; reference-faithful trajectory (both phases) -> corners within the method's accuracy on
+    16-ring data (cm-level in the ring-sparse direction; measured 1.9-5.3 mm at these poses)."""
+    pts, _ = load_fixture(golden_dir, n)
+    board = synth.Board()
+    pose = synth.pose_from_fixture(n - 1)
+    cloud = synth.make_frame(synth.vlp16(), board, pose, 0xC0FFEE + n - 1)
+    assert cloud.shape == (28800, 4)
+    click = synth.make_click(pose, 0xC0FFEE + n - 1)
+    p = ob.default_params()
+    p.solver = ob.SOLVER_REFERENCE_LOCAL
+    res = ob.extract(cloud, click, p)
+    assert res.status == 0 and res.n_corners == 35
+    err = synth.corner_error(ob.result_corners(res), pts, board)
+    assert err < 0.010, err
