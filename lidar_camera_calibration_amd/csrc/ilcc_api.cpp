@@ -187,6 +187,7 @@ int32_t run_pipeline(ilcc_handle* h, const float4* d_xyzi, const uint64_t* offse
   hipStream_t s = h->stream;
   HIP_TRY(h, hipMemcpyAsync(h->d_off, offsets, sizeof(uint64_t) * (n_frames + 1), hipMemcpyHostToDevice, s));
   HIP_TRY(h, hipMemsetAsync(h->d_count, 0, sizeof(uint32_t) * offsets[n_frames], s));
+  HIP_TRY(h, hipMemsetAsync(h->d_res, 0, sizeof(ilcc_result) * n_frames, s));   // no stale fields in failed frames
   const Ctx c = make_ctx(h, d_xyzi, d_clicks, n_frames, chunks);
 
   HIP_TRY(h, hipEventRecord(h->ev[0], s));

@@ -168,7 +168,6 @@ class LidarCornersBatch:
                                         int(max_frames) * int(max_points_per_frame))
         if not self._h:
             raise IlccError(N.HIP_ERROR, self._lib.ilcc_last_error(None).decode())
-        self._res = (N.Result * int(max_frames))()
 
     def close(self):
         if self._h:
@@ -199,22 +198,24 @@ class LidarCornersBatch:
             n = clouds.shape[-2]
             offsets = np.arange(f + 1, dtype=np.uint64) * np.uint64(n)
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        res = (N.Result * f)()               # fresh records per call (the caller owns them)
         st = self._lib.ilcc_extract_batch(self._h, N.fptr(clouds), offsets.ctypes.data_as(C.POINTER(C.c_uint64)),
-                                          f, N.fptr(clicks), self._res)
+                                          f, N.fptr(clicks), res)
         if st != N.OK:
             raise IlccError(st, self._err())
-        return self._res
+        return res
 
     def extract_device(self, d_xyzi_ptr: int, n_frames: int, n_points: int, d_clicks_ptr: int):
         """Inputs resident in HBM: raw device pointers (e.g. ``tensor.data_ptr()``), fixed N per frame.
         The producer's stream must be synchronised before the call."""
         offsets = np.arange(n_frames + 1, dtype=np.uint64) * np.uint64(n_points)
+        res = (N.Result * n_frames)()
         st = self._lib.ilcc_extract_batch_device(self._h, C.c_void_p(d_xyzi_ptr),
                                                  offsets.ctypes.data_as(C.POINTER(C.c_uint64)), n_frames,
-                                                 C.c_void_p(d_clicks_ptr), self._res)
+                                                 C.c_void_p(d_clicks_ptr), res)
         if st != N.OK:
             raise IlccError(st, self._err())
-        return self._res
+        return res
 
     def fetch_cloud(self, frame: int, which: int) -> np.ndarray:
         n = self._lib.ilcc_fetch_cloud(self._h, frame, which, None, 0)
