@@ -17,7 +17,10 @@ constexpr int kCropChunk = 4096;       // points per K1 block
 constexpr int kFrameThreads = 1024;    // K2..K5, K7: one workgroup per frame
 constexpr int kGridThreads = 256;      // K6: 4 wavefronts per workgroup
 constexpr int kTileA = 4;              // K6 candidate tile: ty values per wavefront pass
-constexpr int kTileB = 4;              // K6 candidate tile: tz values per wavefront pass
+#ifndef ILCC_TILE_B
+#define ILCC_TILE_B 4
+#endif
+constexpr int kTileB = ILCC_TILE_B;    // K6 candidate tile: tz values per wavefront pass (4 or 8)
 constexpr int kGridLdsPointsMax = 16384;  // K6 LDS staging upper bound (9 B per point -> 144 KiB)
 constexpr int kSolveThreads = 256;     // K7: 4 wavefronts per frame
 constexpr int kClusterLdsParents = 16384;  // K2 union-find parents kept in LDS (64 KiB)

@@ -14,11 +14,16 @@
 
 namespace ilcc {
 
+// find with path halving.  Parents only ever point to smaller indices (the larger root is hooked
+// under the smaller), so replacing parent[x] by its grandparent keeps it an ancestor: safe against
+// concurrent hooks, which only touch roots.
 template <typename P>
 __device__ __forceinline__ uint32_t uf_find(P* parent, uint32_t x) {
   for (;;) {
     const uint32_t p = __hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (p == x) return x;
+    const uint32_t gp = __hip_atomic_load(&parent[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (gp != p) __hip_atomic_store(&parent[x], gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     x = p;
   }
 }
@@ -90,7 +95,12 @@ __device__ void cluster_frame(const Ctx& c, uint32_t f, uint32_t* lds_parent, fl
         float d2 = dx * dx;
         d2 = d2 + dy * dy;
         d2 = d2 + dz * dz;
-        if (jj < lim && d2 < tol2) uf_unite(parent, i, jc + jj);
+        if (jj < lim && d2 < tol2) {
+          // most neighbours already share a parent after the first few hooks: skip the find loops
+          const uint32_t qi = __hip_atomic_load(&parent[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const uint32_t qj = __hip_atomic_load(&parent[jc + jj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (qi != qj) uf_unite(parent, i, jc + jj);
+        }
       }
     }
   }

@@ -7,7 +7,7 @@
 //
 // Mapping (gfx950): workgroup = (frame, theta index), 4 wavefronts.  The frame's labelled
 // points (y, z in the plane frame + black/white label) are staged ONCE into LDS per workgroup.
-// One wavefront owns a tile of kTileA x kTileB (ty, tz) candidates at the workgroup's theta:
+// One wavefront owns a tile of kTileA x kTileB = 4 x 8 (ty, tz) candidates at the workgroup's theta:
 // its 64 lanes stride over the points, each lane keeps 2 x 16 partial sums (both colour phases
 // of the 16 candidates), and the sums are reduced across the wavefront with shuffles once per
 // tile.  Sharing theta inside a tile means the rotation is done once per point, and the
@@ -31,6 +31,22 @@ namespace ilcc {
 typedef unsigned long long lanemask_t;
 __device__ __forceinline__ lanemask_t ballot(bool b) { return __builtin_amdgcn_ballot_w64(b); }
 __device__ __forceinline__ bool unballot(lanemask_t m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
+
+constexpr int kAcc = kTileA * kTileB * 2;   // partial sums per lane
+static_assert(kAcc == ILCC_WAVE || kAcc == ILCC_WAVE / 2, "transposed reduction: 32 or 64 accumulators per lane");
+
+// one halving step of the transposed reduction (compile-time recursion keeps acc[] in registers)
+template <int HALF>
+__device__ __forceinline__ void transposed_reduce(float (&acc)[kAcc], int lane) {
+  const bool up = (lane & HALF) != 0;
+#pragma unroll
+  for (int k = 0; k < HALF; ++k) {
+    const float send = up ? acc[k] : acc[k + HALF];
+    const float keep = up ? acc[k + HALF] : acc[k];
+    acc[k] = keep + __shfl_xor(send, HALF, ILCC_WAVE);
+  }
+  if constexpr (HALF > 1) transposed_reduce<HALF / 2>(acc, lane);
+}
 
 struct Best {
   float cost;
@@ -88,6 +104,11 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
   const uint32_t dk = (uint32_t)((int)k - c.c_th) * (uint32_t)((int)k - c.c_th);
 
   Best best{__builtin_inff(), 0xFFFFFFFFu, 0xFFFFFFFFu};
+  float* vol = VOLUME ? volume + (uint64_t)f * (uint64_t)c.p.n_th * n_ty * n_tz * 2u : nullptr;
+
+  // after the transposed reduction lane l owns accumulator l = (a*kTileB + b)*2 + phase
+  const int my_l = lane & (kAcc - 1);
+  const int my_ph = my_l & 1, my_b = (my_l >> 1) % kTileB, my_a = (my_l >> 1) / kTileB;
 
   for (int t = wid; t < n_tiles; t += kGridThreads / ILCC_WAVE) {
     const int a0 = (t / ntb) * kTileA, b0 = (t % ntb) * kTileB;
@@ -102,11 +123,9 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
 #pragma unroll
     for (int b = 0; b < kTileB; ++b) azh[b] = 0.5f * azv[b];
 
-    float x0[kTileA][kTileB], x1[kTileA][kTileB];
+    float acc[kAcc];
 #pragma unroll
-    for (int a = 0; a < kTileA; ++a)
-#pragma unroll
-      for (int b = 0; b < kTileB; ++b) x0[a][b] = x1[a][b] = 0.f;
+    for (int k = 0; k < kAcc; ++k) acc[k] = 0.f;
 
     for (uint32_t base = 0; base < Mpad; base += ILCC_WAVE) {
       const uint32_t idx = base + lane;
@@ -158,51 +177,57 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
         for (int b = 0; b < kTileB; ++b) {
           const lanemask_t oob = oa[a] | ob[b];
           const lanemask_t mis0 = pa[a] ^ pb[b];   // colour mismatch under phase 0 (topleftWhite=false)
-          const float rin = fabsf(di[a]) + fabsf(dj[b]);
+          float rin = fabsf(di[a]) + fabsf(dj[b]);
           float rr;
-          if (OOB)
-            rr = unballot(oob) ? (fabsf(ui[a]) + fabsf(uj[b])) : rin;
-          else
+          if (OOB) {
+            float rout = fabsf(ui[a]) + fabsf(uj[b]);
+            // keep "select of two sums" (2 full-rate adds + 1 v_cndmask): LLVM would rewrite it into
+            // a sum of two selects, and v_cndmask issues at about half the rate of v_add on gfx950
+            asm volatile("" : "+v"(rin), "+v"(rout));
+            rr = unballot(oob) ? rout : rin;
+          } else {
             rr = unballot(oob) ? 0.f : rin;
+          }
           const float q = fminf(rr, dl);
           const float h = q * fmaf(-0.5f, q, rr);
+          float& x0 = acc[(a * kTileB + b) * 2];
+          float& x1 = acc[(a * kTileB + b) * 2 + 1];
           if (OOB) {
-            x0[a][b] += unballot(oob | mis0) ? h : 0.f;
-            x1[a][b] += unballot(oob | ~mis0) ? h : 0.f;
+            x0 += unballot(oob | mis0) ? h : 0.f;
+            x1 += unballot(oob | ~mis0) ? h : 0.f;
           } else {
-            x0[a][b] += unballot(mis0) ? h : 0.f;
-            x1[a][b] += unballot(mis0) ? 0.f : h;
+            x0 += unballot(mis0) ? h : 0.f;
+            x1 += unballot(mis0) ? 0.f : h;
           }
         }
     }
 
-    // wavefront reduction (butterfly: every lane ends with the total)
+    // transposed wavefront reduction: kAcc accumulators x 64 lanes -> lane l (< kAcc) holds the
+    // total of accumulator l (63 shuffles instead of kAcc x 6); every step halves the values per lane.
+    if (kAcc < ILCC_WAVE) {
 #pragma unroll
-    for (int a = 0; a < kTileA; ++a)
-#pragma unroll
-      for (int b = 0; b < kTileB; ++b) {
-        float v0 = x0[a][b], v1 = x1[a][b];
-#pragma unroll
-        for (int o = ILCC_WAVE / 2; o > 0; o >>= 1) {
-          v0 += __shfl_xor(v0, o, ILCC_WAVE);
-          v1 += __shfl_xor(v1, o, ILCC_WAVE);
-        }
-        const int ia = a0 + a, ib = b0 + b;
-        if (ia < n_ty && ib < n_tz) {
-          const uint32_t cell = ((uint32_t)k * (uint32_t)n_ty + (uint32_t)ia) * (uint32_t)n_tz + (uint32_t)ib;
-          const uint32_t d2 = dk + (uint32_t)((ia - c.c_ty) * (ia - c.c_ty)) +
-                              (uint32_t)((ib - c.c_tz) * (ib - c.c_tz));
-          if (better(v0, d2, 2u * cell, best)) best = Best{v0, d2, 2u * cell};
-          if (better(v1, d2, 2u * cell + 1u, best)) best = Best{v1, d2, 2u * cell + 1u};
-          if (VOLUME && lane == 0) {
-            float* vol = volume + (uint64_t)f * (uint64_t)c.p.n_th * n_ty * n_tz * 2u;
-            vol[2u * cell] = v0;
-            vol[2u * cell + 1u] = v1;
-          }
-        }
-      }
+      for (int k = 0; k < kAcc; ++k) acc[k] += __shfl_xor(acc[k], 32, ILCC_WAVE);
+    }
+    transposed_reduce<kAcc / 2>(acc, lane);
+    const int ia = a0 + my_a, ib = b0 + my_b;
+    if (lane < kAcc && ia < n_ty && ib < n_tz) {
+      const uint32_t cell = ((uint32_t)k * (uint32_t)n_ty + (uint32_t)ia) * (uint32_t)n_tz + (uint32_t)ib;
+      const uint32_t d2 = dk + (uint32_t)((ia - c.c_ty) * (ia - c.c_ty)) + (uint32_t)((ib - c.c_tz) * (ib - c.c_tz));
+      const uint32_t flat = 2u * cell + (uint32_t)my_ph;
+      if (better(acc[0], d2, flat, best)) best = Best{acc[0], d2, flat};
+      if (VOLUME) vol[flat] = acc[0];
+    }
   }
 
+  // lanes hold different candidates: wavefront argmin, then across the 4 wavefronts
+#pragma unroll
+  for (int o = ILCC_WAVE / 2; o > 0; o >>= 1) {
+    Best t;
+    t.cost = __shfl_down(best.cost, o, ILCC_WAVE);
+    t.d2 = __shfl_down(best.d2, o, ILCC_WAVE);
+    t.flat = __shfl_down(best.flat, o, ILCC_WAVE);
+    if (better(t.cost, t.d2, t.flat, best)) best = t;
+  }
   if (lane == 0) s_best[wid] = best;
   __syncthreads();
   if (threadIdx.x == 0) {

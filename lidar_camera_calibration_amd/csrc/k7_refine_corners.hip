@@ -1,6 +1,6 @@
 // K7 refine_and_corners.
 //
-// K7a local_solve: ONE WAVEFRONT per (frame, colour phase).
+// K7a local_solve: one 256-thread workgroup (4 wavefronts) per (frame, colour phase).
 //  (1) picks the start: the argmin of the K6 per-workgroup partials (ILCC_SOLVER_GRID) or
 //      (0,0,0) (ILCC_SOLVER_REFERENCE_LOCAL, the reference's own start);
 //  (2) runs the reference's two local solves, pass A (useOutofBoard = true) then pass B (false)
@@ -8,10 +8,11 @@
 //      each a restatement of what ceres::Solve does for Optimization::get_theta_t
 //      (/root/reference/ilcc2/src/Optimization.cpp:94-160): TRUST_REGION, DOGLEG/SUBSPACE_DOGLEG,
 //      DENSE_NORMAL_CHOLESKY, HuberLoss(0.1) through Ceres' Corrector, Jacobi scaling, Ceres 1.14
-//      default tolerances.  The 64 lanes stride over the points (residual + Jacobian in double),
-//      sums are combined with a shuffle butterfly so every lane holds bitwise-identical totals,
-//      and the 3-parameter trust-region bookkeeping is executed redundantly by all lanes: no
-//      LDS hand-off, no barrier, no divergence.  A solve is a chain of ~100 dependent
+//      default tolerances.  The threads stride over the points (residual + Jacobian in double),
+//      sums are combined with a shuffle butterfly per wavefront and ONE barrier per evaluation
+//      (double-buffered LDS slots, fixed summation order) so every thread holds bitwise-identical
+//      totals, and the 3-parameter trust-region bookkeeping is executed redundantly by all
+//      threads: no thread-0 section, no divergence.  A solve is a chain of ~100 dependent
 //      evaluations, so latency -- not throughput -- is what this layout minimises; frames and
 //      phases run concurrently on different CUs.
 // K7b corners: picks the phase with the lower with-OOB cost, then builds the corner lattice:
@@ -82,12 +83,16 @@ __device__ __forceinline__ void huber(double a, double s, double& rho0, double& 
 }
 
 // ------------------------------------------------------------------ wavefront-wide evaluation
+constexpr int kSolveWaves = kSolveThreads / ILCC_WAVE;
+
 struct Problem {
   const float2* yz;      // LDS or global
   const uint8_t* lab;
   uint32_t n;
   Board bd;
   bool tlw, oob;
+  double* red;           // LDS: 2 x kSolveWaves x 10 doubles (double-buffered partial sums)
+  int* flip;             // per-thread toggle (register copy lives in the caller)
 };
 
 template <typename T>
@@ -106,7 +111,7 @@ __device__ __forceinline__ void evaluate(const Problem& q, const double x[3], do
   double acc[10];
 #pragma unroll
   for (int k = 0; k < 10; ++k) acc[k] = 0.0;
-  for (uint32_t p = lane_id(); p < q.n; p += ILCC_WAVE) {
+  for (uint32_t p = threadIdx.x; p < q.n; p += blockDim.x) {
     const float2 v = q.yz[p];
     double jac[3];
     const double res = residual<JAC>(x, cs, sn, (double)v.x, (double)v.y, q.bd, q.tlw, q.lab[p] != 0,
@@ -131,7 +136,27 @@ __device__ __forceinline__ void evaluate(const Problem& q, const double x[3], do
   }
   constexpr int NV = JAC ? 10 : 1;
 #pragma unroll
-  for (int k = 0; k < NV; ++k) sums[k] = wave_allsum(acc[k]);
+  for (int k = 0; k < NV; ++k) acc[k] = wave_allsum(acc[k]);
+  if (blockDim.x == ILCC_WAVE) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) sums[k] = acc[k];
+    return;
+  }
+  // wavefronts -> LDS -> everyone, fixed order; the slot alternates so one barrier per call is enough
+  *q.flip ^= 1;
+  double* slot = q.red + (*q.flip) * (kSolveWaves * 10);
+  if (lane_id() == 0) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) slot[wave_id() * 10 + k] = acc[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    double t = slot[k];
+#pragma unroll
+    for (int w = 1; w < kSolveWaves; ++w) t += slot[w * 10 + k];
+    sums[k] = t;
+  }
 }
 
 // ------------------------------------------------------------------ dogleg bookkeeping (per lane, uniform)
@@ -466,7 +491,7 @@ __device__ __forceinline__ bool partial_less(const GridPartial& a, const GridPar
 }
 
 template <bool LDS_POINTS>
-__device__ void solve_body(const Ctx& c, SolveRec* rec, float2* s_yz, uint8_t* s_lab) {
+__device__ void solve_body(const Ctx& c, SolveRec* rec, float2* s_yz, uint8_t* s_lab, double* s_red) {
   const uint32_t f = blockIdx.x, slot = blockIdx.y;
   ilcc_result* r = &c.res[f];
   SolveRec* out = &rec[2 * f + slot];
@@ -474,11 +499,14 @@ __device__ void solve_body(const Ctx& c, SolveRec* rec, float2* s_yz, uint8_t* s
   const uint64_t beg = c.off[f];
   const uint32_t n = c.n_lab[f];
 
+  int flip = 0;
   Problem q;
   q.n = n;
   q.bd = Board{(double)c.p.board_w, (double)c.p.board_h, c.p.grid_length, c.p.huber_delta};
+  q.red = s_red;
+  q.flip = &flip;
   if (LDS_POINTS) {
-    for (uint32_t i = lane; i < n; i += ILCC_WAVE) {
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
       s_yz[i] = c.yz[beg + i];
       s_lab[i] = c.lab[beg + i];
     }
@@ -508,12 +536,12 @@ __device__ void solve_body(const Ctx& c, SolveRec* rec, float2* s_yz, uint8_t* s
       t.flat = __shfl_xor(b.flat, o, ILCC_WAVE);
       if (partial_less(t, b)) b = t;
     }
-    if (lane == 0) {
+    if (threadIdx.x == 0) {
       r->grid_index = (int32_t)b.flat;
       r->grid_cost = b.cost;
     }
     if (b.flat == 0xFFFFFFFFu) {
-      if (lane == 0) out->valid = 0;
+      if (threadIdx.x == 0) out->valid = 0;
       return;
     }
     const uint32_t cell = b.flat >> 1;
@@ -536,7 +564,7 @@ __device__ void solve_body(const Ctx& c, SolveRec* rec, float2* s_yz, uint8_t* s
   q.oob = true;
   double cs[10];
   evaluate<false>(q, x, cs);
-  if (lane == 0) {
+  if (threadIdx.x == 0) {
     out->x[0] = x[0];
     out->x[1] = x[1];
     out->x[2] = x[2];
@@ -550,8 +578,9 @@ __device__ void solve_body(const Ctx& c, SolveRec* rec, float2* s_yz, uint8_t* s
   }
 }
 
-__global__ __launch_bounds__(ILCC_WAVE) void k7a_local_solve(Ctx c, SolveRec* rec) {
+__global__ __launch_bounds__(kSolveThreads) void k7a_local_solve(Ctx c, SolveRec* rec) {
   extern __shared__ __align__(16) unsigned char smem[];
+  __shared__ double s_red[2 * kSolveWaves * 10];
   const uint32_t f = blockIdx.x;
   if (c.res[f].status != ILCC_OK) {
     if (threadIdx.x == 0) rec[2 * f + blockIdx.y].valid = 0;
@@ -560,9 +589,9 @@ __global__ __launch_bounds__(ILCC_WAVE) void k7a_local_solve(Ctx c, SolveRec* re
   float2* s_yz = reinterpret_cast<float2*>(smem);
   uint8_t* s_lab = smem + sizeof(float2) * (size_t)c.grid_lds_points;
   if (c.n_lab[f] <= c.grid_lds_points)
-    solve_body<true>(c, rec, s_yz, s_lab);
+    solve_body<true>(c, rec, s_yz, s_lab, s_red);
   else
-    solve_body<false>(c, rec, s_yz, s_lab);
+    solve_body<false>(c, rec, s_yz, s_lab, s_red);
 }
 
 // ------------------------------------------------------------------ K7b corners (getPCDcorners)
@@ -649,7 +678,7 @@ __global__ __launch_bounds__(kSolveThreads) void k7b_corners(Ctx c, const SolveR
 }
 
 // test entry: one solve on frame 0's labelled points (global memory)
-__global__ __launch_bounds__(ILCC_WAVE) void k7_local_solve_test(Ctx c, int tlw, int use_oob, double* theta_t,
+__global__ __launch_bounds__(kSolveThreads) void k7_local_solve_test(Ctx c, int tlw, int use_oob, double* theta_t,
                                                                  double* cost_iters) {
   Problem q;
   q.yz = c.yz;
@@ -658,6 +687,10 @@ __global__ __launch_bounds__(ILCC_WAVE) void k7_local_solve_test(Ctx c, int tlw,
   q.bd = Board{(double)c.p.board_w, (double)c.p.board_h, c.p.grid_length, c.p.huber_delta};
   q.tlw = tlw != 0;
   q.oob = use_oob != 0;
+  __shared__ double s_red[2 * kSolveWaves * 10];
+  int flip = 0;
+  q.red = s_red;
+  q.flip = &flip;
   double x[3] = {theta_t[0], theta_t[1], theta_t[2]};
   double cost = 0;
   const int it = trust_region_minimize(q, x, cost, c.p.max_iterations);
@@ -679,13 +712,13 @@ void launch_refine_corners(const Ctx& c, hipStream_t s) {
                               (int)((sizeof(float2) + 1) * (size_t)kGridLdsPointsMax));
     attr_done = true;
   }
-  hipLaunchKernelGGL(k7a_local_solve, dim3(c.n_frames, n_slots), dim3(ILCC_WAVE), lds, s, c, c.solve_rec);
+  hipLaunchKernelGGL(k7a_local_solve, dim3(c.n_frames, n_slots), dim3(kSolveThreads), lds, s, c, c.solve_rec);
   hipLaunchKernelGGL(k7b_corners, dim3(c.n_frames), dim3(kSolveThreads), 0, s, c, c.solve_rec, n_slots);
 }
 
 void launch_local_solve(const Ctx& c, hipStream_t s, int32_t tlw, int32_t use_oob, double* theta_t,
                         double* cost_iters) {
-  hipLaunchKernelGGL(k7_local_solve_test, dim3(1), dim3(ILCC_WAVE), 0, s, c, tlw, use_oob, theta_t, cost_iters);
+  hipLaunchKernelGGL(k7_local_solve_test, dim3(1), dim3(kSolveThreads), 0, s, c, tlw, use_oob, theta_t, cost_iters);
 }
 
 }  // namespace ilcc
