@@ -35,10 +35,12 @@ sys.path.insert(0, ROOT)
 
 BYTES_PER_FRAME_CFG2 = 16 * 28800 + 12 * 35 + 64   # 461 284 B
 HBM_PEAK_GBPS = 8000.0                              # MI355X_MICROARCH.md: 8 TB/s spec
-VALU_FP32_PEAK_TFLOPS = 157.3                       # MI355X_MICROARCH.md
+# VALU issue peak: 256 CU x 4 SIMD x 32 lanes x 2.4 GHz = 78.6 T lane-instructions/s
+# (= the 157.3 TFLOP/s fp32 vector peak of MI355X_MICROARCH.md when every instruction is an FMA)
+VALU_ISSUE_PEAK_T = 78.6
 # VALU instructions per (point, candidate) evaluation of k6_grid_cost (both phases), counted from
-# the gfx950 ISA of the inner loop (DESIGN.md "K6"); each is one fp32-lane op for the rate below.
-K6_VALU_OPS_PER_EVAL = 14.0
+# the gfx950 ISA of the inner loop: 232 per 64-point x 16-candidate trip (DESIGN.md "K6")
+K6_VALU_OPS_PER_EVAL = 14.5
 
 
 def main():
@@ -118,8 +120,9 @@ def main():
         k6_ms = tm.grid_cost_ms_sum / launches
         k6_bytes = BYTES_PER_FRAME_CFG2 * F
         achieved = k6_bytes / (k6_ms * 1e-3) / 1e9
-        evals_per_launch = tm.grid_cost_evals_sum / launches
-        valu_tflops = evals_per_launch * K6_VALU_OPS_PER_EVAL / (k6_ms * 1e-3) / 1e12
+        evals_per_launch = tm.grid_cost_evals_sum / launches            # executed (after branch-and-bound cuts)
+        evals_nominal = tm.grid_cost_evals_nominal_sum / launches       # what a cut-free exhaustive pass needs
+        valu_rate = evals_per_launch * K6_VALU_OPS_PER_EVAL / (k6_ms * 1e-3) / 1e12
         out = {
             "metric": "chessboard-corner frames/sec + max corner error (mm), VLP-16 cloud",
             "value": fps,
@@ -164,9 +167,13 @@ def main():
                 "note": "kernel is VALU/LDS-bound by construction (points staged once in LDS, ~1e8 "
                         "point-candidate evaluations per frame, no MFMA); HBM fraction reported because "
                         "BASELINE.json asks for it",
-                "valu": {"evals_per_launch": evals_per_launch, "ops_per_eval": K6_VALU_OPS_PER_EVAL,
-                         "achieved_tflops": valu_tflops, "peak_tflops": VALU_FP32_PEAK_TFLOPS,
-                         "frac": valu_tflops / VALU_FP32_PEAK_TFLOPS},
+                "valu": {"evals_executed_per_launch": evals_per_launch,
+                         "evals_nominal_per_launch": evals_nominal,
+                         "executed_fraction": evals_per_launch / evals_nominal if evals_nominal else None,
+                         "valu_instr_per_eval": K6_VALU_OPS_PER_EVAL,
+                         "achieved_T_lane_instr_per_s": valu_rate,
+                         "peak_T_lane_instr_per_s": VALU_ISSUE_PEAK_T,
+                         "frac": valu_rate / VALU_ISSUE_PEAK_T},
             },
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -96,6 +96,9 @@ typedef struct ilcc_params {
   int32_t phase_mode;  /* REFERENCE_LOCAL only: 0 topleftWhite=false (reference's first turn),
                           1 true, 2 both from zero, keep lower with-OOB cost (replaces key 'd') */
   int32_t max_iterations; /* trust-region iterations per pass (Ceres default 50) */
+  int32_t grid_prune;     /* 1 (default): K6 abandons a candidate tile as soon as its partial costs exceed
+                             the best complete cost known for the frame (exact: the argmin cannot
+                             change); 0: every candidate is summed over every point */
   /* exhaustive grid: theta_k = th_min + k th_step (rad), ty_a, tz_b likewise (m) */
   int32_t n_th, n_ty, n_tz;
   double th_min, th_step;
@@ -131,6 +134,7 @@ typedef struct ilcc_timing {
   uint32_t grid_cost_launches;   /* kernel launches accumulated since ilcc_reset_timing */
   double grid_cost_ms_sum;       /* their summed HIP-event duration, ms */
   uint64_t grid_cost_evals_sum;  /* point x candidate evaluations they performed (both phases = 1) */
+  uint64_t grid_cost_evals_nominal_sum; /* evaluations an unpruned exhaustive pass needs */
 } ilcc_timing;
 
 int32_t ilcc_abi_version(void);

@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libilcc_hip.so")
+# ILCC_HIP_LIB selects another build of the same library (kernel A/B experiments); never a fallback
+LIB_PATH = os.environ.get("ILCC_HIP_LIB") or os.path.join(_HERE, "libilcc_hip.so")
 MAX_CORNERS = 256
 
 OK, NO_ROI_POINTS, NO_CLUSTER, NO_PLANE, DEGENERATE_HIST, TOO_FEW_POINTS, BAD_ARGUMENT, CAPACITY, \
@@ -47,6 +48,7 @@ class Params(C.Structure):
         ("solver", C.c_int32),
         ("phase_mode", C.c_int32),
         ("max_iterations", C.c_int32),
+        ("grid_prune", C.c_int32),
         ("n_th", C.c_int32), ("n_ty", C.c_int32), ("n_tz", C.c_int32),
         ("th_min", C.c_double), ("th_step", C.c_double),
         ("ty_min", C.c_double), ("ty_step", C.c_double),
@@ -87,6 +89,7 @@ class Timing(C.Structure):
         ("grid_cost_launches", C.c_uint32),
         ("grid_cost_ms_sum", C.c_double),
         ("grid_cost_evals_sum", C.c_uint64),
+        ("grid_cost_evals_nominal_sum", C.c_uint64),
     ]
 
 

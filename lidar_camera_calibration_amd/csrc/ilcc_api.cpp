@@ -35,6 +35,12 @@ struct ilcc_handle {
   GridPartial* d_partial = nullptr;
   SolveRec* d_solverec = nullptr;
   float *d_cth = nullptr, *d_sth = nullptr, *d_ay = nullptr, *d_az = nullptr;
+  // decimated subset of the same candidate tables: seeding pass of K6's branch and bound
+  float *d_cth2 = nullptr, *d_sth2 = nullptr, *d_ay2 = nullptr, *d_az2 = nullptr;
+  GridPartial* d_partial2 = nullptr;
+  int32_t n_th2 = 0, n_ty2 = 0, n_tz2 = 0, seed_stride_th = 4, seed_stride_t = 2;
+  uint32_t* d_bound = nullptr;
+  unsigned long long* d_iters = nullptr;
   double* d_solve = nullptr;   // 3 theta_t + 2 (cost, iterations) for the test entry
   uint32_t crop_chunks_cap = 0;
   // last batch
@@ -107,6 +113,23 @@ int32_t upload_tables(ilcc_handle* h) {
   HIP_TRY(h, hipMemcpyAsync(h->d_sth, sth.data(), sizeof(float) * p.n_th, hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, hipMemcpyAsync(h->d_ay, ay.data(), sizeof(float) * p.n_ty, hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, hipMemcpyAsync(h->d_az, az.data(), sizeof(float) * p.n_tz, hipMemcpyHostToDevice, h->stream));
+  // seed subset: every 4th theta (centred), every 2nd ty / tz -- same float values as the full tables
+  std::vector<float> cth2, sth2, ay2, az2;
+  for (int k = h->seed_stride_th / 2; k < p.n_th; k += h->seed_stride_th) {
+    cth2.push_back(cth[k]);
+    sth2.push_back(sth[k]);
+  }
+  for (int a = 0; a < p.n_ty; a += h->seed_stride_t) ay2.push_back(ay[a]);
+  for (int b = 0; b < p.n_tz; b += h->seed_stride_t) az2.push_back(az[b]);
+  h->n_th2 = (int32_t)cth2.size();
+  h->n_ty2 = (int32_t)ay2.size();
+  h->n_tz2 = (int32_t)az2.size();
+  if (h->n_th2 > 0) {
+    HIP_TRY(h, hipMemcpyAsync(h->d_cth2, cth2.data(), sizeof(float) * cth2.size(), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_sth2, sth2.data(), sizeof(float) * sth2.size(), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_ay2, ay2.data(), sizeof(float) * ay2.size(), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_az2, az2.data(), sizeof(float) * az2.size(), hipMemcpyHostToDevice, h->stream));
+  }
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   return ILCC_OK;
 }
@@ -135,6 +158,12 @@ Ctx make_ctx(ilcc_handle* h, const float4* d_xyzi, const float* d_clicks, uint32
   c.solve_rec = h->d_solverec;
   c.grid_blocks = (uint32_t)h->p.n_th;
   c.grid_lds_points = h->grid_lds_points;
+  c.grid_bound = h->d_bound;
+  c.grid_iters = h->d_iters;
+  c.seed_partial = nullptr;
+  c.seed_blocks = 0;
+  c.seed_n_ty = c.seed_n_tz = 1;
+  c.seed_stride_t = 1;
   c.cth = h->d_cth;
   c.sth = h->d_sth;
   c.ay = h->d_ay;
@@ -200,7 +229,32 @@ int32_t run_pipeline(ilcc_handle* h, const float4* d_xyzi, const uint64_t* offse
   launch_plane_frame_hist(c, s);
   HIP_TRY(h, hipEventRecord(h->ev[4], s));
   const bool grid = h->p.solver == ILCC_SOLVER_GRID;
-  if (grid) launch_grid_cost(c, s, /*use_oob=*/1, nullptr);
+  if (grid) {
+    HIP_TRY(h, hipMemsetAsync(h->d_iters, 0, sizeof(unsigned long long), s));
+    const bool prune = h->p.grid_prune != 0;
+    Ctx full = c;
+    if (prune && h->n_th2 > 0 && h->p.n_th >= 8 && h->p.n_ty >= 8 && h->p.n_tz >= 8) {
+      // seeding pass: a decimated subset of the SAME candidates, fully evaluated (with pruning
+      // among themselves) -> per-frame bound + where to start the full pass
+      Ctx seed = c;
+      seed.cth = h->d_cth2;
+      seed.sth = h->d_sth2;
+      seed.ay = h->d_ay2;
+      seed.az = h->d_az2;
+      seed.p.n_th = h->n_th2;
+      seed.p.n_ty = h->n_ty2;
+      seed.p.n_tz = h->n_tz2;
+      seed.grid_blocks = (uint32_t)h->n_th2;
+      seed.partial = h->d_partial2;
+      launch_grid_cost(seed, s, /*use_oob=*/1, nullptr, true);
+      full.seed_partial = h->d_partial2;
+      full.seed_blocks = (uint32_t)h->n_th2;
+      full.seed_n_ty = h->n_ty2;
+      full.seed_n_tz = h->n_tz2;
+      full.seed_stride_t = h->seed_stride_t;
+    }
+    launch_grid_cost(full, s, /*use_oob=*/1, nullptr, prune);
+  }
   HIP_TRY(h, hipEventRecord(h->ev[5], s));
   launch_refine_corners(c, s);
   HIP_TRY(h, hipEventRecord(h->ev[6], s));
@@ -220,6 +274,8 @@ int32_t run_pipeline(ilcc_handle* h, const float4* d_xyzi, const uint64_t* offse
   t.grid_cost = ms[4];
   t.refine_corners = ms[5];
   t.total = tot;
+  unsigned long long iters = 0;
+  if (grid) HIP_TRY(h, hipMemcpy(&iters, h->d_iters, sizeof(iters), hipMemcpyDeviceToHost));
   uint32_t max_lab = 0;
   uint64_t evals = 0;
   for (uint32_t f = 0; f < n_frames; ++f) {
@@ -231,7 +287,9 @@ int32_t run_pipeline(ilcc_handle* h, const float4* d_xyzi, const uint64_t* offse
   if (grid) {
     t.grid_cost_launches += 1;
     t.grid_cost_ms_sum += ms[4];
-    t.grid_cost_evals_sum += evals;
+    t.grid_cost_evals_nominal_sum += evals;
+    // one wavefront-iteration = 64 points x (kTileA x kTileB) candidates (both phases = 1 evaluation)
+    t.grid_cost_evals_sum += (uint64_t)iters * ILCC_WAVE * kTileA * kTileB;
   }
   // adapt the K6 LDS staging size to the labelled-point counts actually seen (next call)
   uint32_t want = 1024;
@@ -284,6 +342,7 @@ void ilcc_default_params(ilcc_params* p) {
   p->solver = ILCC_SOLVER_GRID;
   p->phase_mode = 2;
   p->max_iterations = 50;
+  p->grid_prune = 1;
   const double kPi = 3.14159265358979323846;
   p->n_th = 61;
   p->th_step = 0.5 * kPi / 180.0;
@@ -410,6 +469,13 @@ ilcc_handle* ilcc_create(int32_t device, const ilcc_params* p, uint32_t max_fram
   ALLOC(h->d_ay, sizeof(float) * h->max_theta);
   ALLOC(h->d_az, sizeof(float) * h->max_theta);
   ALLOC(h->d_solve, sizeof(double) * 8);
+  ALLOC(h->d_cth2, sizeof(float) * h->max_theta);
+  ALLOC(h->d_sth2, sizeof(float) * h->max_theta);
+  ALLOC(h->d_ay2, sizeof(float) * h->max_theta);
+  ALLOC(h->d_az2, sizeof(float) * h->max_theta);
+  ALLOC(h->d_partial2, sizeof(GridPartial) * (size_t)max_frames * h->max_theta);
+  ALLOC(h->d_bound, sizeof(uint32_t) * max_frames);
+  ALLOC(h->d_iters, sizeof(unsigned long long));
 #undef ALLOC
   if (upload_tables(h) != ILCC_OK) {
     g_err = h->err;
@@ -423,7 +489,7 @@ void ilcc_destroy(ilcc_handle* h) {
   if (!h) return;
   void* bufs[] = {h->d_xyzi, h->d_clicks, h->d_off,    h->d_res,    h->d_roi,   h->d_cluster, h->d_board,
                   h->d_pca,  h->d_optim,  h->d_yz,     h->d_lab,    h->d_nlab,  h->d_counts,  h->d_parent,
-                  h->d_count, h->d_partial, h->d_solverec, h->d_cth,  h->d_sth,    h->d_ay,    h->d_az,      h->d_solve};
+                  h->d_count, h->d_partial, h->d_solverec, h->d_cth,  h->d_sth,    h->d_ay,    h->d_az,      h->d_solve, h->d_cth2, h->d_sth2, h->d_ay2, h->d_az2, h->d_partial2, h->d_bound, h->d_iters};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   for (auto& ev : h->ev)
@@ -546,7 +612,10 @@ int32_t ilcc_grid_cost(ilcc_handle* h, const float* yz, const uint8_t* label, ui
   h->grid_lds_points = std::max(saved, lds);
   const Ctx c = make_ctx(h, nullptr, nullptr, 1, 1);
   h->grid_lds_points = saved;
-  launch_grid_cost(c, s, use_oob, d_vol);
+  const uint32_t inf_bits = 0x7f800000u;
+  HIP_TRY(h, hipMemcpyAsync(h->d_bound, &inf_bits, sizeof(inf_bits), hipMemcpyHostToDevice, s));
+  // full evaluation when the volume is wanted, the pipeline's branch-and-bound variant otherwise
+  launch_grid_cost(c, s, use_oob, d_vol, /*prune=*/d_vol == nullptr && h->p.grid_prune != 0);
   std::vector<GridPartial> part(c.grid_blocks);
   hipError_t e = hipMemcpyAsync(part.data(), h->d_partial, sizeof(GridPartial) * c.grid_blocks, hipMemcpyDeviceToHost, s);
   if (e == hipSuccess && cost_out) e = hipMemcpyAsync(cost_out, d_vol, sizeof(float) * vol, hipMemcpyDeviceToHost, s);

@@ -64,6 +64,12 @@ struct Ctx {
   SolveRec* solve_rec;       // n_frames x 2
   uint32_t grid_blocks;      // K6 workgroups per frame
   uint32_t grid_lds_points;  // K6 points staged in LDS per workgroup (multiple of 64)
+  uint32_t* grid_bound;      // per frame: float bits of the best complete candidate cost so far (K6 pruning)
+  unsigned long long* grid_iters;  // executed K6 wavefront-iterations (64 points x one tile), for the VALU rate
+  // seeding pass of the branch-and-bound (a decimated subset of the same grid, evaluated first)
+  const GridPartial* seed_partial; // n_frames x seed_blocks, nullptr when this launch is the seed pass / unused
+  uint32_t seed_blocks;
+  int32_t seed_n_ty, seed_n_tz, seed_stride_t;   // seed (a2,b2) -> grid (a2*stride, b2*stride)
   // candidate tables (device)
   const float* cth;          // cos(theta_k)/g
   const float* sth;          // sin(theta_k)/g
@@ -128,7 +134,8 @@ void launch_roi_crop(const Ctx& c, hipStream_t s);
 void launch_cluster(const Ctx& c, hipStream_t s);
 void launch_ransac_plane(const Ctx& c, hipStream_t s);
 void launch_plane_frame_hist(const Ctx& c, hipStream_t s);
-void launch_grid_cost(const Ctx& c, hipStream_t s, int32_t use_oob, float* cost_volume /*nullable*/);
+void launch_grid_cost(const Ctx& c, hipStream_t s, int32_t use_oob, float* cost_volume /*nullable*/,
+                      bool prune);
 void launch_refine_corners(const Ctx& c, hipStream_t s);
 // stand-alone local solve on the labelled points of frame 0 (test entry)
 void launch_local_solve(const Ctx& c, hipStream_t s, int32_t tlw, int32_t use_oob, double* theta_t,

@@ -54,6 +54,7 @@ __global__ __launch_bounds__(kCropThreads) void k1_roi_count(Ctx c) {
     r->cost_a = r->cost_b = r->sel_cost = 0.0;
     r->theta_t[0] = r->theta_t[1] = r->theta_t[2] = 0.0;
     c.n_lab[f] = 0;
+    c.grid_bound[f] = 0x7f800000u;   // +inf
   }
   const uint64_t cbeg = (uint64_t)s * kCropChunk;
   uint32_t cnt = 0;

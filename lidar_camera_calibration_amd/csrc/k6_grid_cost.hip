@@ -26,6 +26,10 @@
 // under phase 0 is a match under phase 1: both phases come out of one pass.
 #include "ilcc_internal.h"
 
+#ifndef ILCC_K6_SCHED
+#define ILCC_K6_SCHED 0
+#endif
+
 namespace ilcc {
 
 typedef unsigned long long lanemask_t;
@@ -48,6 +52,16 @@ __device__ __forceinline__ void transposed_reduce(float (&acc)[kAcc], int lane) 
   if constexpr (HALF > 1) transposed_reduce<HALF / 2>(acc, lane);
 }
 
+// kAcc accumulators x 64 lanes -> lane l (< kAcc) holds the total of accumulator l in acc[0]
+// (63 shuffles instead of kAcc x 6): every step halves the values per lane.
+__device__ __forceinline__ void transposed_sum(float (&acc)[kAcc], int lane) {
+  if (kAcc < ILCC_WAVE) {
+#pragma unroll
+    for (int k = 0; k < kAcc; ++k) acc[k] += __shfl_xor(acc[k], 32, ILCC_WAVE);
+  }
+  transposed_reduce<kAcc / 2>(acc, lane);
+}
+
 struct Best {
   float cost;
   uint32_t d2;
@@ -57,7 +71,7 @@ __device__ __forceinline__ bool better(float c, uint32_t d2, uint32_t flat, cons
   return c < b.cost || (c == b.cost && (d2 < b.d2 || (d2 == b.d2 && flat < b.flat)));
 }
 
-template <bool OOB, bool VOLUME, bool LDS_POINTS>
+template <bool OOB, bool VOLUME, bool LDS_POINTS, bool PRUNE>
 __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, float2* s_pts,
                                                uint8_t* s_lab, Best* s_best) {
   const uint32_t f = blockIdx.y;
@@ -104,13 +118,44 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
   const uint32_t dk = (uint32_t)((int)k - c.c_th) * (uint32_t)((int)k - c.c_th);
 
   Best best{__builtin_inff(), 0xFFFFFFFFu, 0xFFFFFFFFu};
+  uint32_t* bound = c.grid_bound + f;
+  float shared_bound = __builtin_inff();   // what this wavefront last published
+  const uint32_t n_iter = Mpad / ILCC_WAVE;
+  uint32_t iters_done = 0;
   float* vol = VOLUME ? volume + (uint64_t)f * (uint64_t)c.p.n_th * n_ty * n_tz * 2u : nullptr;
 
   // after the transposed reduction lane l owns accumulator l = (a*kTileB + b)*2 + phase
   const int my_l = lane & (kAcc - 1);
   const int my_ph = my_l & 1, my_b = (my_l >> 1) % kTileB, my_a = (my_l >> 1) / kTileB;
 
-  for (int t = wid; t < n_tiles; t += kGridThreads / ILCC_WAVE) {
+  // start at the tile that holds the seed pass's best translation so that the shared bound is
+  // tight after the first round of tiles; the order never changes the result
+  int t0 = 0;
+  if (PRUNE && c.seed_partial != nullptr) {
+    const GridPartial* sp = c.seed_partial + (uint64_t)f * c.seed_blocks;
+    Best sb{__builtin_inff(), 0xFFFFFFFFu, 0xFFFFFFFFu};
+    for (uint32_t q = (uint32_t)lane; q < c.seed_blocks; q += ILCC_WAVE) {
+      const GridPartial g = sp[q];
+      if (better(g.cost, g.d2, g.flat, sb)) sb = Best{g.cost, g.d2, g.flat};
+    }
+#pragma unroll
+    for (int o = ILCC_WAVE / 2; o > 0; o >>= 1) {
+      Best tb;
+      tb.cost = __shfl_xor(sb.cost, o, ILCC_WAVE);
+      tb.d2 = __shfl_xor(sb.d2, o, ILCC_WAVE);
+      tb.flat = __shfl_xor(sb.flat, o, ILCC_WAVE);
+      if (better(tb.cost, tb.d2, tb.flat, sb)) sb = tb;
+    }
+    if (sb.flat != 0xFFFFFFFFu) {
+      const uint32_t cell = sb.flat >> 1;
+      const int b2 = (int)(cell % (uint32_t)c.seed_n_tz), a2 = (int)((cell / (uint32_t)c.seed_n_tz) % (uint32_t)c.seed_n_ty);
+      const int sa = min(a2 * c.seed_stride_t, n_ty - 1), sbb = min(b2 * c.seed_stride_t, n_tz - 1);
+      t0 = __builtin_amdgcn_readfirstlane((sa / kTileA) * ntb + (sbb / kTileB));
+    }
+  }
+
+  for (int tt = wid; tt < n_tiles; tt += kGridThreads / ILCC_WAVE) {
+    const int t = (tt + t0) % n_tiles;
     const int a0 = (t / ntb) * kTileA, b0 = (t % ntb) * kTileB;
     float ayv[kTileA], azv[kTileB];
 #pragma unroll
@@ -126,6 +171,17 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
     float acc[kAcc];
 #pragma unroll
     for (int k = 0; k < kAcc; ++k) acc[k] = 0.f;
+
+    // Branch and bound (PRUNE): costs are sums of non-negative terms, so a candidate whose partial
+    // sum already exceeds the best COMPLETE cost known for this frame cannot be the argmin.  After
+    // 1/8, 1/4 and 1/2 of the points the partial sums are reduced; if every candidate of the tile is
+    // beaten the wavefront moves on.  Exact: only provably losing candidates are cut short.
+    float done_part = 0.f;           // this lane's candidate: reduced sum of the finished segments
+    bool pruned = false;
+    const int ia = a0 + my_a, ib = b0 + my_b;
+    const bool owner = lane < kAcc && ia < n_ty && ib < n_tz;
+    uint32_t next_check = PRUNE ? (n_iter >= 8 ? n_iter / 8 : 1) : 0xFFFFFFFFu;
+    uint32_t it_no = 0;
 
     for (uint32_t base = 0; base < Mpad; base += ILCC_WAVE) {
       const uint32_t idx = base + lane;
@@ -199,23 +255,48 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
             x0 += unballot(mis0) ? h : 0.f;
             x1 += unballot(mis0) ? 0.f : h;
           }
+#if ILCC_K6_SCHED == 1
+          __builtin_amdgcn_sched_barrier(0);
+#elif ILCC_K6_SCHED == 2
+          if (b & 1) __builtin_amdgcn_sched_barrier(0);
+#endif
         }
-    }
-
-    // transposed wavefront reduction: kAcc accumulators x 64 lanes -> lane l (< kAcc) holds the
-    // total of accumulator l (63 shuffles instead of kAcc x 6); every step halves the values per lane.
-    if (kAcc < ILCC_WAVE) {
+      ++it_no;
+      if (PRUNE && it_no == next_check && it_no < n_iter) {
+        transposed_sum(acc, lane);
+        done_part += acc[0];
 #pragma unroll
-      for (int k = 0; k < kAcc; ++k) acc[k] += __shfl_xor(acc[k], 32, ILCC_WAVE);
+        for (int k = 0; k < kAcc; ++k) acc[k] = 0.f;
+        const float gb = __uint_as_float(__hip_atomic_load(bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        const float lim = fminf(gb, best.cost);
+        if (!__any(owner && !(done_part > lim))) {
+          pruned = true;
+          break;
+        }
+        next_check *= 2;
+      }
     }
-    transposed_reduce<kAcc / 2>(acc, lane);
-    const int ia = a0 + my_a, ib = b0 + my_b;
-    if (lane < kAcc && ia < n_ty && ib < n_tz) {
+    iters_done += it_no;
+    if (PRUNE && pruned) continue;
+
+    transposed_sum(acc, lane);
+    const float total = done_part + acc[0];
+    if (owner) {
       const uint32_t cell = ((uint32_t)k * (uint32_t)n_ty + (uint32_t)ia) * (uint32_t)n_tz + (uint32_t)ib;
       const uint32_t d2 = dk + (uint32_t)((ia - c.c_ty) * (ia - c.c_ty)) + (uint32_t)((ib - c.c_tz) * (ib - c.c_tz));
       const uint32_t flat = 2u * cell + (uint32_t)my_ph;
-      if (better(acc[0], d2, flat, best)) best = Best{acc[0], d2, flat};
-      if (VOLUME) vol[flat] = acc[0];
+      if (better(total, d2, flat, best)) best = Best{total, d2, flat};
+      if (VOLUME) vol[flat] = total;
+    }
+    if (PRUNE) {
+      // share the wavefront's best complete cost with every workgroup of the frame
+      float wb = best.cost;
+#pragma unroll
+      for (int o = ILCC_WAVE / 2; o > 0; o >>= 1) wb = fminf(wb, __shfl_xor(wb, o, ILCC_WAVE));
+      if (lane == 0 && wb < shared_bound) {
+        shared_bound = wb;
+        atomicMin(bound, __float_as_uint(wb));   // costs are >= 0: uint order == float order
+      }
     }
   }
 
@@ -228,7 +309,10 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
     t.flat = __shfl_down(best.flat, o, ILCC_WAVE);
     if (better(t.cost, t.d2, t.flat, best)) best = t;
   }
-  if (lane == 0) s_best[wid] = best;
+  if (lane == 0) {
+    s_best[wid] = best;
+    atomicAdd(c.grid_iters, (unsigned long long)iters_done);
+  }
   __syncthreads();
   if (threadIdx.x == 0) {
     Best b = s_best[0];
@@ -242,7 +326,7 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
 
 // dynamic LDS: [grid_lds_points float2][grid_lds_points u8]; frames with more labelled points
 // than the staged capacity read them through L1/L2 instead (same code, global pointers).
-template <bool OOB, bool VOLUME>
+template <bool OOB, bool VOLUME, bool PRUNE>
 __global__ __launch_bounds__(kGridThreads) void k6_grid_cost(Ctx c, float* volume) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ Best s_best[kGridThreads / ILCC_WAVE];
@@ -250,33 +334,39 @@ __global__ __launch_bounds__(kGridThreads) void k6_grid_cost(Ctx c, float* volum
   uint8_t* s_lab = smem + sizeof(float2) * (size_t)c.grid_lds_points;
   const uint32_t M = c.n_lab[blockIdx.y];
   if (M <= c.grid_lds_points)
-    grid_cost_body<OOB, VOLUME, true>(c, volume, s_pts, s_lab, s_best);
+    grid_cost_body<OOB, VOLUME, true, PRUNE>(c, volume, s_pts, s_lab, s_best);
   else
-    grid_cost_body<OOB, VOLUME, false>(c, volume, s_pts, s_lab, s_best);
+    grid_cost_body<OOB, VOLUME, false, PRUNE>(c, volume, s_pts, s_lab, s_best);
 }
 
-void launch_grid_cost(const Ctx& c, hipStream_t s, int32_t use_oob, float* cost_volume) {
+void launch_grid_cost(const Ctx& c, hipStream_t s, int32_t use_oob, float* cost_volume, bool prune) {
   const dim3 grid(c.grid_blocks, c.n_frames), block(kGridThreads);
   const size_t lds = (sizeof(float2) + 1) * (size_t)c.grid_lds_points;
   static bool attr_done = false;
+  const void* fns[] = {(const void*)k6_grid_cost<true, true, false>,  (const void*)k6_grid_cost<true, false, false>,
+                       (const void*)k6_grid_cost<false, true, false>, (const void*)k6_grid_cost<false, false, false>,
+                       (const void*)k6_grid_cost<true, false, true>,  (const void*)k6_grid_cost<false, false, true>};
   if (!attr_done) {   // allow > 64 KiB of dynamic LDS (gfx950 has 160 KiB per CU)
     const int cap = (int)((sizeof(float2) + 1) * (size_t)kGridLdsPointsMax);
-    (void)hipFuncSetAttribute((const void*)k6_grid_cost<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-    (void)hipFuncSetAttribute((const void*)k6_grid_cost<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-    (void)hipFuncSetAttribute((const void*)k6_grid_cost<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-    (void)hipFuncSetAttribute((const void*)k6_grid_cost<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    for (const void* fn : fns) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
     attr_done = true;
   }
-  if (use_oob) {
-    if (cost_volume)
-      hipLaunchKernelGGL((k6_grid_cost<true, true>), grid, block, lds, s, c, cost_volume);
+  // the diagnostic volume is always a complete evaluation (no pruning)
+  if (cost_volume) {
+    if (use_oob)
+      hipLaunchKernelGGL((k6_grid_cost<true, true, false>), grid, block, lds, s, c, cost_volume);
     else
-      hipLaunchKernelGGL((k6_grid_cost<true, false>), grid, block, lds, s, c, cost_volume);
+      hipLaunchKernelGGL((k6_grid_cost<false, true, false>), grid, block, lds, s, c, cost_volume);
+  } else if (prune) {
+    if (use_oob)
+      hipLaunchKernelGGL((k6_grid_cost<true, false, true>), grid, block, lds, s, c, cost_volume);
+    else
+      hipLaunchKernelGGL((k6_grid_cost<false, false, true>), grid, block, lds, s, c, cost_volume);
   } else {
-    if (cost_volume)
-      hipLaunchKernelGGL((k6_grid_cost<false, true>), grid, block, lds, s, c, cost_volume);
+    if (use_oob)
+      hipLaunchKernelGGL((k6_grid_cost<true, false, false>), grid, block, lds, s, c, cost_volume);
     else
-      hipLaunchKernelGGL((k6_grid_cost<false, false>), grid, block, lds, s, c, cost_volume);
+      hipLaunchKernelGGL((k6_grid_cost<false, false, false>), grid, block, lds, s, c, cost_volume);
   }
 }
 

@@ -37,7 +37,7 @@ def test_struct_layouts_match_the_library():
     assert (p.cluster_tol, p.cluster_min, p.cluster_max) == (0.12, 100, 25000)
     assert p.ransac_thresh == 0.03 and p.hist_bins == 100 and p.gray_rate == 2.5 and p.huber_delta == 0.1
     assert (p.grid_length, p.board_w, p.board_h) == (0.15, 6, 8)
-    assert p.solver == N.SOLVER_GRID and p.phase_mode == 2 and p.max_iterations == 50
+    assert p.solver == N.SOLVER_GRID and p.phase_mode == 2 and p.max_iterations == 50 and p.grid_prune == 1
     assert (p.n_th, p.n_ty, p.n_tz) == (61, 40, 40)
     assert p.tz_step == pytest.approx(0.0075) and p.tz_min == pytest.approx(-0.15)
     assert C.sizeof(N.Result) == 14 * 4 + 4 + 16 + 64 + 4 + 16 + 24 + 24 + 3 * 4 * 256  # no hidden padding surprises
