@@ -168,7 +168,17 @@ int32_t ilcc_extract_batch(ilcc_handle* h, const float* xyzi, const uint64_t* of
 int32_t ilcc_extract_batch_device(ilcc_handle* h, const float* d_xyzi, const uint64_t* offsets,
                                   uint32_t n_frames, const float* d_clicks, ilcc_result* out);
 
-/* copy one of the last batch's intermediate clouds of a frame (n x 4 float32) to the host.
+/* Asynchronous form of ilcc_extract_batch_device: enqueue the whole path for one batch and return;
+ * up to 3 batches may be in flight per handle (each in its own buffers and stream), so the short
+ * latency-bound stages of one batch overlap with the grid search of another.  *ticket identifies the
+ * batch; ilcc_wait blocks until it is complete and copies its records to out (n_frames entries).
+ * Tickets must be waited for in submission order once all slots are taken (ILCC_CAPACITY otherwise).
+ * The inputs must stay valid and unchanged until the matching ilcc_wait returns. */
+int32_t ilcc_submit_batch_device(ilcc_handle* h, const float* d_xyzi, const uint64_t* offsets,
+                                 uint32_t n_frames, const float* d_clicks, int32_t* ticket);
+int32_t ilcc_wait(ilcc_handle* h, int32_t ticket, ilcc_result* out);
+
+/* copy one of the last completed batch's intermediate clouds of a frame (n x 4 float32) to the host.
  * returns the point count (<= cap_points written), or a negative status. */
 int64_t ilcc_fetch_cloud(ilcc_handle* h, uint32_t frame, int32_t which, float* out_xyzi,
                          uint64_t cap_points);

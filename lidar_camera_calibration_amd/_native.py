@@ -24,7 +24,7 @@ CLOUD_ROI, CLOUD_CLUSTER, CLOUD_CHESSBOARD, CLOUD_PCA, CLOUD_OPTIM = range(5)
 EXPORTS = [
     "ilcc_abi_version", "ilcc_strerror", "ilcc_last_error", "ilcc_default_params",
     "ilcc_set_chessboard_param", "ilcc_create", "ilcc_destroy", "ilcc_set_params", "ilcc_extract",
-    "ilcc_extract_batch", "ilcc_extract_batch_device", "ilcc_fetch_cloud", "ilcc_fetch_labelled",
+    "ilcc_extract_batch", "ilcc_extract_batch_device", "ilcc_submit_batch_device", "ilcc_wait", "ilcc_fetch_cloud", "ilcc_fetch_labelled",
     "ilcc_grid_cost", "ilcc_get_theta_t", "ilcc_get_timing", "ilcc_reset_timing",
     "ilcc_save_corners2txt", "ilcc_read_lidar_corners",
 ]
@@ -125,6 +125,10 @@ def lib():
         L.ilcc_extract_batch.restype = C.c_int32
         L.ilcc_extract_batch_device.argtypes = [vp, vp, C.POINTER(C.c_uint64), C.c_uint32, vp, rp]
         L.ilcc_extract_batch_device.restype = C.c_int32
+        L.ilcc_submit_batch_device.argtypes = [vp, vp, C.POINTER(C.c_uint64), C.c_uint32, vp, C.POINTER(C.c_int32)]
+        L.ilcc_submit_batch_device.restype = C.c_int32
+        L.ilcc_wait.argtypes = [vp, C.c_int32, rp]
+        L.ilcc_wait.restype = C.c_int32
         L.ilcc_fetch_cloud.argtypes = [vp, C.c_uint32, C.c_int32, fp, C.c_uint64]
         L.ilcc_fetch_cloud.restype = C.c_int64
         L.ilcc_fetch_labelled.argtypes = [vp, C.c_uint32, fp, C.POINTER(C.c_uint8), C.c_uint64]

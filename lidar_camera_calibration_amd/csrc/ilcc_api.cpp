@@ -16,13 +16,14 @@
 
 using namespace ilcc;
 
-struct ilcc_handle {
-  int device = 0;
+constexpr int kSlots = 3;   // batches in flight per handle (submit/wait); slot 0 serves the synchronous calls
+
+// One in-flight batch: its own stream, events, stage buffers and pinned result staging.
+struct Slot {
   hipStream_t stream = nullptr;
-  ilcc_params p{};
-  uint32_t max_frames = 0;
-  uint64_t max_points = 0;
-  uint32_t max_theta = 0;
+  hipEvent_t ev[8]{};
+  hipEvent_t k6_done = nullptr;
+  bool allocated = false;
   // device buffers
   float4* d_xyzi = nullptr;   // staging for host-input calls
   float* d_clicks = nullptr;
@@ -32,23 +33,37 @@ struct ilcc_handle {
   float2* d_yz = nullptr;
   uint8_t* d_lab = nullptr;
   uint32_t *d_nlab = nullptr, *d_counts = nullptr, *d_parent = nullptr, *d_count = nullptr;
-  GridPartial* d_partial = nullptr;
+  GridPartial *d_partial = nullptr, *d_partial2 = nullptr;
   SolveRec* d_solverec = nullptr;
-  float *d_cth = nullptr, *d_sth = nullptr, *d_ay = nullptr, *d_az = nullptr;
-  // decimated subset of the same candidate tables: seeding pass of K6's branch and bound
-  float *d_cth2 = nullptr, *d_sth2 = nullptr, *d_ay2 = nullptr, *d_az2 = nullptr;
-  GridPartial* d_partial2 = nullptr;
-  int32_t n_th2 = 0, n_ty2 = 0, n_tz2 = 0, seed_stride_th = 4, seed_stride_t = 2;
   uint32_t* d_bound = nullptr;
   unsigned long long* d_iters = nullptr;
-  double* d_solve = nullptr;   // 3 theta_t + 2 (cost, iterations) for the test entry
-  uint32_t crop_chunks_cap = 0;
-  // last batch
+  // pinned host staging
+  ilcc_result* h_res = nullptr;
+  unsigned long long* h_iters = nullptr;
+  // state of the batch in flight / last completed
   std::vector<uint64_t> off;
   uint32_t n_frames = 0;
+  bool busy = false, grid = false;
+};
+
+struct ilcc_handle {
+  int device = 0;
+  ilcc_params p{};
+  uint32_t max_frames = 0;
+  uint64_t max_points = 0;
+  uint32_t max_theta = 0;
+  uint32_t crop_chunks_cap = 0;
+  Slot slots[kSlots];
+  int next_slot = 0;    // round robin for ilcc_submit_*
+  int last_slot = -1;   // slot whose batch the fetch calls look at
+  int k6_last = -1;     // slot that issued the most recent K6 (K6 launches are chained: clean timing)
+  // candidate tables (shared by all slots, read-only while batches are in flight)
+  float *d_cth = nullptr, *d_sth = nullptr, *d_ay = nullptr, *d_az = nullptr;
+  // decimated subset of the same tables: seeding pass of K6's branch and bound
+  float *d_cth2 = nullptr, *d_sth2 = nullptr, *d_ay2 = nullptr, *d_az2 = nullptr;
+  int32_t n_th2 = 0, n_ty2 = 0, n_tz2 = 0, seed_stride_th = 4, seed_stride_t = 2;
+  double* d_solve = nullptr;   // 3 theta_t + 2 (cost, iterations) for the test entry
   uint32_t grid_lds_points = 2048;
-  // timing
-  hipEvent_t ev[8]{};
   ilcc_timing timing{};
   std::string err;
 };
@@ -94,12 +109,19 @@ bool params_ok(const ilcc_params& p, std::string& why) {
   return true;
 }
 
+int32_t sync_all(ilcc_handle* h) {
+  for (Slot& sl : h->slots)
+    if (sl.allocated) HIP_TRY(h, hipStreamSynchronize(sl.stream));
+  return ILCC_OK;
+}
+
 int32_t upload_tables(ilcc_handle* h) {
   const ilcc_params& p = h->p;
   if ((uint32_t)p.n_th > h->max_theta || (uint32_t)p.n_ty > h->max_theta || (uint32_t)p.n_tz > h->max_theta) {
     h->err = "grid axis longer than the handle's table capacity";
     return ILCC_CAPACITY;
   }
+  hipStream_t st = h->slots[0].stream;
   std::vector<float> cth(p.n_th), sth(p.n_th), ay(p.n_ty), az(p.n_tz);
   const double g = p.grid_length;
   for (int k = 0; k < p.n_th; ++k) {
@@ -109,10 +131,10 @@ int32_t upload_tables(ilcc_handle* h) {
   }
   for (int a = 0; a < p.n_ty; ++a) ay[a] = (float)(((p.ty_min + a * p.ty_step) + p.board_w * g / 2.0) / g);
   for (int b = 0; b < p.n_tz; ++b) az[b] = (float)(((p.tz_min + b * p.tz_step) + p.board_h * g / 2.0) / g);
-  HIP_TRY(h, hipMemcpyAsync(h->d_cth, cth.data(), sizeof(float) * p.n_th, hipMemcpyHostToDevice, h->stream));
-  HIP_TRY(h, hipMemcpyAsync(h->d_sth, sth.data(), sizeof(float) * p.n_th, hipMemcpyHostToDevice, h->stream));
-  HIP_TRY(h, hipMemcpyAsync(h->d_ay, ay.data(), sizeof(float) * p.n_ty, hipMemcpyHostToDevice, h->stream));
-  HIP_TRY(h, hipMemcpyAsync(h->d_az, az.data(), sizeof(float) * p.n_tz, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(h->d_cth, cth.data(), sizeof(float) * p.n_th, hipMemcpyHostToDevice, st));
+  HIP_TRY(h, hipMemcpyAsync(h->d_sth, sth.data(), sizeof(float) * p.n_th, hipMemcpyHostToDevice, st));
+  HIP_TRY(h, hipMemcpyAsync(h->d_ay, ay.data(), sizeof(float) * p.n_ty, hipMemcpyHostToDevice, st));
+  HIP_TRY(h, hipMemcpyAsync(h->d_az, az.data(), sizeof(float) * p.n_tz, hipMemcpyHostToDevice, st));
   // seed subset: every 4th theta (centred), every 2nd ty / tz -- same float values as the full tables
   std::vector<float> cth2, sth2, ay2, az2;
   for (int k = h->seed_stride_th / 2; k < p.n_th; k += h->seed_stride_th) {
@@ -125,41 +147,91 @@ int32_t upload_tables(ilcc_handle* h) {
   h->n_ty2 = (int32_t)ay2.size();
   h->n_tz2 = (int32_t)az2.size();
   if (h->n_th2 > 0) {
-    HIP_TRY(h, hipMemcpyAsync(h->d_cth2, cth2.data(), sizeof(float) * cth2.size(), hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->d_sth2, sth2.data(), sizeof(float) * sth2.size(), hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->d_ay2, ay2.data(), sizeof(float) * ay2.size(), hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->d_az2, az2.data(), sizeof(float) * az2.size(), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_cth2, cth2.data(), sizeof(float) * cth2.size(), hipMemcpyHostToDevice, st));
+    HIP_TRY(h, hipMemcpyAsync(h->d_sth2, sth2.data(), sizeof(float) * sth2.size(), hipMemcpyHostToDevice, st));
+    HIP_TRY(h, hipMemcpyAsync(h->d_ay2, ay2.data(), sizeof(float) * ay2.size(), hipMemcpyHostToDevice, st));
+    HIP_TRY(h, hipMemcpyAsync(h->d_az2, az2.data(), sizeof(float) * az2.size(), hipMemcpyHostToDevice, st));
   }
-  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  HIP_TRY(h, hipStreamSynchronize(st));
   return ILCC_OK;
 }
 
-Ctx make_ctx(ilcc_handle* h, const float4* d_xyzi, const float* d_clicks, uint32_t n_frames,
+void free_slot(Slot& sl) {
+  void* bufs[] = {sl.d_xyzi, sl.d_clicks, sl.d_off, sl.d_res, sl.d_roi, sl.d_cluster, sl.d_board, sl.d_pca, sl.d_optim,
+                  sl.d_yz, sl.d_lab, sl.d_nlab, sl.d_counts, sl.d_parent, sl.d_count, sl.d_partial, sl.d_partial2,
+                  sl.d_solverec, sl.d_bound, sl.d_iters};
+  for (void* b : bufs)
+    if (b) (void)hipFree(b);
+  if (sl.h_res) (void)hipHostFree(sl.h_res);
+  if (sl.h_iters) (void)hipHostFree(sl.h_iters);
+  for (auto& ev : sl.ev)
+    if (ev) (void)hipEventDestroy(ev);
+  if (sl.k6_done) (void)hipEventDestroy(sl.k6_done);
+  if (sl.stream) (void)hipStreamDestroy(sl.stream);
+  sl = Slot{};
+}
+
+int32_t alloc_slot(ilcc_handle* h, Slot& sl) {
+  if (sl.allocated) return ILCC_OK;
+  const uint64_t np = h->max_points;
+  const uint32_t mf = h->max_frames;
+  HIP_TRY(h, hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
+  for (auto& ev : sl.ev) HIP_TRY(h, hipEventCreate(&ev));
+  HIP_TRY(h, hipEventCreateWithFlags(&sl.k6_done, hipEventDisableTiming));
+#define ALLOC(ptr, bytes) HIP_TRY(h, hipMalloc((void**)&(ptr), (size_t)(bytes)))
+  ALLOC(sl.d_xyzi, sizeof(float4) * np);
+  ALLOC(sl.d_clicks, sizeof(float) * 3 * mf);
+  ALLOC(sl.d_off, sizeof(uint64_t) * (mf + 1));
+  ALLOC(sl.d_res, sizeof(ilcc_result) * mf);
+  ALLOC(sl.d_roi, sizeof(float4) * np);
+  ALLOC(sl.d_cluster, sizeof(float4) * np);
+  ALLOC(sl.d_board, sizeof(float4) * np);
+  ALLOC(sl.d_pca, sizeof(float4) * np);
+  ALLOC(sl.d_optim, sizeof(float4) * np);
+  ALLOC(sl.d_yz, sizeof(float2) * np);
+  ALLOC(sl.d_lab, np);
+  ALLOC(sl.d_nlab, sizeof(uint32_t) * mf);
+  ALLOC(sl.d_counts, sizeof(uint32_t) * h->crop_chunks_cap);
+  ALLOC(sl.d_parent, sizeof(uint32_t) * np);
+  ALLOC(sl.d_count, sizeof(uint32_t) * np);
+  ALLOC(sl.d_partial, sizeof(GridPartial) * (size_t)mf * h->max_theta);
+  ALLOC(sl.d_partial2, sizeof(GridPartial) * (size_t)mf * h->max_theta);
+  ALLOC(sl.d_solverec, sizeof(SolveRec) * 2 * (size_t)mf);
+  ALLOC(sl.d_bound, sizeof(uint32_t) * mf);
+  ALLOC(sl.d_iters, sizeof(unsigned long long));
+#undef ALLOC
+  HIP_TRY(h, hipHostMalloc((void**)&sl.h_res, sizeof(ilcc_result) * mf, hipHostMallocDefault));
+  HIP_TRY(h, hipHostMalloc((void**)&sl.h_iters, sizeof(unsigned long long), hipHostMallocDefault));
+  sl.allocated = true;
+  return ILCC_OK;
+}
+
+Ctx make_ctx(ilcc_handle* h, Slot& sl, const float4* d_xyzi, const float* d_clicks, uint32_t n_frames,
              uint32_t crop_chunks) {
   Ctx c{};
   c.xyzi = d_xyzi;
-  c.off = h->d_off;
+  c.off = sl.d_off;
   c.clicks = d_clicks;
   c.n_frames = n_frames;
   c.crop_chunks = crop_chunks;
-  c.res = h->d_res;
-  c.roi = h->d_roi;
-  c.cluster = h->d_cluster;
-  c.board = h->d_board;
-  c.pca = h->d_pca;
-  c.optim = h->d_optim;
-  c.yz = h->d_yz;
-  c.lab = h->d_lab;
-  c.n_lab = h->d_nlab;
-  c.crop_counts = h->d_counts;
-  c.uf_parent = h->d_parent;
-  c.uf_count = h->d_count;
-  c.partial = h->d_partial;
-  c.solve_rec = h->d_solverec;
+  c.res = sl.d_res;
+  c.roi = sl.d_roi;
+  c.cluster = sl.d_cluster;
+  c.board = sl.d_board;
+  c.pca = sl.d_pca;
+  c.optim = sl.d_optim;
+  c.yz = sl.d_yz;
+  c.lab = sl.d_lab;
+  c.n_lab = sl.d_nlab;
+  c.crop_counts = sl.d_counts;
+  c.uf_parent = sl.d_parent;
+  c.uf_count = sl.d_count;
+  c.partial = sl.d_partial;
+  c.solve_rec = sl.d_solverec;
   c.grid_blocks = (uint32_t)h->p.n_th;
   c.grid_lds_points = h->grid_lds_points;
-  c.grid_bound = h->d_bound;
-  c.grid_iters = h->d_iters;
+  c.grid_bound = sl.d_bound;
+  c.grid_iters = sl.d_iters;
   c.seed_partial = nullptr;
   c.seed_blocks = 0;
   c.seed_n_ty = c.seed_n_tz = 1;
@@ -200,37 +272,44 @@ int32_t check_offsets(ilcc_handle* h, const uint64_t* offsets, uint32_t n_frames
   return ILCC_OK;
 }
 
-// the pipeline proper: everything on h->stream, inputs already in HBM
-int32_t run_pipeline(ilcc_handle* h, const float4* d_xyzi, const uint64_t* offsets, uint32_t n_frames,
-                     const float* d_clicks, ilcc_result* out) {
+// enqueue the whole path for one batch on the slot's stream (no host synchronisation)
+int32_t enqueue(ilcc_handle* h, int si, const float4* d_xyzi, const uint64_t* offsets, uint32_t n_frames,
+                const float* d_clicks) {
+  Slot& sl = h->slots[si];
   uint64_t max_n = 0;
   for (uint32_t f = 0; f < n_frames; ++f) max_n = std::max<uint64_t>(max_n, offsets[f + 1] - offsets[f]);
   uint32_t chunks = (uint32_t)((max_n + kCropChunk - 1) / kCropChunk);
   if (chunks == 0) chunks = 1;
   if ((uint64_t)chunks * n_frames > (uint64_t)h->crop_chunks_cap) {
-    h->err = "crop chunk table too small for this batch";
+    h->err = "crop chunk table too small for this (very ragged) batch";
     return ILCC_CAPACITY;
   }
-  h->off.assign(offsets, offsets + n_frames + 1);
-  h->n_frames = n_frames;
-  hipStream_t s = h->stream;
-  HIP_TRY(h, hipMemcpyAsync(h->d_off, offsets, sizeof(uint64_t) * (n_frames + 1), hipMemcpyHostToDevice, s));
-  HIP_TRY(h, hipMemsetAsync(h->d_count, 0, sizeof(uint32_t) * offsets[n_frames], s));
-  HIP_TRY(h, hipMemsetAsync(h->d_res, 0, sizeof(ilcc_result) * n_frames, s));   // no stale fields in failed frames
-  const Ctx c = make_ctx(h, d_xyzi, d_clicks, n_frames, chunks);
+  sl.off.assign(offsets, offsets + n_frames + 1);
+  sl.n_frames = n_frames;
+  hipStream_t s = sl.stream;
+  HIP_TRY(h, hipMemcpyAsync(sl.d_off, sl.off.data(), sizeof(uint64_t) * (n_frames + 1), hipMemcpyHostToDevice, s));
+  HIP_TRY(h, hipMemsetAsync(sl.d_count, 0, sizeof(uint32_t) * offsets[n_frames], s));
+  HIP_TRY(h, hipMemsetAsync(sl.d_res, 0, sizeof(ilcc_result) * n_frames, s));   // no stale fields in failed frames
+  const Ctx c = make_ctx(h, sl, d_xyzi, d_clicks, n_frames, chunks);
 
-  HIP_TRY(h, hipEventRecord(h->ev[0], s));
+  HIP_TRY(h, hipEventRecord(sl.ev[0], s));
   launch_roi_crop(c, s);
-  HIP_TRY(h, hipEventRecord(h->ev[1], s));
+  HIP_TRY(h, hipEventRecord(sl.ev[1], s));
   launch_cluster(c, s);
-  HIP_TRY(h, hipEventRecord(h->ev[2], s));
+  HIP_TRY(h, hipEventRecord(sl.ev[2], s));
   launch_ransac_plane(c, s);
-  HIP_TRY(h, hipEventRecord(h->ev[3], s));
+  HIP_TRY(h, hipEventRecord(sl.ev[3], s));
   launch_plane_frame_hist(c, s);
-  HIP_TRY(h, hipEventRecord(h->ev[4], s));
-  const bool grid = h->p.solver == ILCC_SOLVER_GRID;
-  if (grid) {
-    HIP_TRY(h, hipMemsetAsync(h->d_iters, 0, sizeof(unsigned long long), s));
+  sl.grid = h->p.solver == ILCC_SOLVER_GRID;
+  if (sl.grid) {
+    HIP_TRY(h, hipMemsetAsync(sl.d_iters, 0, sizeof(unsigned long long), s));
+    // K6 launches of different slots are chained so that they never share the chip: the small
+    // latency-bound stages of the other batches are what overlaps with a K6, not another K6
+    if (h->k6_last >= 0 && h->k6_last != si && h->slots[h->k6_last].busy)
+      HIP_TRY(h, hipStreamWaitEvent(s, h->slots[h->k6_last].k6_done, 0));
+  }
+  HIP_TRY(h, hipEventRecord(sl.ev[4], s));
+  if (sl.grid) {
     const bool prune = h->p.grid_prune != 0;
     Ctx full = c;
     if (prune && h->n_th2 > 0 && h->p.n_th >= 8 && h->p.n_ty >= 8 && h->p.n_tz >= 8) {
@@ -245,27 +324,40 @@ int32_t run_pipeline(ilcc_handle* h, const float4* d_xyzi, const uint64_t* offse
       seed.p.n_ty = h->n_ty2;
       seed.p.n_tz = h->n_tz2;
       seed.grid_blocks = (uint32_t)h->n_th2;
-      seed.partial = h->d_partial2;
+      seed.partial = sl.d_partial2;
       launch_grid_cost(seed, s, /*use_oob=*/1, nullptr, true);
-      full.seed_partial = h->d_partial2;
+      full.seed_partial = sl.d_partial2;
       full.seed_blocks = (uint32_t)h->n_th2;
       full.seed_n_ty = h->n_ty2;
       full.seed_n_tz = h->n_tz2;
       full.seed_stride_t = h->seed_stride_t;
     }
     launch_grid_cost(full, s, /*use_oob=*/1, nullptr, prune);
+    HIP_TRY(h, hipEventRecord(sl.k6_done, s));
+    h->k6_last = si;
   }
-  HIP_TRY(h, hipEventRecord(h->ev[5], s));
+  HIP_TRY(h, hipEventRecord(sl.ev[5], s));
   launch_refine_corners(c, s);
-  HIP_TRY(h, hipEventRecord(h->ev[6], s));
+  HIP_TRY(h, hipEventRecord(sl.ev[6], s));
   HIP_TRY(h, hipGetLastError());
-  HIP_TRY(h, hipMemcpyAsync(out, h->d_res, sizeof(ilcc_result) * n_frames, hipMemcpyDeviceToHost, s));
-  HIP_TRY(h, hipStreamSynchronize(s));
+  HIP_TRY(h, hipMemcpyAsync(sl.h_res, sl.d_res, sizeof(ilcc_result) * n_frames, hipMemcpyDeviceToHost, s));
+  HIP_TRY(h, hipMemcpyAsync(sl.h_iters, sl.d_iters, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+  sl.busy = true;
+  return ILCC_OK;
+}
 
+// wait for the slot's batch, hand the records over, account the timing
+int32_t finish(ilcc_handle* h, int si, ilcc_result* out) {
+  Slot& sl = h->slots[si];
+  HIP_TRY(h, hipStreamSynchronize(sl.stream));
+  sl.busy = false;
+  h->last_slot = si;
+  const uint32_t n_frames = sl.n_frames;
+  std::memcpy(out, sl.h_res, sizeof(ilcc_result) * n_frames);
   float ms[6];
-  for (int k = 0; k < 6; ++k) HIP_TRY(h, hipEventElapsedTime(&ms[k], h->ev[k], h->ev[k + 1]));
+  for (int k = 0; k < 6; ++k) HIP_TRY(h, hipEventElapsedTime(&ms[k], sl.ev[k], sl.ev[k + 1]));
   float tot = 0;
-  HIP_TRY(h, hipEventElapsedTime(&tot, h->ev[0], h->ev[6]));
+  HIP_TRY(h, hipEventElapsedTime(&tot, sl.ev[0], sl.ev[6]));
   ilcc_timing& t = h->timing;
   t.roi_crop = ms[0];
   t.cluster = ms[1];
@@ -274,8 +366,6 @@ int32_t run_pipeline(ilcc_handle* h, const float4* d_xyzi, const uint64_t* offse
   t.grid_cost = ms[4];
   t.refine_corners = ms[5];
   t.total = tot;
-  unsigned long long iters = 0;
-  if (grid) HIP_TRY(h, hipMemcpy(&iters, h->d_iters, sizeof(iters), hipMemcpyDeviceToHost));
   uint32_t max_lab = 0;
   uint64_t evals = 0;
   for (uint32_t f = 0; f < n_frames; ++f) {
@@ -284,14 +374,14 @@ int32_t run_pipeline(ilcc_handle* h, const float4* d_xyzi, const uint64_t* offse
     max_lab = std::max(max_lab, m);
     evals += (uint64_t)m * (uint64_t)h->p.n_th * h->p.n_ty * h->p.n_tz;
   }
-  if (grid) {
+  if (sl.grid) {
     t.grid_cost_launches += 1;
     t.grid_cost_ms_sum += ms[4];
     t.grid_cost_evals_nominal_sum += evals;
     // one wavefront-iteration = 64 points x (kTileA x kTileB) candidates (both phases = 1 evaluation)
-    t.grid_cost_evals_sum += (uint64_t)iters * ILCC_WAVE * kTileA * kTileB;
+    t.grid_cost_evals_sum += (uint64_t)(*sl.h_iters) * ILCC_WAVE * kTileA * kTileB;
   }
-  // adapt the K6 LDS staging size to the labelled-point counts actually seen (next call)
+  // adapt the K6 LDS staging size to the labelled-point counts actually seen (later calls)
   uint32_t want = 1024;
   while (want < max_lab && want < (uint32_t)kGridLdsPointsMax) want <<= 1;
   if (want > h->grid_lds_points) h->grid_lds_points = want;
@@ -428,73 +518,40 @@ ilcc_handle* ilcc_create(int32_t device, const ilcc_params* p, uint32_t max_fram
   h->max_frames = max_frames;
   h->max_points = max_total_points;
   h->max_theta = 4096;
-  auto fail = [&](const char* what, hipError_t e) {
-    g_err = std::string(what) + ": " + hipGetErrorString(e);
+  h->crop_chunks_cap =
+      (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, max_total_points / kCropChunk + (uint64_t)max_frames + 1);
+  auto fail = [&](const std::string& what) {
+    g_err = what;
     ilcc_destroy(h);
     return (ilcc_handle*)nullptr;
   };
   hipError_t e;
   if (device >= 0) {
-    if ((e = hipSetDevice(device)) != hipSuccess) return fail("hipSetDevice", e);
+    if ((e = hipSetDevice(device)) != hipSuccess) return fail(std::string("hipSetDevice: ") + hipGetErrorString(e));
     h->device = device;
   } else {
     (void)hipGetDevice(&h->device);
   }
-  if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
-  for (auto& ev : h->ev)
-    if ((e = hipEventCreate(&ev)) != hipSuccess) return fail("hipEventCreate", e);
-  const uint64_t np = max_total_points;
-  h->crop_chunks_cap = (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, np / kCropChunk + (uint64_t)max_frames + 1);
-#define ALLOC(ptr, bytes)                                                     \
-  if ((e = hipMalloc((void**)&(ptr), (size_t)(bytes))) != hipSuccess) return fail("hipMalloc " #ptr, e)
-  ALLOC(h->d_xyzi, sizeof(float4) * np);
-  ALLOC(h->d_clicks, sizeof(float) * 3 * max_frames);
-  ALLOC(h->d_off, sizeof(uint64_t) * (max_frames + 1));
-  ALLOC(h->d_res, sizeof(ilcc_result) * max_frames);
-  ALLOC(h->d_roi, sizeof(float4) * np);
-  ALLOC(h->d_cluster, sizeof(float4) * np);
-  ALLOC(h->d_board, sizeof(float4) * np);
-  ALLOC(h->d_pca, sizeof(float4) * np);
-  ALLOC(h->d_optim, sizeof(float4) * np);
-  ALLOC(h->d_yz, sizeof(float2) * np);
-  ALLOC(h->d_lab, np);
-  ALLOC(h->d_nlab, sizeof(uint32_t) * max_frames);
-  ALLOC(h->d_counts, sizeof(uint32_t) * h->crop_chunks_cap);
-  ALLOC(h->d_parent, sizeof(uint32_t) * np);
-  ALLOC(h->d_count, sizeof(uint32_t) * np);
-  ALLOC(h->d_partial, sizeof(GridPartial) * (size_t)max_frames * h->max_theta);
-  ALLOC(h->d_solverec, sizeof(SolveRec) * 2 * (size_t)max_frames);
-  ALLOC(h->d_cth, sizeof(float) * h->max_theta);
-  ALLOC(h->d_sth, sizeof(float) * h->max_theta);
-  ALLOC(h->d_ay, sizeof(float) * h->max_theta);
-  ALLOC(h->d_az, sizeof(float) * h->max_theta);
-  ALLOC(h->d_solve, sizeof(double) * 8);
-  ALLOC(h->d_cth2, sizeof(float) * h->max_theta);
-  ALLOC(h->d_sth2, sizeof(float) * h->max_theta);
-  ALLOC(h->d_ay2, sizeof(float) * h->max_theta);
-  ALLOC(h->d_az2, sizeof(float) * h->max_theta);
-  ALLOC(h->d_partial2, sizeof(GridPartial) * (size_t)max_frames * h->max_theta);
-  ALLOC(h->d_bound, sizeof(uint32_t) * max_frames);
-  ALLOC(h->d_iters, sizeof(unsigned long long));
-#undef ALLOC
-  if (upload_tables(h) != ILCC_OK) {
-    g_err = h->err;
-    ilcc_destroy(h);
-    return nullptr;
-  }
+  float** tabs[] = {&h->d_cth, &h->d_sth, &h->d_ay, &h->d_az, &h->d_cth2, &h->d_sth2, &h->d_ay2, &h->d_az2};
+  for (float** t : tabs)
+    if ((e = hipMalloc((void**)t, sizeof(float) * h->max_theta)) != hipSuccess)
+      return fail(std::string("hipMalloc tables: ") + hipGetErrorString(e));
+  if ((e = hipMalloc((void**)&h->d_solve, sizeof(double) * 8)) != hipSuccess)
+    return fail(std::string("hipMalloc: ") + hipGetErrorString(e));
+  if (alloc_slot(h, h->slots[0]) != ILCC_OK) return fail(h->err);   // further slots on first asynchronous use
+  if (upload_tables(h) != ILCC_OK) return fail(h->err);
   return h;
 }
 
 void ilcc_destroy(ilcc_handle* h) {
   if (!h) return;
-  void* bufs[] = {h->d_xyzi, h->d_clicks, h->d_off,    h->d_res,    h->d_roi,   h->d_cluster, h->d_board,
-                  h->d_pca,  h->d_optim,  h->d_yz,     h->d_lab,    h->d_nlab,  h->d_counts,  h->d_parent,
-                  h->d_count, h->d_partial, h->d_solverec, h->d_cth,  h->d_sth,    h->d_ay,    h->d_az,      h->d_solve, h->d_cth2, h->d_sth2, h->d_ay2, h->d_az2, h->d_partial2, h->d_bound, h->d_iters};
+  for (Slot& sl : h->slots) {
+    if (sl.stream) (void)hipStreamSynchronize(sl.stream);
+    free_slot(sl);
+  }
+  void* bufs[] = {h->d_cth, h->d_sth, h->d_ay, h->d_az, h->d_cth2, h->d_sth2, h->d_ay2, h->d_az2, h->d_solve};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
-  for (auto& ev : h->ev)
-    if (ev) (void)hipEventDestroy(ev);
-  if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
 
@@ -505,32 +562,82 @@ int32_t ilcc_set_params(ilcc_handle* h, const ilcc_params* p) {
     h->err = why;
     return ILCC_BAD_ARGUMENT;
   }
+  for (const Slot& sl : h->slots)
+    if (sl.busy) {
+      h->err = "ilcc_set_params with a batch in flight: ilcc_wait first";
+      return ILCC_BAD_ARGUMENT;
+    }
+  int32_t st = sync_all(h);
+  if (st != ILCC_OK) return st;
   const ilcc_params old = h->p;
   h->p = *p;
-  const int32_t st = upload_tables(h);
+  st = upload_tables(h);
   if (st != ILCC_OK) h->p = old;
   return st;
+}
+
+int32_t ilcc_submit_batch_device(ilcc_handle* h, const float* d_xyzi, const uint64_t* offsets, uint32_t n_frames,
+                                 const float* d_clicks, int32_t* ticket) {
+  if (!h || !d_xyzi || !d_clicks || !ticket) return ILCC_BAD_ARGUMENT;
+  HIP_TRY(h, hipSetDevice(h->device));
+  int32_t st = check_offsets(h, offsets, n_frames);
+  if (st != ILCC_OK) return st;
+  const int si = h->next_slot;
+  Slot& sl = h->slots[si];
+  if (sl.busy) {
+    h->err = "every pipeline slot holds a batch: ilcc_wait for the oldest ticket first";
+    return ILCC_CAPACITY;
+  }
+  st = alloc_slot(h, sl);
+  if (st != ILCC_OK) return st;
+  st = enqueue(h, si, reinterpret_cast<const float4*>(d_xyzi), offsets, n_frames, d_clicks);
+  if (st != ILCC_OK) return st;
+  *ticket = si;
+  h->next_slot = (si + 1) % kSlots;
+  return ILCC_OK;
+}
+
+int32_t ilcc_wait(ilcc_handle* h, int32_t ticket, ilcc_result* out) {
+  if (!h || !out || ticket < 0 || ticket >= kSlots || !h->slots[ticket].busy) {
+    if (h) h->err = "ilcc_wait: no batch in flight under this ticket";
+    return ILCC_BAD_ARGUMENT;
+  }
+  HIP_TRY(h, hipSetDevice(h->device));
+  return finish(h, ticket, out);
 }
 
 int32_t ilcc_extract_batch_device(ilcc_handle* h, const float* d_xyzi, const uint64_t* offsets,
                                   uint32_t n_frames, const float* d_clicks, ilcc_result* out) {
   if (!h || !d_xyzi || !d_clicks || !out) return ILCC_BAD_ARGUMENT;
   HIP_TRY(h, hipSetDevice(h->device));
-  const int32_t st = check_offsets(h, offsets, n_frames);
+  int32_t st = check_offsets(h, offsets, n_frames);
   if (st != ILCC_OK) return st;
-  return run_pipeline(h, reinterpret_cast<const float4*>(d_xyzi), offsets, n_frames, d_clicks, out);
+  if (h->slots[0].busy) {
+    h->err = "synchronous call while ticket 0 is in flight";
+    return ILCC_BAD_ARGUMENT;
+  }
+  st = enqueue(h, 0, reinterpret_cast<const float4*>(d_xyzi), offsets, n_frames, d_clicks);
+  if (st != ILCC_OK) return st;
+  return finish(h, 0, out);
 }
 
 int32_t ilcc_extract_batch(ilcc_handle* h, const float* xyzi, const uint64_t* offsets, uint32_t n_frames,
                            const float* clicks, ilcc_result* out) {
   if (!h || !xyzi || !clicks || !out) return ILCC_BAD_ARGUMENT;
   HIP_TRY(h, hipSetDevice(h->device));
-  const int32_t st = check_offsets(h, offsets, n_frames);
+  int32_t st = check_offsets(h, offsets, n_frames);
   if (st != ILCC_OK) return st;
+  Slot& sl = h->slots[0];
+  if (sl.busy) {
+    h->err = "synchronous call while ticket 0 is in flight";
+    return ILCC_BAD_ARGUMENT;
+  }
   if (offsets[n_frames] > 0)
-    HIP_TRY(h, hipMemcpyAsync(h->d_xyzi, xyzi, sizeof(float4) * offsets[n_frames], hipMemcpyHostToDevice, h->stream));
-  HIP_TRY(h, hipMemcpyAsync(h->d_clicks, clicks, sizeof(float) * 3 * n_frames, hipMemcpyHostToDevice, h->stream));
-  return run_pipeline(h, h->d_xyzi, offsets, n_frames, h->d_clicks, out);
+    HIP_TRY(h, hipMemcpyAsync(sl.d_xyzi, xyzi, sizeof(float4) * offsets[n_frames], hipMemcpyHostToDevice, sl.stream));
+  HIP_TRY(h, hipMemcpyAsync(sl.d_clicks, clicks, sizeof(float) * 3 * n_frames, hipMemcpyHostToDevice, sl.stream));
+  st = enqueue(h, 0, sl.d_xyzi, offsets, n_frames, sl.d_clicks);
+  if (st != ILCC_OK) return st;
+  return finish(h, 0, out);
 }
 
 int32_t ilcc_extract(ilcc_handle* h, const float* xyzi, uint32_t n, const float click[3], ilcc_result* out) {
@@ -539,62 +646,70 @@ int32_t ilcc_extract(ilcc_handle* h, const float* xyzi, uint32_t n, const float 
 }
 
 int64_t ilcc_fetch_cloud(ilcc_handle* h, uint32_t frame, int32_t which, float* out_xyzi, uint64_t cap_points) {
-  if (!h || frame >= h->n_frames) return -(int64_t)ILCC_BAD_ARGUMENT;
-  ilcc_result r;
-  if (hipMemcpy(&r, h->d_res + frame, sizeof(r), hipMemcpyDeviceToHost) != hipSuccess) return -(int64_t)ILCC_HIP_ERROR;
+  if (!h || h->last_slot < 0) return -(int64_t)ILCC_BAD_ARGUMENT;
+  Slot& sl = h->slots[h->last_slot];
+  if (sl.busy || frame >= sl.n_frames) return -(int64_t)ILCC_BAD_ARGUMENT;
+  const ilcc_result& r = sl.h_res[frame];
   const float4* src = nullptr;
   int64_t n = 0;
   switch (which) {
-    case ILCC_CLOUD_ROI: src = h->d_roi; n = r.n_roi; break;
-    case ILCC_CLOUD_CLUSTER: src = h->d_cluster; n = r.n_cluster; break;
-    case ILCC_CLOUD_CHESSBOARD: src = h->d_board; n = r.n_plane; break;
-    case ILCC_CLOUD_PCA: src = h->d_pca; n = (r.status == ILCC_OK || r.status == ILCC_DEGENERATE_HIST) ? r.n_plane : 0; break;
-    case ILCC_CLOUD_OPTIM: src = h->d_optim; n = (r.status == ILCC_OK) ? r.n_plane : 0; break;
+    case ILCC_CLOUD_ROI: src = sl.d_roi; n = r.n_roi; break;
+    case ILCC_CLOUD_CLUSTER: src = sl.d_cluster; n = r.n_cluster; break;
+    case ILCC_CLOUD_CHESSBOARD: src = sl.d_board; n = r.n_plane; break;
+    case ILCC_CLOUD_PCA: src = sl.d_pca; n = (r.status == ILCC_OK || r.status == ILCC_DEGENERATE_HIST) ? r.n_plane : 0; break;
+    case ILCC_CLOUD_OPTIM: src = sl.d_optim; n = (r.status == ILCC_OK) ? r.n_plane : 0; break;
     default: return -(int64_t)ILCC_BAD_ARGUMENT;
   }
   const int64_t m = std::min<int64_t>(n, (int64_t)cap_points);
   if (m > 0 && out_xyzi &&
-      hipMemcpy(out_xyzi, src + h->off[frame], sizeof(float4) * (size_t)m, hipMemcpyDeviceToHost) != hipSuccess)
+      hipMemcpy(out_xyzi, src + sl.off[frame], sizeof(float4) * (size_t)m, hipMemcpyDeviceToHost) != hipSuccess)
     return -(int64_t)ILCC_HIP_ERROR;
   return n;
 }
 
 int64_t ilcc_fetch_labelled(ilcc_handle* h, uint32_t frame, float* out_yz, uint8_t* out_label, uint64_t cap_points) {
-  if (!h || frame >= h->n_frames) return -(int64_t)ILCC_BAD_ARGUMENT;
+  if (!h || h->last_slot < 0) return -(int64_t)ILCC_BAD_ARGUMENT;
+  Slot& sl = h->slots[h->last_slot];
+  if (sl.busy || frame >= sl.n_frames) return -(int64_t)ILCC_BAD_ARGUMENT;
   uint32_t n = 0;
-  if (hipMemcpy(&n, h->d_nlab + frame, sizeof(n), hipMemcpyDeviceToHost) != hipSuccess) return -(int64_t)ILCC_HIP_ERROR;
+  if (hipMemcpy(&n, sl.d_nlab + frame, sizeof(n), hipMemcpyDeviceToHost) != hipSuccess) return -(int64_t)ILCC_HIP_ERROR;
   const uint64_t m = std::min<uint64_t>(n, cap_points);
   if (m > 0) {
-    if (out_yz && hipMemcpy(out_yz, h->d_yz + h->off[frame], sizeof(float2) * m, hipMemcpyDeviceToHost) != hipSuccess)
+    if (out_yz && hipMemcpy(out_yz, sl.d_yz + sl.off[frame], sizeof(float2) * m, hipMemcpyDeviceToHost) != hipSuccess)
       return -(int64_t)ILCC_HIP_ERROR;
-    if (out_label && hipMemcpy(out_label, h->d_lab + h->off[frame], m, hipMemcpyDeviceToHost) != hipSuccess)
+    if (out_label && hipMemcpy(out_label, sl.d_lab + sl.off[frame], m, hipMemcpyDeviceToHost) != hipSuccess)
       return -(int64_t)ILCC_HIP_ERROR;
   }
   return (int64_t)n;
 }
 
-// shared setup for the two single-kernel test entries: frame 0 = caller's labelled points
+// shared setup for the two single-kernel test entries: frame 0 of slot 0 = caller's labelled points
 static int32_t stage_labelled(ilcc_handle* h, const float* yz, const uint8_t* label, uint32_t m) {
   if (!h || (m > 0 && (!yz || !label))) return ILCC_BAD_ARGUMENT;
   if (m > h->max_points) {
     h->err = "more points than the handle holds";
     return ILCC_CAPACITY;
   }
+  Slot& sl = h->slots[0];
+  if (sl.busy) {
+    h->err = "diagnostic entry while ticket 0 is in flight";
+    return ILCC_BAD_ARGUMENT;
+  }
   HIP_TRY(h, hipSetDevice(h->device));
-  hipStream_t s = h->stream;
+  hipStream_t s = sl.stream;
   const uint64_t off[2] = {0, m};
   ilcc_result r;
   std::memset(&r, 0, sizeof(r));
   r.status = ILCC_OK;
-  HIP_TRY(h, hipMemcpyAsync(h->d_off, off, sizeof(off), hipMemcpyHostToDevice, s));
-  HIP_TRY(h, hipMemcpyAsync(h->d_res, &r, sizeof(r), hipMemcpyHostToDevice, s));
-  HIP_TRY(h, hipMemcpyAsync(h->d_nlab, &m, sizeof(m), hipMemcpyHostToDevice, s));
+  HIP_TRY(h, hipMemcpyAsync(sl.d_off, off, sizeof(off), hipMemcpyHostToDevice, s));
+  HIP_TRY(h, hipMemcpyAsync(sl.d_res, &r, sizeof(r), hipMemcpyHostToDevice, s));
+  HIP_TRY(h, hipMemcpyAsync(sl.d_nlab, &m, sizeof(m), hipMemcpyHostToDevice, s));
   if (m > 0) {
-    HIP_TRY(h, hipMemcpyAsync(h->d_yz, yz, sizeof(float2) * m, hipMemcpyHostToDevice, s));
-    HIP_TRY(h, hipMemcpyAsync(h->d_lab, label, m, hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(sl.d_yz, yz, sizeof(float2) * m, hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(sl.d_lab, label, m, hipMemcpyHostToDevice, s));
   }
   HIP_TRY(h, hipStreamSynchronize(s));
-  h->n_frames = 0;
+  sl.n_frames = 0;   // the stage buffers no longer describe a batch
   return ILCC_OK;
 }
 
@@ -602,7 +717,8 @@ int32_t ilcc_grid_cost(ilcc_handle* h, const float* yz, const uint8_t* label, ui
                        float* cost_out, int32_t* best_index, float* best_cost) {
   int32_t st = stage_labelled(h, yz, label, m);
   if (st != ILCC_OK) return st;
-  hipStream_t s = h->stream;
+  Slot& sl = h->slots[0];
+  hipStream_t s = sl.stream;
   const size_t vol = (size_t)h->p.n_th * h->p.n_ty * h->p.n_tz * 2;
   float* d_vol = nullptr;
   if (cost_out) HIP_TRY(h, hipMalloc((void**)&d_vol, sizeof(float) * vol));
@@ -610,14 +726,14 @@ int32_t ilcc_grid_cost(ilcc_handle* h, const float* yz, const uint8_t* label, ui
   while (lds < m && lds < (uint32_t)kGridLdsPointsMax) lds <<= 1;
   const uint32_t saved = h->grid_lds_points;
   h->grid_lds_points = std::max(saved, lds);
-  const Ctx c = make_ctx(h, nullptr, nullptr, 1, 1);
+  const Ctx c = make_ctx(h, sl, nullptr, nullptr, 1, 1);
   h->grid_lds_points = saved;
   const uint32_t inf_bits = 0x7f800000u;
-  HIP_TRY(h, hipMemcpyAsync(h->d_bound, &inf_bits, sizeof(inf_bits), hipMemcpyHostToDevice, s));
+  HIP_TRY(h, hipMemcpyAsync(sl.d_bound, &inf_bits, sizeof(inf_bits), hipMemcpyHostToDevice, s));
   // full evaluation when the volume is wanted, the pipeline's branch-and-bound variant otherwise
   launch_grid_cost(c, s, use_oob, d_vol, /*prune=*/d_vol == nullptr && h->p.grid_prune != 0);
   std::vector<GridPartial> part(c.grid_blocks);
-  hipError_t e = hipMemcpyAsync(part.data(), h->d_partial, sizeof(GridPartial) * c.grid_blocks, hipMemcpyDeviceToHost, s);
+  hipError_t e = hipMemcpyAsync(part.data(), sl.d_partial, sizeof(GridPartial) * c.grid_blocks, hipMemcpyDeviceToHost, s);
   if (e == hipSuccess && cost_out) e = hipMemcpyAsync(cost_out, d_vol, sizeof(float) * vol, hipMemcpyDeviceToHost, s);
   if (e == hipSuccess) e = hipStreamSynchronize(s);
   if (d_vol) (void)hipFree(d_vol);
@@ -640,9 +756,10 @@ int32_t ilcc_get_theta_t(ilcc_handle* h, const float* yz, const uint8_t* label, 
   if (!theta_t) return ILCC_BAD_ARGUMENT;
   int32_t st = stage_labelled(h, yz, label, m);
   if (st != ILCC_OK) return st;
-  hipStream_t s = h->stream;
+  Slot& sl = h->slots[0];
+  hipStream_t s = sl.stream;
   HIP_TRY(h, hipMemcpyAsync(h->d_solve, theta_t, sizeof(double) * 3, hipMemcpyHostToDevice, s));
-  const Ctx c = make_ctx(h, nullptr, nullptr, 1, 1);
+  const Ctx c = make_ctx(h, sl, nullptr, nullptr, 1, 1);
   launch_local_solve(c, s, topleft_white, use_oob, h->d_solve, h->d_solve + 3);
   double back[5];
   HIP_TRY(h, hipMemcpyAsync(back, h->d_solve, sizeof(back), hipMemcpyDeviceToHost, s));

@@ -217,6 +217,25 @@ class LidarCornersBatch:
             raise IlccError(st, self._err())
         return res
 
+    def submit_device(self, d_xyzi_ptr: int, n_frames: int, n_points: int, d_clicks_ptr: int):
+        """Asynchronous ``extract_device``: returns a ticket; up to 3 batches in flight per handle."""
+        offsets = np.arange(n_frames + 1, dtype=np.uint64) * np.uint64(n_points)
+        ticket = C.c_int32(-1)
+        st = self._lib.ilcc_submit_batch_device(self._h, C.c_void_p(d_xyzi_ptr),
+                                                offsets.ctypes.data_as(C.POINTER(C.c_uint64)), n_frames,
+                                                C.c_void_p(d_clicks_ptr), C.byref(ticket))
+        if st != N.OK:
+            raise IlccError(st, self._err())
+        return ticket.value, n_frames
+
+    def wait(self, ticket):
+        t, n_frames = ticket
+        res = (N.Result * n_frames)()
+        st = self._lib.ilcc_wait(self._h, t, res)
+        if st != N.OK:
+            raise IlccError(st, self._err())
+        return res
+
     def fetch_cloud(self, frame: int, which: int) -> np.ndarray:
         n = self._lib.ilcc_fetch_cloud(self._h, frame, which, None, 0)
         if n < 0:

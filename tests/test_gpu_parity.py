@@ -234,6 +234,26 @@ def test_ragged_batch_and_single_frame_entry(ob, frames):
     m.close()
 
 
+def test_async_submit_wait_matches_synchronous_calls(frames):
+    """Three batches in flight (submit/wait) return exactly what three synchronous calls return."""
+    import torch
+    clouds, clicks, _ = frames
+    dev = torch.device("cuda", 0)
+    e = LidarCornersBatch(8, 28800, N.default_params())
+    sets = [(0, 6), (6, 11), (11, 16)]
+    sync = [[r.corners_array() for r in e.extract(clouds[a:b], clicks[a:b])] for a, b in sets]
+    d = [(torch.from_numpy(clouds[a:b].copy()).to(dev), torch.from_numpy(clicks[a:b].copy()).to(dev)) for a, b in sets]
+    torch.cuda.synchronize()
+    tickets = [e.submit_device(dc.data_ptr(), len(dk), 28800, dk.data_ptr()) for dc, dk in d]
+    with pytest.raises(Exception):
+        e.submit_device(d[0][0].data_ptr(), len(d[0][1]), 28800, d[0][1].data_ptr())   # all slots taken
+    for (a, b), t, want in zip(sets, tickets, sync):
+        got = [r.corners_array() for r in e.wait(t)]
+        assert all(np.array_equal(g, w) for g, w in zip(got, want))
+    assert len(e.fetch_cloud(0, N.CLOUD_CHESSBOARD)) > 100          # last completed batch is inspectable
+    e.close()
+
+
 def test_full_size_batch_properties():
     """BASELINE config 4's per-GPU shard (128 x 28 800 points): determinism, batch-composition
     independence and permutation equivariance -- size-independent properties, no oracle needed."""
