@@ -198,10 +198,10 @@ int32_t alloc_slot(ilcc_handle* h, Slot& sl) {
   ALLOC(sl.d_partial2, sizeof(GridPartial) * (size_t)mf * h->max_theta);
   ALLOC(sl.d_solverec, sizeof(SolveRec) * 2 * (size_t)mf);
   ALLOC(sl.d_bound, sizeof(uint32_t) * mf);
-  ALLOC(sl.d_iters, sizeof(unsigned long long));
+  ALLOC(sl.d_iters, sizeof(unsigned long long) * kIterSlots);
 #undef ALLOC
   HIP_TRY(h, hipHostMalloc((void**)&sl.h_res, sizeof(ilcc_result) * mf, hipHostMallocDefault));
-  HIP_TRY(h, hipHostMalloc((void**)&sl.h_iters, sizeof(unsigned long long), hipHostMallocDefault));
+  HIP_TRY(h, hipHostMalloc((void**)&sl.h_iters, sizeof(unsigned long long) * kIterSlots, hipHostMallocDefault));
   sl.allocated = true;
   return ILCC_OK;
 }
@@ -302,7 +302,7 @@ int32_t enqueue(ilcc_handle* h, int si, const float4* d_xyzi, const uint64_t* of
   launch_plane_frame_hist(c, s);
   sl.grid = h->p.solver == ILCC_SOLVER_GRID;
   if (sl.grid) {
-    HIP_TRY(h, hipMemsetAsync(sl.d_iters, 0, sizeof(unsigned long long), s));
+    HIP_TRY(h, hipMemsetAsync(sl.d_iters, 0, sizeof(unsigned long long) * kIterSlots, s));
     // K6 launches of different slots are chained so that they never share the chip: the small
     // latency-bound stages of the other batches are what overlaps with a K6, not another K6
     if (h->k6_last >= 0 && h->k6_last != si && h->slots[h->k6_last].busy)
@@ -312,7 +312,8 @@ int32_t enqueue(ilcc_handle* h, int si, const float4* d_xyzi, const uint64_t* of
   if (sl.grid) {
     const bool prune = h->p.grid_prune != 0;
     Ctx full = c;
-    if (prune && h->n_th2 > 0 && h->p.n_th >= 8 && h->p.n_ty >= 8 && h->p.n_tz >= 8) {
+    static const bool no_seed = std::getenv("ILCC_K6_NOSEED") != nullptr;   // experiment switch
+    if (prune && !no_seed && h->n_th2 > 0 && h->p.n_th >= 8 && h->p.n_ty >= 8 && h->p.n_tz >= 8) {
       // seeding pass: a decimated subset of the SAME candidates, fully evaluated (with pruning
       // among themselves) -> per-frame bound + where to start the full pass
       Ctx seed = c;
@@ -341,7 +342,7 @@ int32_t enqueue(ilcc_handle* h, int si, const float4* d_xyzi, const uint64_t* of
   HIP_TRY(h, hipEventRecord(sl.ev[6], s));
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipMemcpyAsync(sl.h_res, sl.d_res, sizeof(ilcc_result) * n_frames, hipMemcpyDeviceToHost, s));
-  HIP_TRY(h, hipMemcpyAsync(sl.h_iters, sl.d_iters, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+  HIP_TRY(h, hipMemcpyAsync(sl.h_iters, sl.d_iters, sizeof(unsigned long long) * kIterSlots, hipMemcpyDeviceToHost, s));
   sl.busy = true;
   return ILCC_OK;
 }
@@ -379,7 +380,9 @@ int32_t finish(ilcc_handle* h, int si, ilcc_result* out) {
     t.grid_cost_ms_sum += ms[4];
     t.grid_cost_evals_nominal_sum += evals;
     // one wavefront-iteration = 64 points x (kTileA x kTileB) candidates (both phases = 1 evaluation)
-    t.grid_cost_evals_sum += (uint64_t)(*sl.h_iters) * ILCC_WAVE * kTileA * kTileB;
+    unsigned long long iters = 0;
+    for (int k = 0; k < kIterSlots; ++k) iters += sl.h_iters[k];
+    t.grid_cost_evals_sum += (uint64_t)iters * ILCC_WAVE * kTileA * kTileB;
   }
   // adapt the K6 LDS staging size to the labelled-point counts actually seen (later calls)
   uint32_t want = 1024;

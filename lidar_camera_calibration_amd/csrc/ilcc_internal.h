@@ -23,6 +23,7 @@ constexpr int kTileA = 4;              // K6 candidate tile: ty values per wavef
 constexpr int kTileB = ILCC_TILE_B;    // K6 candidate tile: tz values per wavefront pass (4 or 8)
 constexpr int kGridLdsPointsMax = 16384;  // K6 LDS staging upper bound (9 B per point -> 144 KiB)
 constexpr int kSolveThreads = 256;     // K7: 4 wavefronts per frame
+constexpr int kIterSlots = 64;         // K6 executed-iteration counters (spread to avoid one hot atomic)
 constexpr int kClusterLdsParents = 16384;  // K2 union-find parents kept in LDS (64 KiB)
 
 struct GridPartial {   // per K6 workgroup best candidate

@@ -36,30 +36,77 @@ typedef unsigned long long lanemask_t;
 __device__ __forceinline__ lanemask_t ballot(bool b) { return __builtin_amdgcn_ballot_w64(b); }
 __device__ __forceinline__ bool unballot(lanemask_t m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
 
+#ifndef ILCC_K6_FIRST_CHECK_DIV
+#define ILCC_K6_FIRST_CHECK_DIV 16
+#endif
+constexpr int kFirstCheckDiv = ILCC_K6_FIRST_CHECK_DIV;   // first bound check after n_iter / this many iterations
+constexpr int kTabLds = 256;   // (ty, tz) table entries kept in LDS
 constexpr int kAcc = kTileA * kTileB * 2;   // partial sums per lane
-static_assert(kAcc == ILCC_WAVE || kAcc == ILCC_WAVE / 2, "transposed reduction: 32 or 64 accumulators per lane");
 
-// one halving step of the transposed reduction (compile-time recursion keeps acc[] in registers)
-template <int HALF>
-__device__ __forceinline__ void transposed_reduce(float (&acc)[kAcc], int lane) {
-  const bool up = (lane & HALF) != 0;
-#pragma unroll
-  for (int k = 0; k < HALF; ++k) {
-    const float send = up ? acc[k] : acc[k + HALF];
-    const float keep = up ? acc[k + HALF] : acc[k];
-    acc[k] = keep + __shfl_xor(send, HALF, ILCC_WAVE);
-  }
-  if constexpr (HALF > 1) transposed_reduce<HALF / 2>(acc, lane);
+// ---- transposed wavefront reduction of the 32 partial sums, in registers only ----------------
+// 32 accumulators x 64 lanes -> lane l holds the total of accumulator (l >> 1) in acc[0].
+// Every step halves the values per lane and doubles the lanes summed; partners are reached with
+// v_permlane32_swap / v_permlane16_swap (gfx950) and DPP row rotations / quad permutes -- plain
+// VALU instructions, no LDS round trips (a ds_bpermute chain costs several point-iterations of
+// latency, which matters because the branch-and-bound checks reduce after every few iterations).
+static_assert(kAcc == 32, "the register reduction below is written for a 4 x 4 x 2 tile");
+
+// [aL+aH | bL+bH] over the two 32-lane halves
+__device__ __forceinline__ float swap32_add(float a, float b) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// per 32-lane half: [a.row0+a.row1 | b.row0+b.row1] over its two 16-lane rows
+__device__ __forceinline__ float swap16_add(float a, float b) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp(float v) {
+  return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float dpp_xor4(float v) {   // lane i <- lane i^4 inside each 16-lane row
+  // row_ror:n hands lane i the value of lane (i - n) mod 16: banks 1,3 take i-4, banks 0,2 take i+4
+  const unsigned lo = __builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x124 /*row_ror:4*/, 0xf, 0xa, false);
+  return __uint_as_float(__builtin_amdgcn_update_dpp(lo, __float_as_uint(v), 0x12C /*row_ror:12*/, 0xf, 0x5, false));
 }
 
-// kAcc accumulators x 64 lanes -> lane l (< kAcc) holds the total of accumulator l in acc[0]
-// (63 shuffles instead of kAcc x 6): every step halves the values per lane.
 __device__ __forceinline__ void transposed_sum(float (&acc)[kAcc], int lane) {
-  if (kAcc < ILCC_WAVE) {
+  // lane bit 5: 32 -> 16 values
 #pragma unroll
-    for (int k = 0; k < kAcc; ++k) acc[k] += __shfl_xor(acc[k], 32, ILCC_WAVE);
+  for (int k = 0; k < 16; ++k) acc[k] = swap32_add(acc[k], acc[k + 16]);
+  // lane bit 4: 16 -> 8
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = swap16_add(acc[k], acc[k + 8]);
+  // lane bit 3: 8 -> 4   (partner = lane ^ 8 = row_ror:8)
+  {
+    const bool up = (lane & 8) != 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float s0 = acc[k] + dpp<0x128>(acc[k]);
+      const float s1 = acc[k + 4] + dpp<0x128>(acc[k + 4]);
+      acc[k] = up ? s1 : s0;
+    }
   }
-  transposed_reduce<kAcc / 2>(acc, lane);
+  // lane bit 2: 4 -> 2   (partner = lane ^ 4)
+  {
+    const bool up = (lane & 4) != 0;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const float s0 = acc[k] + dpp_xor4(acc[k]);
+      const float s1 = acc[k + 2] + dpp_xor4(acc[k + 2]);
+      acc[k] = up ? s1 : s0;
+    }
+  }
+  // lane bit 1: 2 -> 1   (partner = lane ^ 2 = quad_perm [2,3,0,1])
+  {
+    const bool up = (lane & 2) != 0;
+    const float s0 = acc[0] + dpp<0x4E>(acc[0]);
+    const float s1 = acc[1] + dpp<0x4E>(acc[1]);
+    acc[0] = up ? s1 : s0;
+  }
+  // lane bit 0: both lanes of a pair end with the full 64-lane total (quad_perm [1,0,3,2])
+  acc[0] = acc[0] + dpp<0xB1>(acc[0]);
 }
 
 struct Best {
@@ -73,7 +120,8 @@ __device__ __forceinline__ bool better(float c, uint32_t d2, uint32_t flat, cons
 
 template <bool OOB, bool VOLUME, bool LDS_POINTS, bool PRUNE>
 __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, float2* s_pts,
-                                               uint8_t* s_lab, Best* s_best) {
+                                               uint8_t* s_lab, Best* s_best, uint32_t* s_iters, float* s_ay,
+                                               float* s_az) {
   const uint32_t f = blockIdx.y;
   const uint32_t k = blockIdx.x;   // theta index
   const ilcc_result* r = &c.res[f];
@@ -109,6 +157,14 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
     __syncthreads();
   }
 
+  // (ty, tz) tables in LDS: a cut-short tile lasts about as long as one L2 round trip, so its
+  // prologue must not wait for global loads
+  const bool tab_lds = c.p.n_ty <= kTabLds && c.p.n_tz <= kTabLds;
+  if (tab_lds) {
+    for (int i = threadIdx.x; i < c.p.n_ty; i += kGridThreads) s_ay[i] = c.ay[i];
+    for (int i = threadIdx.x; i < c.p.n_tz; i += kGridThreads) s_az[i] = c.az[i];
+    __syncthreads();
+  }
   const float cth = c.cth[k], sth = c.sth[k];
   const float Wh = 0.5f * (float)c.p.board_w, Hh = 0.5f * (float)c.p.board_h;
   const float delta = (float)c.p.huber_delta;
@@ -125,7 +181,7 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
   float* vol = VOLUME ? volume + (uint64_t)f * (uint64_t)c.p.n_th * n_ty * n_tz * 2u : nullptr;
 
   // after the transposed reduction lane l owns accumulator l = (a*kTileB + b)*2 + phase
-  const int my_l = lane & (kAcc - 1);
+  const int my_l = lane >> 1;   // transposed_sum leaves accumulator (lane >> 1) in this lane
   const int my_ph = my_l & 1, my_b = (my_l >> 1) % kTileB, my_a = (my_l >> 1) / kTileB;
 
   // start at the tile that holds the seed pass's best translation so that the shared bound is
@@ -155,13 +211,13 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
   }
 
   for (int tt = wid; tt < n_tiles; tt += kGridThreads / ILCC_WAVE) {
-    const int t = (tt + t0) % n_tiles;
+    const int t = (c.p.grid_prune == 9) ? tt : (tt + t0) % n_tiles;   // experiment 9: no tile rotation
     const int a0 = (t / ntb) * kTileA, b0 = (t % ntb) * kTileB;
     float ayv[kTileA], azv[kTileB];
 #pragma unroll
-    for (int a = 0; a < kTileA; ++a) ayv[a] = c.ay[min(a0 + a, n_ty - 1)];
+    for (int a = 0; a < kTileA; ++a) ayv[a] = tab_lds ? s_ay[min(a0 + a, n_ty - 1)] : c.ay[min(a0 + a, n_ty - 1)];
 #pragma unroll
-    for (int b = 0; b < kTileB; ++b) azv[b] = c.az[min(b0 + b, n_tz - 1)];
+    for (int b = 0; b < kTileB; ++b) azv[b] = tab_lds ? s_az[min(b0 + b, n_tz - 1)] : c.az[min(b0 + b, n_tz - 1)];
     float ayh[kTileA], azh[kTileB];
 #pragma unroll
     for (int a = 0; a < kTileA; ++a) ayh[a] = 0.5f * ayv[a];
@@ -179,9 +235,14 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
     float done_part = 0.f;           // this lane's candidate: reduced sum of the finished segments
     bool pruned = false;
     const int ia = a0 + my_a, ib = b0 + my_b;
-    const bool owner = lane < kAcc && ia < n_ty && ib < n_tz;
-    uint32_t next_check = PRUNE ? (n_iter >= 8 ? n_iter / 8 : 1) : 0xFFFFFFFFu;
+    const bool owner = ia < n_ty && ib < n_tz;   // both lanes of a pair own the same candidate
+    uint32_t next_check = PRUNE ? (n_iter >= kFirstCheckDiv ? n_iter / kFirstCheckDiv : 1) : 0xFFFFFFFFu;
+    if (c.p.grid_prune == 5 || c.p.grid_prune == 7 || c.p.grid_prune == 8 || c.p.grid_prune == 9) next_check = 0xFFFFFFFFu;   // experiments: PRUNE code, no checks at all
+    if (c.p.grid_prune == 6) next_check = n_iter / 2;     // experiment 6: a single check per tile
     uint32_t it_no = 0;
+    // the shared bound is fetched one segment ahead of its use: an L2 round trip is longer than a
+    // cut-short tile, and a slightly stale bound only delays a cut
+    uint32_t gb_bits = (PRUNE && c.p.grid_prune != 8) ? __hip_atomic_load(bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0x7f800000u;   // experiment 8: no tile-start load
 
     for (uint32_t base = 0; base < Mpad; base += ILCC_WAVE) {
       const uint32_t idx = base + lane;
@@ -263,12 +324,15 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
         }
       ++it_no;
       if (PRUNE && it_no == next_check && it_no < n_iter) {
-        transposed_sum(acc, lane);
+        if (c.p.grid_prune != 4)                            // experiment 4: no reduction in the check
+          transposed_sum(acc, lane);
         done_part += acc[0];
 #pragma unroll
         for (int k = 0; k < kAcc; ++k) acc[k] = 0.f;
-        const float gb = __uint_as_float(__hip_atomic_load(bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        const float lim = fminf(gb, best.cost);
+        float lim = fminf(__uint_as_float(gb_bits), best.cost);
+        if (c.p.grid_prune >= 2) lim = __builtin_inff();   // experiments: pay for the checks, never cut
+        if (c.p.grid_prune != 3)                            // experiment 3: no reload of the shared bound
+          gb_bits = __hip_atomic_load(bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next check
         if (!__any(owner && !(done_part > lim))) {
           pruned = true;
           break;
@@ -288,12 +352,14 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
       if (better(total, d2, flat, best)) best = Best{total, d2, flat};
       if (VOLUME) vol[flat] = total;
     }
-    if (PRUNE) {
+    if (PRUNE && c.p.grid_prune != 7) {   // experiment 7: never publish
       // share the wavefront's best complete cost with every workgroup of the frame
       float wb = best.cost;
 #pragma unroll
       for (int o = ILCC_WAVE / 2; o > 0; o >>= 1) wb = fminf(wb, __shfl_xor(wb, o, ILCC_WAVE));
-      if (lane == 0 && wb < shared_bound) {
+      // publish only what improves the frame's bound as this wavefront last saw it: atomics on a
+      // word that thousands of wavefronts also load serialise in L2 (measured: 2.5x on the kernel)
+      if (lane == 0 && wb < fminf(shared_bound, __uint_as_float(gb_bits))) {
         shared_bound = wb;
         atomicMin(bound, __float_as_uint(wb));   // costs are >= 0: uint order == float order
       }
@@ -311,10 +377,13 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
   }
   if (lane == 0) {
     s_best[wid] = best;
-    atomicAdd(c.grid_iters, (unsigned long long)iters_done);
+    s_iters[wid] = iters_done;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
+    uint32_t it_sum = 0;
+    for (int w = 0; w < kGridThreads / ILCC_WAVE; ++w) it_sum += s_iters[w];
+    atomicAdd(c.grid_iters + (f & (kIterSlots - 1)), (unsigned long long)it_sum);   // spread over 64 words
     Best b = s_best[0];
     for (int w = 1; w < kGridThreads / ILCC_WAVE; ++w)
       if (better(s_best[w].cost, s_best[w].d2, s_best[w].flat, b)) b = s_best[w];
@@ -330,13 +399,15 @@ template <bool OOB, bool VOLUME, bool PRUNE>
 __global__ __launch_bounds__(kGridThreads) void k6_grid_cost(Ctx c, float* volume) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ Best s_best[kGridThreads / ILCC_WAVE];
+  __shared__ uint32_t s_iters[kGridThreads / ILCC_WAVE];
+  __shared__ float s_ay[kTabLds], s_az[kTabLds];
   float2* s_pts = reinterpret_cast<float2*>(smem);
   uint8_t* s_lab = smem + sizeof(float2) * (size_t)c.grid_lds_points;
   const uint32_t M = c.n_lab[blockIdx.y];
   if (M <= c.grid_lds_points)
-    grid_cost_body<OOB, VOLUME, true, PRUNE>(c, volume, s_pts, s_lab, s_best);
+    grid_cost_body<OOB, VOLUME, true, PRUNE>(c, volume, s_pts, s_lab, s_best, s_iters, s_ay, s_az);
   else
-    grid_cost_body<OOB, VOLUME, false, PRUNE>(c, volume, s_pts, s_lab, s_best);
+    grid_cost_body<OOB, VOLUME, false, PRUNE>(c, volume, s_pts, s_lab, s_best, s_iters, s_ay, s_az);
 }
 
 void launch_grid_cost(const Ctx& c, hipStream_t s, int32_t use_oob, float* cost_volume, bool prune) {
