@@ -35,6 +35,9 @@ sys.path.insert(0, ROOT)
 
 BYTES_PER_FRAME_CFG2 = 16 * 28800 + 12 * 35 + 64   # 461 284 B
 HBM_PEAK_GBPS = 8000.0                              # MI355X_MICROARCH.md: 8 TB/s spec
+# HBM bytes of the K6 stage (seed + full launch) for the default 128-frame step, from the PMC passes
+# committed in profiles/r01_hbm_traffic_pmc.csv: 2 x (5145254 + 5549811) + 508685 + 348941
+K6_HBM_TRAFFIC_BYTES_128 = 22247756
 # VALU issue peak: 256 CU x 4 SIMD x 32 lanes x 2.4 GHz = 78.6 T lane-instructions/s
 # (= the 157.3 TFLOP/s fp32 vector peak of MI355X_MICROARCH.md when every instruction is an FMA)
 VALU_ISSUE_PEAK_T = 78.6
@@ -175,12 +178,15 @@ def main():
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": None,
+                "traffic": K6_HBM_TRAFFIC_BYTES_128 if (F == 128 and lidar.n_points == 28800) else None,
+                "traffic_note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (profiles/r01_hbm_traffic_pmc.csv): "
+                                "(2 x FETCH_SIZE + WRITE_SIZE) x 1024 summed over the stage's two launches (seed + full pass)",
                 "launch_ms": k6_ms,
                 "algorithmic_bytes_per_launch": k6_bytes,
-                "note": "kernel is VALU/LDS-bound by construction (points staged once in LDS, ~1e8 "
-                        "point-candidate evaluations per frame, no MFMA); HBM fraction reported because "
-                        "BASELINE.json asks for it",
+                "note": "k6_grid_cost is VALU-bound by construction (points staged once in LDS, ~1e8 nominal "
+                        "point-candidate evaluations per frame, no MFMA); the HBM fraction is reported because "
+                        "BASELINE.json asks for it.  launch = the K6 stage of one step (seed launch + full launch), "
+                        "timed by HIP events on the library's stream",
                 "valu": {"evals_executed_per_launch": evals_per_launch,
                          "evals_nominal_per_launch": evals_nominal,
                          "executed_fraction": evals_per_launch / evals_nominal if evals_nominal else None,
@@ -191,7 +197,17 @@ def main():
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(clouds, clicks, gts, board, args.cpu_seconds)
+            # the reference's own trajectory on the GPU (ILCC_SOLVER_REFERENCE_LOCAL), to compare corner for
+            # corner with the CPU port below (BASELINE.json: <= 1e-3 m vs the reference CPU path)
+            p_ref = N.default_params()
+            p_ref.solver = N.SOLVER_REFERENCE_LOCAL
+            est.set_params(p_ref)
+            t_ref = time.perf_counter()
+            res_ref = est.extract_device(d_clouds.data_ptr(), F, lidar.n_points, d_clicks.data_ptr())
+            t_ref = time.perf_counter() - t_ref
+            gpu_ref = [res_ref[f].corners_array() if res_ref[f].status == 0 else None for f in range(F)]
+            out["cpu_baseline"] = cpu_baseline(clouds, clicks, gts, board, args.cpu_seconds, gpu_ref)
+            out["cpu_baseline"]["gpu_reference_local_mode_frames_per_s_single_call"] = F / t_ref
         print(json.dumps(out), flush=True)
     est.close()
     if world > 1:
@@ -199,22 +215,27 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(clouds, clicks, gts, board, budget_s):
+def cpu_baseline(clouds, clicks, gts, board, budget_s, gpu_ref=None):
     """Reference-faithful CPU path (oracle, ORC_SOLVER_REFERENCE_LOCAL, both phases), 1 thread."""
     from lidar_camera_calibration_amd import synth
     from oracle import binding as ob   # checker / baseline only; never on the product path
     p = ob.default_params()
     p.solver = ob.SOLVER_REFERENCE_LOCAL
     p.phase_mode = 2
-    p.accum_float = 1
+    p.accum_float = 0   # same accumulation precision as the HIP path, so the corner comparison below is like for like
     n = 0
-    errs = []
+    errs, dev, status_match = [], [], 0
     t0 = time.perf_counter()
     while True:
         f = n % len(clouds)
         r = ob.extract(clouds[f], clicks[f], p)
-        if n < len(clouds) and r.status == 0:
-            errs.append(synth.corner_error(ob.result_corners(r), gts[f], board))
+        if n < len(clouds):
+            if r.status == 0:
+                errs.append(synth.corner_error(ob.result_corners(r), gts[f], board))
+            if gpu_ref is not None:
+                status_match += int((r.status == 0) == (gpu_ref[f] is not None))
+                if r.status == 0 and gpu_ref[f] is not None:
+                    dev.append(float(np.abs(ob.result_corners(r) - gpu_ref[f]).max()))
         n += 1
         if time.perf_counter() - t0 >= budget_s and n >= 16:
             break
@@ -228,6 +249,14 @@ def cpu_baseline(clouds, clicks, gts, board, budget_s):
                   "path (crop, cluster, RANSAC, PCA, gray zone, 2 phases x Ceres-style pass A+B); omits "
                   "Ceres autodiff/heap and PCL kd-tree overheads, so it is faster than the real reference" % (n, dt),
         "max_corner_error_mm_vs_ground_truth": 1e3 * max(errs) if errs else None,
+        "gpu_vs_cpu_corner_deviation_mm": {
+            "what": "GPU ILCC_SOLVER_REFERENCE_LOCAL vs this CPU path, same frames, max |dx| over corners",
+            "frames_compared": len(dev), "status_agree": status_match,
+            "max": 1e3 * max(dev) if dev else None,
+            "n_above_1mm": int(sum(d > 1e-3 for d in dev)),
+            "note": "both sides accumulate centroid/covariance in double (PCL: float; switching the oracle to float "
+                    "moves corners by < 0.1 mm)",
+        } if gpu_ref is not None else None,
     }
 
 

@@ -234,6 +234,43 @@ def test_ragged_batch_and_single_frame_entry(ob, frames):
     m.close()
 
 
+def test_branch_and_bound_does_not_change_the_result(ob, frames):
+    """grid_prune=1 (seeding pass + early exit of beaten candidate tiles) must return exactly what the
+    cut-free exhaustive pass returns: same argmin index, same corners; and both equal the oracle's argmin."""
+    clouds, clicks, _ = frames
+    out = {}
+    for prune in (0, 1):
+        p = N.default_params()
+        p.grid_prune = prune
+        e = LidarCornersBatch(16, 28800, p)
+        res = e.extract(clouds, clicks)
+        out[prune] = [(r.status, r.grid_index, r.corners_array()) for r in res]
+        tm = e.timing()
+        if prune:
+            assert tm.grid_cost_evals_sum < 0.6 * tm.grid_cost_evals_nominal_sum       # it does cut work
+        else:
+            assert tm.grid_cost_evals_sum >= tm.grid_cost_evals_nominal_sum
+        e.close()
+    for a, b in zip(out[0], out[1]):
+        assert a[0] == b[0] and a[1] == b[1]
+        assert np.abs(a[2] - b[2]).max() < 1e-6 if a[0] == 0 else True
+    # K6 alone on arbitrary points, pruned entry vs the oracle's exhaustive argmin
+    rng = np.random.default_rng(77)
+    p = N.default_params()
+    e = LidarCornersBatch(1, 28800, p)
+    op = ob.default_params()
+    op.n_th, op.n_ty, op.n_tz = 9, 12, 12
+    for k in ("n_th", "n_ty", "n_tz"):
+        setattr(p, k, getattr(op, k))
+    e.set_params(p)
+    for m in (200, 1500):
+        yz, lab = _rand_points(rng, m)
+        bi, bc, _ = e.grid_cost(yz, lab, 1, want_volume=False)            # branch-and-bound variant
+        oflat, oc, ovol = ob.grid_search(yz[:, 0], yz[:, 1], lab.astype(np.int8), op, 1, want_volume=True)
+        assert ovol[bi] <= oc * (1 + 2e-5) + 2e-6 and bc == pytest.approx(ovol[bi], rel=2e-5, abs=2e-6)
+    e.close()
+
+
 def test_async_submit_wait_matches_synchronous_calls(frames):
     """Three batches in flight (submit/wait) return exactly what three synchronous calls return."""
     import torch
