@@ -102,6 +102,7 @@ bool params_ok(const ilcc_params& p, std::string& why) {
   if (!(p.cluster_tol > 0) || p.cluster_min < 1 || p.cluster_max < p.cluster_min) return bad("cluster params");
   if (p.solver != ILCC_SOLVER_REFERENCE_LOCAL && p.solver != ILCC_SOLVER_GRID) return bad("solver");
   if (p.phase_mode < 0 || p.phase_mode > 2) return bad("phase_mode");
+  if (p.grid_prune != 0 && p.grid_prune != 1) return bad("grid_prune must be 0 or 1");
   if (p.max_iterations < 0 || p.max_iterations > 100000) return bad("max_iterations");
   if (p.n_th < 1 || p.n_ty < 1 || p.n_tz < 1) return bad("grid sizes must be >= 1");
   if ((uint64_t)p.n_th * p.n_ty * p.n_tz * 2ull >= 0xFFFFFFFFull) return bad("grid too large");
@@ -312,8 +313,7 @@ int32_t enqueue(ilcc_handle* h, int si, const float4* d_xyzi, const uint64_t* of
   if (sl.grid) {
     const bool prune = h->p.grid_prune != 0;
     Ctx full = c;
-    static const bool no_seed = std::getenv("ILCC_K6_NOSEED") != nullptr;   // experiment switch
-    if (prune && !no_seed && h->n_th2 > 0 && h->p.n_th >= 8 && h->p.n_ty >= 8 && h->p.n_tz >= 8) {
+    if (prune && h->n_th2 > 0 && h->p.n_th >= 8 && h->p.n_ty >= 8 && h->p.n_tz >= 8) {
       // seeding pass: a decimated subset of the SAME candidates, fully evaluated (with pruning
       // among themselves) -> per-frame bound + where to start the full pass
       Ctx seed = c;

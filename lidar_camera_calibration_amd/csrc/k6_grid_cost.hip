@@ -26,10 +26,6 @@
 // under phase 0 is a match under phase 1: both phases come out of one pass.
 #include "ilcc_internal.h"
 
-#ifndef ILCC_K6_SCHED
-#define ILCC_K6_SCHED 0
-#endif
-
 namespace ilcc {
 
 typedef unsigned long long lanemask_t;
@@ -211,7 +207,7 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
   }
 
   for (int tt = wid; tt < n_tiles; tt += kGridThreads / ILCC_WAVE) {
-    const int t = (c.p.grid_prune == 9) ? tt : (tt + t0) % n_tiles;   // experiment 9: no tile rotation
+    const int t = (tt + t0) % n_tiles;
     const int a0 = (t / ntb) * kTileA, b0 = (t % ntb) * kTileB;
     float ayv[kTileA], azv[kTileB];
 #pragma unroll
@@ -237,12 +233,10 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
     const int ia = a0 + my_a, ib = b0 + my_b;
     const bool owner = ia < n_ty && ib < n_tz;   // both lanes of a pair own the same candidate
     uint32_t next_check = PRUNE ? (n_iter >= kFirstCheckDiv ? n_iter / kFirstCheckDiv : 1) : 0xFFFFFFFFu;
-    if (c.p.grid_prune == 5 || c.p.grid_prune == 7 || c.p.grid_prune == 8 || c.p.grid_prune == 9) next_check = 0xFFFFFFFFu;   // experiments: PRUNE code, no checks at all
-    if (c.p.grid_prune == 6) next_check = n_iter / 2;     // experiment 6: a single check per tile
     uint32_t it_no = 0;
     // the shared bound is fetched one segment ahead of its use: an L2 round trip is longer than a
     // cut-short tile, and a slightly stale bound only delays a cut
-    uint32_t gb_bits = (PRUNE && c.p.grid_prune != 8) ? __hip_atomic_load(bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0x7f800000u;   // experiment 8: no tile-start load
+    uint32_t gb_bits = PRUNE ? __hip_atomic_load(bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0x7f800000u;
 
     for (uint32_t base = 0; base < Mpad; base += ILCC_WAVE) {
       const uint32_t idx = base + lane;
@@ -316,23 +310,15 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
             x0 += unballot(mis0) ? h : 0.f;
             x1 += unballot(mis0) ? 0.f : h;
           }
-#if ILCC_K6_SCHED == 1
-          __builtin_amdgcn_sched_barrier(0);
-#elif ILCC_K6_SCHED == 2
-          if (b & 1) __builtin_amdgcn_sched_barrier(0);
-#endif
         }
       ++it_no;
       if (PRUNE && it_no == next_check && it_no < n_iter) {
-        if (c.p.grid_prune != 4)                            // experiment 4: no reduction in the check
-          transposed_sum(acc, lane);
+        transposed_sum(acc, lane);
         done_part += acc[0];
 #pragma unroll
         for (int k = 0; k < kAcc; ++k) acc[k] = 0.f;
-        float lim = fminf(__uint_as_float(gb_bits), best.cost);
-        if (c.p.grid_prune >= 2) lim = __builtin_inff();   // experiments: pay for the checks, never cut
-        if (c.p.grid_prune != 3)                            // experiment 3: no reload of the shared bound
-          gb_bits = __hip_atomic_load(bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next check
+        const float lim = fminf(__uint_as_float(gb_bits), best.cost);
+        gb_bits = __hip_atomic_load(bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next check
         if (!__any(owner && !(done_part > lim))) {
           pruned = true;
           break;
@@ -352,7 +338,7 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
       if (better(total, d2, flat, best)) best = Best{total, d2, flat};
       if (VOLUME) vol[flat] = total;
     }
-    if (PRUNE && c.p.grid_prune != 7) {   // experiment 7: never publish
+    if (PRUNE) {
       // share the wavefront's best complete cost with every workgroup of the frame
       float wb = best.cost;
 #pragma unroll
