@@ -36,7 +36,6 @@ __device__ __forceinline__ bool unballot(lanemask_t m) { return __builtin_amdgcn
 #define ILCC_K6_FIRST_CHECK_DIV 16
 #endif
 constexpr int kFirstCheckDiv = ILCC_K6_FIRST_CHECK_DIV;   // first bound check after n_iter / this many iterations
-constexpr int kTabLds = 256;   // (ty, tz) table entries kept in LDS
 constexpr int kAcc = kTileA * kTileB * 2;   // partial sums per lane
 
 // ---- transposed wavefront reduction of the 32 partial sums, in registers only ----------------
@@ -138,29 +137,31 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
   const uint8_t* __restrict__ glab = c.lab + beg;
   const uint32_t Mpad = (M + ILCC_WAVE - 1) & ~(uint32_t)(ILCC_WAVE - 1);
 
+  // Point order: trip `it` of a wavefront takes the points {lane * n_iter + it}, i.e. every trip is a
+  // sample spread over the whole stream (ring order would hand a trip 64 neighbours on one ring,
+  // which says little about a candidate; a spread sample lets the first bound check cut more tiles).
+  const uint32_t n_iter_pts = Mpad / ILCC_WAVE;
   if (LDS_POINTS) {
-    // stage once per workgroup; pad the last wavefront-row with harmless points
-    for (uint32_t i = threadIdx.x; i < Mpad; i += kGridThreads) {
+    // stage once per workgroup, already in trip order: slot it*64 + lane <- point lane*n_iter + it
+    for (uint32_t sl = threadIdx.x; sl < Mpad; sl += kGridThreads) {
+      const uint32_t i = (sl & (ILCC_WAVE - 1)) * n_iter_pts + (sl >> 6);
       float2 v = make_float2(0.f, 0.f);
       uint8_t l = 0;
       if (i < M) {
         v = gyz[i];
         l = glab[i];
       }
-      s_pts[i] = v;
-      s_lab[i] = l;
+      s_pts[sl] = v;
+      s_lab[sl] = l;
     }
     __syncthreads();
   }
 
   // (ty, tz) tables in LDS: a cut-short tile lasts about as long as one L2 round trip, so its
   // prologue must not wait for global loads
-  const bool tab_lds = c.p.n_ty <= kTabLds && c.p.n_tz <= kTabLds;
-  if (tab_lds) {
-    for (int i = threadIdx.x; i < c.p.n_ty; i += kGridThreads) s_ay[i] = c.ay[i];
-    for (int i = threadIdx.x; i < c.p.n_tz; i += kGridThreads) s_az[i] = c.az[i];
-    __syncthreads();
-  }
+  for (int i = threadIdx.x; i < c.p.n_ty; i += kGridThreads) s_ay[i] = c.ay[i];
+  for (int i = threadIdx.x; i < c.p.n_tz; i += kGridThreads) s_az[i] = c.az[i];
+  __syncthreads();
   const float cth = c.cth[k], sth = c.sth[k];
   const float Wh = 0.5f * (float)c.p.board_w, Hh = 0.5f * (float)c.p.board_h;
   const float delta = (float)c.p.huber_delta;
@@ -206,14 +207,24 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
     }
   }
 
+  // tiles wid, wid+4, ... of the rotated order, tracked as (row, column) so that the per-tile
+  // prologue needs no integer division
+  int t_first = wid + t0;
+  if (t_first >= n_tiles) t_first -= n_tiles;
+  int ta = t_first / ntb, tb = t_first - ta * ntb;
   for (int tt = wid; tt < n_tiles; tt += kGridThreads / ILCC_WAVE) {
-    const int t = (tt + t0) % n_tiles;
-    const int a0 = (t / ntb) * kTileA, b0 = (t % ntb) * kTileB;
+    const int a0 = ta * kTileA, b0 = tb * kTileB;
+    tb += kGridThreads / ILCC_WAVE;            // advance to this wavefront's next tile
+    while (tb >= ntb) {
+      tb -= ntb;
+      ++ta;
+    }
+    if (ta >= nta) ta -= nta;
     float ayv[kTileA], azv[kTileB];
 #pragma unroll
-    for (int a = 0; a < kTileA; ++a) ayv[a] = tab_lds ? s_ay[min(a0 + a, n_ty - 1)] : c.ay[min(a0 + a, n_ty - 1)];
+    for (int a = 0; a < kTileA; ++a) ayv[a] = s_ay[min(a0 + a, n_ty - 1)];
 #pragma unroll
-    for (int b = 0; b < kTileB; ++b) azv[b] = tab_lds ? s_az[min(b0 + b, n_tz - 1)] : c.az[min(b0 + b, n_tz - 1)];
+    for (int b = 0; b < kTileB; ++b) azv[b] = s_az[min(b0 + b, n_tz - 1)];
     float ayh[kTileA], azh[kTileB];
 #pragma unroll
     for (int a = 0; a < kTileA; ++a) ayh[a] = 0.5f * ayv[a];
@@ -239,17 +250,17 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
     uint32_t gb_bits = PRUNE ? __hip_atomic_load(bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0x7f800000u;
 
     for (uint32_t base = 0; base < Mpad; base += ILCC_WAVE) {
-      const uint32_t idx = base + lane;
+      const uint32_t idx = (uint32_t)lane * n_iter_pts + (base >> 6);   // point of this lane in this trip
       float2 p;
       uint32_t lab;
       if (LDS_POINTS) {
-        p = s_pts[idx];
-        lab = s_lab[idx];
+        p = s_pts[base + lane];
+        lab = s_lab[base + lane];
       } else {
         p = idx < M ? gyz[idx] : make_float2(0.f, 0.f);
         lab = idx < M ? glab[idx] : 0;
       }
-      const float dl = idx < M ? delta : 0.f;   // padded lanes: q = min(r,0) = 0 -> no contribution
+      const float dl = idx < M ? delta : 0.f;   // padded slots: q = min(r,0) = 0 -> no contribution
       // Lane predicates are kept as 64-bit wave masks in SGPR pairs (ballot), combined with SALU
       // ops per candidate and fed straight back to v_cndmask (inverse ballot): the VALU only
       // sees the float work.
@@ -386,9 +397,10 @@ __global__ __launch_bounds__(kGridThreads) void k6_grid_cost(Ctx c, float* volum
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ Best s_best[kGridThreads / ILCC_WAVE];
   __shared__ uint32_t s_iters[kGridThreads / ILCC_WAVE];
-  __shared__ float s_ay[kTabLds], s_az[kTabLds];
   float2* s_pts = reinterpret_cast<float2*>(smem);
   uint8_t* s_lab = smem + sizeof(float2) * (size_t)c.grid_lds_points;
+  float* s_ay = reinterpret_cast<float*>(smem + (sizeof(float2) + 1) * (size_t)c.grid_lds_points);   // n_ty floats
+  float* s_az = s_ay + c.p.n_ty;                                                                       // n_tz floats
   const uint32_t M = c.n_lab[blockIdx.y];
   if (M <= c.grid_lds_points)
     grid_cost_body<OOB, VOLUME, true, PRUNE>(c, volume, s_pts, s_lab, s_best, s_iters, s_ay, s_az);
@@ -398,13 +410,13 @@ __global__ __launch_bounds__(kGridThreads) void k6_grid_cost(Ctx c, float* volum
 
 void launch_grid_cost(const Ctx& c, hipStream_t s, int32_t use_oob, float* cost_volume, bool prune) {
   const dim3 grid(c.grid_blocks, c.n_frames), block(kGridThreads);
-  const size_t lds = (sizeof(float2) + 1) * (size_t)c.grid_lds_points;
+  const size_t lds = (sizeof(float2) + 1) * (size_t)c.grid_lds_points + sizeof(float) * (size_t)(c.p.n_ty + c.p.n_tz);
   static bool attr_done = false;
   const void* fns[] = {(const void*)k6_grid_cost<true, true, false>,  (const void*)k6_grid_cost<true, false, false>,
                        (const void*)k6_grid_cost<false, true, false>, (const void*)k6_grid_cost<false, false, false>,
                        (const void*)k6_grid_cost<true, false, true>,  (const void*)k6_grid_cost<false, false, true>};
   if (!attr_done) {   // allow > 64 KiB of dynamic LDS (gfx950 has 160 KiB per CU)
-    const int cap = (int)((sizeof(float2) + 1) * (size_t)kGridLdsPointsMax);
+    const int cap = (int)((sizeof(float2) + 1) * (size_t)kGridLdsPointsMax + sizeof(float) * 2 * 1024);
     for (const void* fn : fns) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
     attr_done = true;
   }
