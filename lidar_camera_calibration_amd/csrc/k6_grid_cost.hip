@@ -39,12 +39,12 @@ constexpr int kFirstCheckDiv = ILCC_K6_FIRST_CHECK_DIV;   // first bound check a
 constexpr int kAcc = kTileA * kTileB * 2;   // partial sums per lane
 
 // ---- transposed wavefront reduction of the 32 partial sums, in registers only ----------------
-// 32 accumulators x 64 lanes -> lane l holds the total of accumulator (l >> 1) in acc[0].
+// kAcc (32 or 64) accumulators x 64 lanes -> every lane ends with one accumulator's total in acc[0].
 // Every step halves the values per lane and doubles the lanes summed; partners are reached with
 // v_permlane32_swap / v_permlane16_swap (gfx950) and DPP row rotations / quad permutes -- plain
 // VALU instructions, no LDS round trips (a ds_bpermute chain costs several point-iterations of
 // latency, which matters because the branch-and-bound checks reduce after every few iterations).
-static_assert(kAcc == 32, "the register reduction below is written for a 4 x 4 x 2 tile");
+static_assert(kAcc == 32 || kAcc == 64, "4 x 4 or 4 x 8 candidate tiles");
 
 // [aL+aH | bL+bH] over the two 32-lane halves
 __device__ __forceinline__ float swap32_add(float a, float b) {
@@ -65,44 +65,41 @@ __device__ __forceinline__ float dpp_xor4(float v) {   // lane i <- lane i^4 ins
   const unsigned lo = __builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x124 /*row_ror:4*/, 0xf, 0xa, false);
   return __uint_as_float(__builtin_amdgcn_update_dpp(lo, __float_as_uint(v), 0x12C /*row_ror:12*/, 0xf, 0x5, false));
 }
-
-__device__ __forceinline__ void transposed_sum(float (&acc)[kAcc], int lane) {
-  // lane bit 5: 32 -> 16 values
-#pragma unroll
-  for (int k = 0; k < 16; ++k) acc[k] = swap32_add(acc[k], acc[k + 16]);
-  // lane bit 4: 16 -> 8
-#pragma unroll
-  for (int k = 0; k < 8; ++k) acc[k] = swap16_add(acc[k], acc[k + 8]);
-  // lane bit 3: 8 -> 4   (partner = lane ^ 8 = row_ror:8)
-  {
-    const bool up = (lane & 8) != 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const float s0 = acc[k] + dpp<0x128>(acc[k]);
-      const float s1 = acc[k + 4] + dpp<0x128>(acc[k + 4]);
-      acc[k] = up ? s1 : s0;
-    }
-  }
-  // lane bit 2: 4 -> 2   (partner = lane ^ 4)
-  {
-    const bool up = (lane & 4) != 0;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const float s0 = acc[k] + dpp_xor4(acc[k]);
-      const float s1 = acc[k + 2] + dpp_xor4(acc[k + 2]);
-      acc[k] = up ? s1 : s0;
-    }
-  }
-  // lane bit 1: 2 -> 1   (partner = lane ^ 2 = quad_perm [2,3,0,1])
-  {
-    const bool up = (lane & 2) != 0;
-    const float s0 = acc[0] + dpp<0x4E>(acc[0]);
-    const float s1 = acc[1] + dpp<0x4E>(acc[1]);
-    acc[0] = up ? s1 : s0;
-  }
-  // lane bit 0: both lanes of a pair end with the full 64-lane total (quad_perm [1,0,3,2])
-  acc[0] = acc[0] + dpp<0xB1>(acc[0]);
+// v + v[lane ^ (1 << BIT)] in every lane
+template <int BIT>
+__device__ __forceinline__ float partner_add(float v) {
+  if constexpr (BIT == 5) return swap32_add(v, v);
+  else if constexpr (BIT == 4) return swap16_add(v, v);
+  else if constexpr (BIT == 3) return v + dpp<0x128>(v);   // row_ror:8
+  else if constexpr (BIT == 2) return v + dpp_xor4(v);
+  else if constexpr (BIT == 1) return v + dpp<0x4E>(v);    // quad_perm [2,3,0,1]
+  else return v + dpp<0xB1>(v);                            // quad_perm [1,0,3,2]
 }
+// lanes with bit BIT clear end with lo + lo[partner], the others with hi + hi[partner]
+template <int BIT>
+__device__ __forceinline__ float halve(float lo, float hi, bool up) {
+  if constexpr (BIT == 5) return swap32_add(lo, hi);
+  else if constexpr (BIT == 4) return swap16_add(lo, hi);
+  else {
+    const float s0 = partner_add<BIT>(lo), s1 = partner_add<BIT>(hi);
+    return up ? s1 : s0;
+  }
+}
+// N values per lane, lane bits BIT..0 still to be summed over
+template <int N, int BIT>
+__device__ __forceinline__ void tsum(float (&acc)[kAcc], int lane) {
+  if constexpr (N > 1) {
+    const bool up = (lane & (1 << BIT)) != 0;
+#pragma unroll
+    for (int k = 0; k < N / 2; ++k) acc[k] = halve<BIT>(acc[k], acc[k + N / 2], up);
+    if constexpr (BIT > 0) tsum<N / 2, BIT - 1>(acc, lane);
+  } else {
+    acc[0] = partner_add<BIT>(acc[0]);
+    if constexpr (BIT > 0) tsum<1, BIT - 1>(acc, lane);
+  }
+}
+// kAcc accumulators x 64 lanes -> acc[0] of lane l = total of accumulator l (kAcc = 64) or l >> 1 (kAcc = 32)
+__device__ __forceinline__ void transposed_sum(float (&acc)[kAcc], int lane) { tsum<kAcc, 5>(acc, lane); }
 
 struct Best {
   float cost;
@@ -178,7 +175,7 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
   float* vol = VOLUME ? volume + (uint64_t)f * (uint64_t)c.p.n_th * n_ty * n_tz * 2u : nullptr;
 
   // after the transposed reduction lane l owns accumulator l = (a*kTileB + b)*2 + phase
-  const int my_l = lane >> 1;   // transposed_sum leaves accumulator (lane >> 1) in this lane
+  const int my_l = (kAcc == ILCC_WAVE) ? lane : lane >> 1;   // the accumulator transposed_sum leaves in this lane
   const int my_ph = my_l & 1, my_b = (my_l >> 1) % kTileB, my_a = (my_l >> 1) / kTileB;
 
   // start at the tile that holds the seed pass's best translation so that the shared bound is
@@ -282,46 +279,51 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
         oa[a] = ballot(!(fabsf(tt) < Wh));          // not (0 < i < W)
         ui[a] = fabsf(tt) - Wh;                     // |.| = min(|i|, |i-W|)
       }
-      float dj[kTileB], uj[kTileB];
-      lanemask_t pb[kTileB], ob[kTileB];
+      // tz candidates in groups of four: their masks live in SGPRs only while the group is combined
 #pragma unroll
-      for (int b = 0; b < kTileB; ++b) {
-        const float j = bj + azv[b];
-        dj[b] = j - rintf(j);
-        pb[b] = ballot(__builtin_amdgcn_fractf(bjh + azh[b]) >= 0.5f);
-        const float tt = j - Hh;
-        ob[b] = ballot(!(fabsf(tt) < Hh));
-        uj[b] = fabsf(tt) - Hh;
-      }
+      for (int bg = 0; bg < kTileB; bg += 4) {
+        float dj[4], uj[4];
+        lanemask_t pb[4], ob[4];
 #pragma unroll
-      for (int a = 0; a < kTileA; ++a)
-#pragma unroll
-        for (int b = 0; b < kTileB; ++b) {
-          const lanemask_t oob = oa[a] | ob[b];
-          const lanemask_t mis0 = pa[a] ^ pb[b];   // colour mismatch under phase 0 (topleftWhite=false)
-          float rin = fabsf(di[a]) + fabsf(dj[b]);
-          float rr;
-          if (OOB) {
-            float rout = fabsf(ui[a]) + fabsf(uj[b]);
-            // keep "select of two sums" (2 full-rate adds + 1 v_cndmask): LLVM would rewrite it into
-            // a sum of two selects, and v_cndmask issues at about half the rate of v_add on gfx950
-            asm volatile("" : "+v"(rin), "+v"(rout));
-            rr = unballot(oob) ? rout : rin;
-          } else {
-            rr = unballot(oob) ? 0.f : rin;
-          }
-          const float q = fminf(rr, dl);
-          const float h = q * fmaf(-0.5f, q, rr);
-          float& x0 = acc[(a * kTileB + b) * 2];
-          float& x1 = acc[(a * kTileB + b) * 2 + 1];
-          if (OOB) {
-            x0 += unballot(oob | mis0) ? h : 0.f;
-            x1 += unballot(oob | ~mis0) ? h : 0.f;
-          } else {
-            x0 += unballot(mis0) ? h : 0.f;
-            x1 += unballot(mis0) ? 0.f : h;
-          }
+        for (int b = 0; b < 4; ++b) {
+          const float j = bj + azv[bg + b];
+          dj[b] = j - rintf(j);
+          pb[b] = ballot(__builtin_amdgcn_fractf(bjh + azh[bg + b]) >= 0.5f);
+          const float tt = j - Hh;
+          ob[b] = ballot(!(fabsf(tt) < Hh));
+          uj[b] = fabsf(tt) - Hh;
         }
+#pragma unroll
+        for (int a = 0; a < kTileA; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            const lanemask_t oob = oa[a] | ob[b];
+            const lanemask_t mis0 = pa[a] ^ pb[b];   // colour mismatch under phase 0 (topleftWhite=false)
+            float rin = fabsf(di[a]) + fabsf(dj[b]);
+            float rr;
+            if (OOB) {
+              float rout = fabsf(ui[a]) + fabsf(uj[b]);
+              // keep "select of two sums" (2 full-rate adds + 1 v_cndmask): LLVM would rewrite it into
+              // a sum of two selects, and v_cndmask issues at about half the rate of v_add on gfx950
+              asm volatile("" : "+v"(rin), "+v"(rout));
+              rr = unballot(oob) ? rout : rin;
+            } else {
+              rr = unballot(oob) ? 0.f : rin;
+            }
+            const float q = fminf(rr, dl);
+            const float h = q * fmaf(-0.5f, q, rr);
+            float& x0 = acc[(a * kTileB + bg + b) * 2];
+            float& x1 = acc[(a * kTileB + bg + b) * 2 + 1];
+            if (OOB) {
+              x0 += unballot(oob | mis0) ? h : 0.f;
+              x1 += unballot(oob | ~mis0) ? h : 0.f;
+            } else {
+              x0 += unballot(mis0) ? h : 0.f;
+              x1 += unballot(mis0) ? 0.f : h;
+            }
+          }
+        if (kTileB > 4) __builtin_amdgcn_sched_barrier(0);   // keep the groups apart (SGPR pressure)
+      }
       ++it_no;
       if (PRUNE && it_no == next_check && it_no < n_iter) {
         transposed_sum(acc, lane);
