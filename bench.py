@@ -63,13 +63,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+    # test hooks for a 1-GPU box (never set by the driver): run the N > 1 code path with every rank on
+    # device 0 and the records gathered over gloo instead of RCCL
+    backend = os.environ.get("ILCC_BENCH_BACKEND", "nccl")
+    if os.environ.get("ILCC_BENCH_SINGLE_DEVICE"):
+        local_rank = 0
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: libilcc_hip has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    rec_dev = dev if backend == "nccl" else torch.device("cpu")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend=backend, rank=rank, world_size=world,
+                                **({"device_id": dev} if backend == "nccl" else {}))
 
     from lidar_camera_calibration_amd import LidarCornersBatch, synth
     from lidar_camera_calibration_amd import _native as N
@@ -88,24 +95,35 @@ def main():
 
     depth = max(1, min(args.in_flight, 3))
 
+    pending = []   # the previous step's gather, still in flight (one RCCL gather per step)
+
     def finish(ticket):
         res = est.wait(ticket)
         if world > 1:   # the path's only collective: one gather of this step's corner records
-            rec = torch.from_numpy(pack_records(res, F, board.n_corners)).to(dev, non_blocking=False)
-            return res, gather_records(rec, world, rank)
-        return res, None
+            rec = torch.from_numpy(pack_records(res, F, board.n_corners)).to(rec_dev)
+            while pending:                       # at most one collective outstanding
+                w, _ = pending.pop(0)
+                w.wait()
+            pending.append(gather_records(rec, world, rank, async_op=True))
+        return res
 
     def run(n_steps):
         """n_steps full passes, up to `depth` batches in flight (the library's submit/wait pipeline:
         the latency-bound stages of one batch overlap with the grid search of another)."""
-        tickets, last = [], (None, None)
+        tickets, last = [], None
         for _ in range(n_steps):
             tickets.append(est.submit_device(d_clouds.data_ptr(), F, lidar.n_points, d_clicks.data_ptr()))
             if len(tickets) == depth:
                 last = finish(tickets.pop(0))
         while tickets:
             last = finish(tickets.pop(0))
-        return last
+        gathered = None
+        while pending:
+            w, bufs = pending.pop(0)
+            if w is not None:
+                w.wait()
+            gathered = torch.cat(bufs, 0) if bufs is not None else None
+        return last, gathered
 
     run(args.warmup)
     est.reset_timing()
@@ -119,9 +137,11 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=rec_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        if rank == 0:   # the gather delivered every rank's records of the last step
+            assert gathered is not None and tuple(gathered.shape) == (world * F, 16 + 3 * board.n_corners)
 
     # accuracy of the last step on this rank
     ok = [f for f in range(F) if res[f].status == 0]

@@ -28,6 +28,24 @@ def shard_range(n_frames: int, world: int, rank: int) -> Tuple[int, int]:
     return lo, min(n_frames, lo + per)
 
 
+_RESULT_DTYPE = None
+
+
+def _as_struct_array(results, n_frames: int):
+    """ctypes array of ilcc_result -> numpy structured view (no copy); None for other sequences."""
+    try:
+        import ctypes
+        from . import _native as N
+        global _RESULT_DTYPE
+        if isinstance(results, ctypes.Array) and results._type_ is N.Result:
+            if _RESULT_DTYPE is None:
+                _RESULT_DTYPE = np.dtype(N.Result)
+            return np.frombuffer(results, dtype=_RESULT_DTYPE, count=n_frames)
+    except Exception:
+        pass
+    return None
+
+
 def pack_records(results: Sequence, n_frames: int, n_corners: Optional[int] = None) -> np.ndarray:
     """ilcc_result-like records -> [n_frames, record_floats] float32.
 
@@ -36,6 +54,19 @@ def pack_records(results: Sequence, n_frames: int, n_corners: Optional[int] = No
     if n_corners is None:
         n_corners = max([int(results[f].n_corners) for f in range(n_frames)] + [0])
     out = np.zeros((n_frames, record_floats(n_corners)), dtype=np.float32)
+    sa = _as_struct_array(results, n_frames)
+    if sa is not None:                      # vectorised: one numpy pass over the whole batch
+        for col, name in enumerate(("status", "n_corners", "phase", "grid_index", "iters_a", "iters_b", "cost_a",
+                                    "cost_b", "sel_cost")):
+            out[:, col] = sa[name]
+        out[:, 9:12] = sa["theta_t"]
+        out[:, 12] = sa["n_plane"]
+        out[:, 13] = sa["n_black"]
+        out[:, 14] = sa["n_white"]
+        out[:, HEADER_FLOATS:] = sa["corners"][:, :3 * n_corners]
+        ok = np.arange(3 * n_corners)[None, :] < 3 * np.minimum(sa["n_corners"], n_corners)[:, None]
+        out[:, HEADER_FLOATS:] *= ok
+        return out
     for f in range(n_frames):
         r = results[f]
         out[f, :15] = (r.status, r.n_corners, r.phase, r.grid_index, r.iters_a, r.iters_b, r.cost_a, r.cost_b,
@@ -54,19 +85,20 @@ def unpack_corners(records: np.ndarray) -> List[np.ndarray]:
     return out
 
 
-def gather_records(local, world: int, rank: int, dst: int = 0):
+def gather_records(local, world: int, rank: int, dst: int = 0, async_op: bool = False):
     """One ``torch.distributed.gather`` of this rank's [F_local, R] record tensor to ``dst``.
-    Every rank must pass the same shape (pad the last shard).  Returns [world*F_local, R] on dst."""
+    Every rank must pass the same shape (pad the last shard).  Returns [world*F_local, R] on dst
+    (None elsewhere); with ``async_op`` returns ``(work, bufs)`` so the caller can overlap the
+    collective with the next batch and ``work.wait()`` later."""
     import torch
     import torch.distributed as dist
     if world == 1:
-        return local
-    if rank == dst:
-        bufs = [torch.empty_like(local) for _ in range(world)]
-        dist.gather(local, gather_list=bufs, dst=dst)
-        return torch.cat(bufs, 0)
-    dist.gather(local, gather_list=None, dst=dst)
-    return None
+        return (None, [local]) if async_op else local
+    bufs = [torch.empty_like(local) for _ in range(world)] if rank == dst else None
+    work = dist.gather(local, gather_list=bufs, dst=dst, async_op=async_op)
+    if async_op:
+        return work, bufs
+    return torch.cat(bufs, 0) if rank == dst else None
 
 
 def run_sharded(extract_fn, clouds: np.ndarray, clicks: np.ndarray, world: int, rank: int, n_corners: int,
