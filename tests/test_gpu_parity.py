@@ -345,3 +345,59 @@ def test_config5_dense_64_ring_cloud(ob):
     assert np.abs(r.corners_array() - ob.result_corners(o)).max() < 1e-5
     assert synth.corner_error(r.corners_array(), synth.true_corners(pose, board), board) < 0.01
     e.close()
+
+
+def test_large_roi_takes_the_global_memory_paths(ob):
+    """ROI wider than the LDS union-find capacity (16 384 parents) and more labelled points than the
+    K6/K7 LDS stage: the global-memory variants of K2, K6 and K7a must give the oracle's result."""
+    board = synth.Board(9, 12, 0.10)
+    rng = np.random.default_rng(21)
+    pose = synth.random_pose(rng, range_m=(2.0, 2.3), yaw_deg=10, pitch_deg=8, roll_deg=20)
+    cloud = synth.make_frame(synth.hdl64(), board, pose, 5)
+    click = synth.make_click(pose, 5)
+    p = N.default_params()
+    p.board_w, p.board_h, p.grid_length = 9, 12, 0.10
+    p.roi_half[0], p.roi_half[1], p.roi_half[2] = 6.0, 6.0, 6.0      # keeps ~ every near point
+    p.n_th, p.n_ty, p.n_tz = 9, 8, 8
+    p.th_min, p.th_step = -0.04, 0.01
+    p.ty_min = p.tz_min = -0.04
+    p.ty_step = p.tz_step = 0.01
+    e = LidarCornersBatch(1, 131072, p)
+    r = e.extract(cloud[None], click[None])[0]
+    op = ob.default_params()
+    op.solver = ob.SOLVER_GRID
+    for k in ("board_w", "board_h", "grid_length", "n_th", "n_ty", "n_tz", "th_min", "th_step", "ty_min",
+              "ty_step", "tz_min", "tz_step"):
+        setattr(op, k, getattr(p, k))
+    for a in range(3):
+        op.roi_half[a] = 6.0
+    o = ob.extract(cloud, click, op)
+    assert r.n_roi > 16384, r.n_roi
+    assert (r.status, r.n_roi, r.n_cluster, r.n_plane) == (o.status, o.n_roi, o.n_cluster, o.n_plane)
+    assert r.status == 0 and r.grid_index == o.grid_index
+    assert np.abs(r.corners_array() - ob.result_corners(o)).max() < 1e-5
+    e.close()
+
+
+def test_cluster_size_gates_and_non_finite_points(ob, frames):
+    """EuclideanClusterExtraction's [min, max] size gate: when the click's component is inadmissible the
+    largest admissible one is taken (plane_index 0); NaN/inf points never reach the clustering."""
+    clouds, clicks, _ = frames
+    cloud = clouds[0].copy()
+    cloud[::97, 0] = np.nan
+    cloud[5::131, 2] = np.inf
+    for cmin, cmax in ((100, 25000), (100, 1500), (2500, 25000)):
+        p = N.default_params()
+        p.cluster_min, p.cluster_max = cmin, cmax
+        e = LidarCornersBatch(1, 28800, p)
+        r = e.extract(cloud[None], clicks[:1])[0]
+        op = ob.default_params()
+        op.solver = ob.SOLVER_GRID
+        op.cluster_min, op.cluster_max = cmin, cmax
+        o = ob.extract(cloud, clicks[0], op)
+        assert (r.status, r.n_roi, r.n_cluster, r.n_plane) == (o.status, o.n_roi, o.n_cluster, o.n_plane), (cmin, cmax)
+        roi = e.fetch_cloud(0, N.CLOUD_ROI)
+        assert np.isfinite(roi[:, :3]).all()
+        if o.status == 0:
+            assert np.abs(r.corners_array() - ob.result_corners(o)).max() < 1e-5
+        e.close()
