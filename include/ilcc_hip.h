@@ -49,7 +49,9 @@ enum {
   ILCC_BAD_ARGUMENT = 6,
   ILCC_CAPACITY = 7,        /* more frames / points than the handle was created for */
   ILCC_HIP_ERROR = 8,
-  ILCC_IO_ERROR = 9
+  ILCC_IO_ERROR = 9,
+  ILCC_BOARD_NOT_FOUND = 10 /* get_chessboard_by_point returned false (plane < 500 points or no cluster
+                               around the predicted centre), LidarCornersEst.cpp:111-112 */
 };
 
 /* how (theta, ty, tz) is found */
@@ -115,7 +117,8 @@ typedef struct ilcc_result {
   int32_t phase;               /* topleftWhite chosen (0/1) */
   int32_t iters_a, iters_b;
   int32_t grid_index;          /* ((k*n_ty+a)*n_tz+b)*2+phase of the grid argmin, -1 if unused */
-  int32_t reserved0;
+  int32_t found_board;         /* 1: the cluster holding the click's nearest point was admissible
+                                  (find_board of get_chessboard_by_point, LidarCornersEst.cpp:91-102) */
   float grid_cost;
   float plane[4];              /* refit plane nx,ny,nz,d of getPlane */
   float pca[16];               /* row-major 4x4 pca_matrix (lidar -> plane frame) */
@@ -177,6 +180,20 @@ int32_t ilcc_extract_batch_device(ilcc_handle* h, const float* d_xyzi, const uin
 int32_t ilcc_submit_batch_device(ilcc_handle* h, const float* d_xyzi, const uint64_t* offsets,
                                  uint32_t n_frames, const float* d_clicks, int32_t* ticket);
 int32_t ilcc_wait(ilcc_handle* h, int32_t ticket, ilcc_result* out);
+
+/* LidarCornersEst::get_chessboard_by_point (LidarCornersEst.cpp:72-115), the front half of the path as
+ * the online node uses it (ilcc2/test/lidar_chessboard_online.cpp:91-101): NO ROI crop, Euclidean
+ * clustering of the whole cloud with params.cluster_tol (the reference uses 0.10 here), the cluster
+ * around `points[f]`, getPlane, then get_gray_zone(rate = params.gray_rate) for colouring.
+ * status per frame: ILCC_OK (reference: true) or ILCC_BOARD_NOT_FOUND / another failure (false).
+ * The plane cloud (`outcloud`) is ILCC_CLOUD_CHESSBOARD; ilcc_fetch_classes gives the
+ * color_by_gray_zone class of each of its points.  Host buffers; batched like ilcc_extract_batch. */
+int32_t ilcc_chessboard_by_point_batch(ilcc_handle* h, const float* xyzi, const uint64_t* offsets,
+                                       uint32_t n_frames, const float* points, int32_t min_plane_points,
+                                       ilcc_result* out);
+/* color_by_gray_zone classes (LidarCornersEst.cpp:452-499) of the last batch's plane cloud:
+ * 0 black (I < gray_zone[0]), 1 gray, 2 white (I > gray_zone[1]).  Returns the point count. */
+int64_t ilcc_fetch_classes(ilcc_handle* h, uint32_t frame, uint8_t* out_class, uint64_t cap_points);
 
 /* copy one of the last completed batch's intermediate clouds of a frame (n x 4 float32) to the host.
  * returns the point count (<= cap_points written), or a negative status. */

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("ILCC_HIP_LIB") or os.path.join(_HERE, "libilcc_hip.so
 MAX_CORNERS = 256
 
 OK, NO_ROI_POINTS, NO_CLUSTER, NO_PLANE, DEGENERATE_HIST, TOO_FEW_POINTS, BAD_ARGUMENT, CAPACITY, \
-    HIP_ERROR, IO_ERROR = range(10)
+    HIP_ERROR, IO_ERROR, BOARD_NOT_FOUND = range(11)
 SOLVER_REFERENCE_LOCAL, SOLVER_GRID = 0, 1
 CLOUD_ROI, CLOUD_CLUSTER, CLOUD_CHESSBOARD, CLOUD_PCA, CLOUD_OPTIM = range(5)
 
@@ -24,7 +24,7 @@ CLOUD_ROI, CLOUD_CLUSTER, CLOUD_CHESSBOARD, CLOUD_PCA, CLOUD_OPTIM = range(5)
 EXPORTS = [
     "ilcc_abi_version", "ilcc_strerror", "ilcc_last_error", "ilcc_default_params",
     "ilcc_set_chessboard_param", "ilcc_create", "ilcc_destroy", "ilcc_set_params", "ilcc_extract",
-    "ilcc_extract_batch", "ilcc_extract_batch_device", "ilcc_submit_batch_device", "ilcc_wait", "ilcc_fetch_cloud", "ilcc_fetch_labelled",
+    "ilcc_extract_batch", "ilcc_extract_batch_device", "ilcc_submit_batch_device", "ilcc_wait", "ilcc_fetch_cloud", "ilcc_fetch_labelled", "ilcc_chessboard_by_point_batch", "ilcc_fetch_classes",
     "ilcc_grid_cost", "ilcc_get_theta_t", "ilcc_get_timing", "ilcc_reset_timing",
     "ilcc_save_corners2txt", "ilcc_read_lidar_corners",
 ]
@@ -66,7 +66,7 @@ class Result(C.Structure):
         ("phase", C.c_int32),
         ("iters_a", C.c_int32), ("iters_b", C.c_int32),
         ("grid_index", C.c_int32),
-        ("reserved0", C.c_int32),
+        ("found_board", C.c_int32),
         ("grid_cost", C.c_float),
         ("plane", C.c_float * 4),
         ("pca", C.c_float * 16),
@@ -129,6 +129,10 @@ def lib():
         L.ilcc_submit_batch_device.restype = C.c_int32
         L.ilcc_wait.argtypes = [vp, C.c_int32, rp]
         L.ilcc_wait.restype = C.c_int32
+        L.ilcc_chessboard_by_point_batch.argtypes = [vp, fp, C.POINTER(C.c_uint64), C.c_uint32, fp, C.c_int32, rp]
+        L.ilcc_chessboard_by_point_batch.restype = C.c_int32
+        L.ilcc_fetch_classes.argtypes = [vp, C.c_uint32, C.POINTER(C.c_uint8), C.c_uint64]
+        L.ilcc_fetch_classes.restype = C.c_int64
         L.ilcc_fetch_cloud.argtypes = [vp, C.c_uint32, C.c_int32, fp, C.c_uint64]
         L.ilcc_fetch_cloud.restype = C.c_int64
         L.ilcc_fetch_labelled.argtypes = [vp, C.c_uint32, fp, C.POINTER(C.c_uint8), C.c_uint64]

@@ -31,8 +31,9 @@ struct Slot {
   ilcc_result* d_res = nullptr;
   float4 *d_roi = nullptr, *d_cluster = nullptr, *d_board = nullptr, *d_pca = nullptr, *d_optim = nullptr;
   float2* d_yz = nullptr;
-  uint8_t* d_lab = nullptr;
+  uint8_t *d_lab = nullptr, *d_cls = nullptr;
   uint32_t *d_nlab = nullptr, *d_counts = nullptr, *d_parent = nullptr, *d_count = nullptr;
+  uint32_t *d_hash_head = nullptr, *d_hash_next = nullptr;
   GridPartial *d_partial = nullptr, *d_partial2 = nullptr;
   SolveRec* d_solverec = nullptr;
   uint32_t* d_bound = nullptr;
@@ -164,7 +165,7 @@ int32_t upload_tables(ilcc_handle* h) {
 
 void free_slot(Slot& sl) {
   void* bufs[] = {sl.d_xyzi, sl.d_clicks, sl.d_off, sl.d_res, sl.d_roi, sl.d_cluster, sl.d_board, sl.d_pca, sl.d_optim,
-                  sl.d_yz, sl.d_lab, sl.d_nlab, sl.d_counts, sl.d_parent, sl.d_count, sl.d_partial, sl.d_partial2,
+                  sl.d_yz, sl.d_lab, sl.d_cls, sl.d_nlab, sl.d_counts, sl.d_parent, sl.d_count, sl.d_hash_head, sl.d_hash_next, sl.d_partial, sl.d_partial2,
                   sl.d_solverec, sl.d_bound, sl.d_iters};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -196,10 +197,13 @@ int32_t alloc_slot(ilcc_handle* h, Slot& sl) {
   ALLOC(sl.d_optim, sizeof(float4) * np);
   ALLOC(sl.d_yz, sizeof(float2) * np);
   ALLOC(sl.d_lab, np);
+  ALLOC(sl.d_cls, np);
   ALLOC(sl.d_nlab, sizeof(uint32_t) * mf);
   ALLOC(sl.d_counts, sizeof(uint32_t) * h->crop_chunks_cap);
   ALLOC(sl.d_parent, sizeof(uint32_t) * np);
   ALLOC(sl.d_count, sizeof(uint32_t) * np);
+  ALLOC(sl.d_hash_head, sizeof(uint32_t) * (size_t)mf * kClusterHashSize);
+  ALLOC(sl.d_hash_next, sizeof(uint32_t) * np);
   ALLOC(sl.d_partial, sizeof(GridPartial) * (size_t)mf * h->max_theta);
   ALLOC(sl.d_partial2, sizeof(GridPartial) * (size_t)mf * h->max_theta);
   ALLOC(sl.d_solverec, sizeof(SolveRec) * 2 * (size_t)mf);
@@ -228,10 +232,13 @@ Ctx make_ctx(ilcc_handle* h, Slot& sl, const float4* d_xyzi, const float* d_clic
   c.optim = sl.d_optim;
   c.yz = sl.d_yz;
   c.lab = sl.d_lab;
+  c.cls = sl.d_cls;
   c.n_lab = sl.d_nlab;
   c.crop_counts = sl.d_counts;
   c.uf_parent = sl.d_parent;
   c.uf_count = sl.d_count;
+  c.uf_hash_head = sl.d_hash_head;
+  c.uf_hash_next = sl.d_hash_next;
   c.partial = sl.d_partial;
   c.solve_rec = sl.d_solverec;
   c.grid_blocks = (uint32_t)h->p.n_th;
@@ -280,7 +287,7 @@ int32_t check_offsets(ilcc_handle* h, const uint64_t* offsets, uint32_t n_frames
 
 // enqueue the whole path for one batch on the slot's stream (no host synchronisation)
 int32_t enqueue(ilcc_handle* h, int si, const float4* d_xyzi, const uint64_t* offsets, uint32_t n_frames,
-                const float* d_clicks) {
+                const float* d_clicks, bool front_only = false, bool no_crop = false) {
   Slot& sl = h->slots[si];
   uint64_t max_n = 0;
   for (uint32_t f = 0; f < n_frames; ++f) max_n = std::max<uint64_t>(max_n, offsets[f + 1] - offsets[f]);
@@ -296,7 +303,9 @@ int32_t enqueue(ilcc_handle* h, int si, const float4* d_xyzi, const uint64_t* of
   HIP_TRY(h, hipMemcpyAsync(sl.d_off, sl.off.data(), sizeof(uint64_t) * (n_frames + 1), hipMemcpyHostToDevice, s));
   HIP_TRY(h, hipMemsetAsync(sl.d_count, 0, sizeof(uint32_t) * offsets[n_frames], s));
   HIP_TRY(h, hipMemsetAsync(sl.d_res, 0, sizeof(ilcc_result) * n_frames, s));   // no stale fields in failed frames
-  const Ctx c = make_ctx(h, sl, d_xyzi, d_clicks, n_frames, chunks);
+  Ctx c = make_ctx(h, sl, d_xyzi, d_clicks, n_frames, chunks);
+  if (no_crop)   // get_chessboard_by_point clusters the whole cloud: an unbounded box only drops non-finite points
+    c.p.roi_half[0] = c.p.roi_half[1] = c.p.roi_half[2] = (double)INFINITY;
 
   HIP_TRY(h, hipEventRecord(sl.ev[0], s));
   launch_roi_crop(c, s);
@@ -306,7 +315,7 @@ int32_t enqueue(ilcc_handle* h, int si, const float4* d_xyzi, const uint64_t* of
   launch_ransac_plane(c, s);
   HIP_TRY(h, hipEventRecord(sl.ev[3], s));
   launch_plane_frame_hist(c, s);
-  sl.grid = h->p.solver == ILCC_SOLVER_GRID;
+  sl.grid = !front_only && h->p.solver == ILCC_SOLVER_GRID;
   if (sl.grid) {
     HIP_TRY(h, hipMemsetAsync(sl.d_iters, 0, sizeof(unsigned long long) * kIterSlots, s));
     // K6 launches of different slots are chained so that they never share the chip: the small
@@ -343,7 +352,7 @@ int32_t enqueue(ilcc_handle* h, int si, const float4* d_xyzi, const uint64_t* of
     h->k6_last = si;
   }
   HIP_TRY(h, hipEventRecord(sl.ev[5], s));
-  launch_refine_corners(c, s);
+  if (!front_only) launch_refine_corners(c, s);
   HIP_TRY(h, hipEventRecord(sl.ev[6], s));
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipMemcpyAsync(sl.h_res, sl.d_res, sizeof(ilcc_result) * n_frames, hipMemcpyDeviceToHost, s));
@@ -414,6 +423,7 @@ const char* ilcc_strerror(int32_t status) {
     case ILCC_CAPACITY: return "handle capacity exceeded";
     case ILCC_HIP_ERROR: return "HIP runtime error";
     case ILCC_IO_ERROR: return "file I/O error";
+    case ILCC_BOARD_NOT_FOUND: return "no chessboard plane of sufficient size around the given point";
     default: return "unknown status";
   }
 }
@@ -658,6 +668,46 @@ int32_t ilcc_extract(ilcc_handle* h, const float* xyzi, uint32_t n, const float 
   return ilcc_extract_batch(h, xyzi, off, 1, click, out);
 }
 
+int32_t ilcc_chessboard_by_point_batch(ilcc_handle* h, const float* xyzi, const uint64_t* offsets, uint32_t n_frames,
+                                       const float* points, int32_t min_plane_points, ilcc_result* out) {
+  if (!h || !xyzi || !points || !out) return ILCC_BAD_ARGUMENT;
+  HIP_TRY(h, hipSetDevice(h->device));
+  int32_t st = check_offsets(h, offsets, n_frames);
+  if (st != ILCC_OK) return st;
+  Slot& sl = h->slots[0];
+  if (sl.busy) {
+    h->err = "synchronous call while ticket 0 is in flight";
+    return ILCC_BAD_ARGUMENT;
+  }
+  if (offsets[n_frames] > 0)
+    HIP_TRY(h, hipMemcpyAsync(sl.d_xyzi, xyzi, sizeof(float4) * offsets[n_frames], hipMemcpyHostToDevice, sl.stream));
+  HIP_TRY(h, hipMemcpyAsync(sl.d_clicks, points, sizeof(float) * 3 * n_frames, hipMemcpyHostToDevice, sl.stream));
+  st = enqueue(h, 0, sl.d_xyzi, offsets, n_frames, sl.d_clicks, /*front_only=*/true, /*no_crop=*/true);
+  if (st != ILCC_OK) return st;
+  st = finish(h, 0, out);
+  if (st != ILCC_OK) return st;
+  // `if(outcloud->size() < 500 || find_board == false) return false;` (LidarCornersEst.cpp:111-112)
+  for (uint32_t f = 0; f < n_frames; ++f)
+    if (out[f].status == ILCC_OK && (out[f].n_plane < min_plane_points || !out[f].found_board)) {
+      out[f].status = ILCC_BOARD_NOT_FOUND;
+      sl.h_res[f].status = ILCC_BOARD_NOT_FOUND;
+    }
+  return ILCC_OK;
+}
+
+int64_t ilcc_fetch_classes(ilcc_handle* h, uint32_t frame, uint8_t* out_class, uint64_t cap_points) {
+  if (!h || h->last_slot < 0) return -(int64_t)ILCC_BAD_ARGUMENT;
+  Slot& sl = h->slots[h->last_slot];
+  if (sl.busy || frame >= sl.n_frames) return -(int64_t)ILCC_BAD_ARGUMENT;
+  const ilcc_result& r = sl.h_res[frame];
+  const int64_t n = (r.status == ILCC_OK || r.status == ILCC_BOARD_NOT_FOUND) ? r.n_plane : 0;
+  const int64_t m = std::min<int64_t>(n, (int64_t)cap_points);
+  if (m > 0 && out_class &&
+      hipMemcpy(out_class, sl.d_cls + sl.off[frame], (size_t)m, hipMemcpyDeviceToHost) != hipSuccess)
+    return -(int64_t)ILCC_HIP_ERROR;
+  return n;
+}
+
 int64_t ilcc_fetch_cloud(ilcc_handle* h, uint32_t frame, int32_t which, float* out_xyzi, uint64_t cap_points) {
   if (!h || h->last_slot < 0) return -(int64_t)ILCC_BAD_ARGUMENT;
   Slot& sl = h->slots[h->last_slot];
@@ -668,8 +718,11 @@ int64_t ilcc_fetch_cloud(ilcc_handle* h, uint32_t frame, int32_t which, float* o
   switch (which) {
     case ILCC_CLOUD_ROI: src = sl.d_roi; n = r.n_roi; break;
     case ILCC_CLOUD_CLUSTER: src = sl.d_cluster; n = r.n_cluster; break;
-    case ILCC_CLOUD_CHESSBOARD: src = sl.d_board; n = r.n_plane; break;
-    case ILCC_CLOUD_PCA: src = sl.d_pca; n = (r.status == ILCC_OK || r.status == ILCC_DEGENERATE_HIST) ? r.n_plane : 0; break;
+    case ILCC_CLOUD_CHESSBOARD: src = sl.d_board; n = r.n_plane; break;   // also after ILCC_BOARD_NOT_FOUND
+    case ILCC_CLOUD_PCA:
+      src = sl.d_pca;
+      n = (r.status == ILCC_OK || r.status == ILCC_DEGENERATE_HIST || r.status == ILCC_BOARD_NOT_FOUND) ? r.n_plane : 0;
+      break;
     case ILCC_CLOUD_OPTIM: src = sl.d_optim; n = (r.status == ILCC_OK) ? r.n_plane : 0; break;
     default: return -(int64_t)ILCC_BAD_ARGUMENT;
   }

@@ -24,6 +24,8 @@ constexpr int kTileB = ILCC_TILE_B;    // K6 candidate tile: tz values per wavef
 constexpr int kGridLdsPointsMax = 16384;  // K6 LDS staging upper bound (9 B per point -> 144 KiB)
 constexpr int kSolveThreads = 256;     // K7: 4 wavefronts per frame
 constexpr int kIterSlots = 64;         // K6 executed-iteration counters (spread to avoid one hot atomic)
+constexpr int kClusterAllPairsMax = 4096;   // K2: above this many points the spatial hash finds neighbours
+constexpr int kClusterHashSize = 1 << 17;    // K2: hash buckets per frame (global memory)
 constexpr int kClusterLdsParents = 16384;  // K2 union-find parents kept in LDS (64 KiB)
 
 struct GridPartial {   // per K6 workgroup best candidate
@@ -58,9 +60,12 @@ struct Ctx {
   float2* yz;                // labelled (non-gray) points, plane-frame y,z
   uint8_t* lab;              // 0 black, 1 white
   uint32_t* n_lab;           // per frame
+  uint8_t* cls;              // color_by_gray_zone class of every plane point: 0 black, 1 gray, 2 white
   uint32_t* crop_counts;     // n_frames x crop_chunks
   uint32_t* uf_parent;       // K2 scratch (global fallback / labels)
   uint32_t* uf_count;        // K2 component sizes
+  uint32_t* uf_hash_head;    // K2 spatial hash: n_frames x kClusterHashSize bucket heads
+  uint32_t* uf_hash_next;    // K2 spatial hash: chain links, one per point
   GridPartial* partial;      // n_frames x grid_blocks
   SolveRec* solve_rec;       // n_frames x 2
   uint32_t grid_blocks;      // K6 workgroups per frame

@@ -7,7 +7,10 @@
 // global scratch array); neighbours are found by tiled all-pairs: 1024 "j" points staged in
 // LDS per tile, every lane holds its own "i" point in registers, LDS reads are wave-uniform
 // (broadcast).  Roots are always the smallest member index, so the labelling is
-// deterministic.  Cluster choice follows the reference: components with
+// deterministic.  Above 4096 points the neighbour search switches from all-pairs to a spatial
+// hash (cell = tolerance, 27 cells per point, chained buckets in global memory), which is what
+// un-cropped clouds (the online caller get_chessboard_by_point, LidarCornersEst.cpp:72-115) need.
+// Cluster choice follows the reference: components with
 // cluster_min <= size <= cluster_max, sorted by size (largest = index 0); the one containing
 // the exact 1-NN of the click wins, otherwise index 0.  Members are emitted in index order.
 #include "ilcc_internal.h"
@@ -45,6 +48,13 @@ __device__ __forceinline__ void uf_unite(P* parent, uint32_t a, uint32_t b) {
   }
 }
 
+// bucket of an integer cell; different cells may share a bucket (a far cell's points then simply
+// fail the distance test)
+__device__ __forceinline__ uint32_t cell_hash(int cx, int cy, int cz) {
+  const uint32_t h = (uint32_t)cx * 73856093u ^ (uint32_t)cy * 19349663u ^ (uint32_t)cz * 83492791u;
+  return h & (uint32_t)(kClusterHashSize - 1);
+}
+
 struct NnKey {
   float d2;
   uint32_t idx;
@@ -70,39 +80,111 @@ __device__ void cluster_frame(const Ctx& c, uint32_t f, uint32_t* lds_parent, fl
   for (uint32_t i = tid; i < M; i += kFrameThreads) parent[i] = i;
   __syncthreads();
 
-  // ---- all pairs (j < i), tiles of 1024
-  for (uint32_t ic = 0; ic < M; ic += kFrameThreads) {
-    const uint32_t i = ic + tid;
-    const bool vi = i < M;
-    const float4 pi = vi ? P[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-    for (uint32_t jc = 0; jc <= ic; jc += kFrameThreads) {
-      __syncthreads();
-      if (jc + tid < M) tile[tid] = P[jc + tid];
-      __syncthreads();
-      uint32_t lim = (M - jc < (uint32_t)kFrameThreads) ? M - jc : (uint32_t)kFrameThreads;
-      if (jc == ic) lim = (tid < lim) ? tid : lim;   // only j < i inside the diagonal tile
-      if (!vi) lim = 0;
-      // wave-uniform upper bound so that LDS reads stay broadcast; lanes mask themselves out
-      uint32_t wlim = lim;
+  if (M > (uint32_t)kClusterAllPairsMax) {
+    // ---- spatial hash: cells of (slightly more than) the tolerance, buckets chained through
+    // `next`; every point tests the 27 cells around its own.  Bucket order depends on the race of
+    // the insertions, the resulting partition does not.
+    float3 lo = make_float3(3.0e38f, 3.0e38f, 3.0e38f);
+    for (uint32_t i = tid; i < M; i += kFrameThreads) {
+      const float4 q = P[i];
+      lo.x = fminf(lo.x, q.x);
+      lo.y = fminf(lo.y, q.y);
+      lo.z = fminf(lo.z, q.z);
+    }
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        const uint32_t t = __shfl_xor(wlim, o, ILCC_WAVE);
-        wlim = t > wlim ? t : wlim;
-      }
-      for (uint32_t jj = 0; jj < wlim; ++jj) {
-        const float4 q = tile[jj];
-        const float dx = q.x - pi.x, dy = q.y - pi.y, dz = q.z - pi.z;
-        float d2 = dx * dx;
-        d2 = d2 + dy * dy;
-        d2 = d2 + dz * dz;
-        if (jj < lim && d2 < tol2) {
-          // most neighbours already share a parent after the first few hooks: skip the find loops
-          const uint32_t qi = __hip_atomic_load(&parent[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const uint32_t qj = __hip_atomic_load(&parent[jc + jj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (qi != qj) uf_unite(parent, i, jc + jj);
+    for (int o = 32; o > 0; o >>= 1) {
+      lo.x = fminf(lo.x, __shfl_xor(lo.x, o, ILCC_WAVE));
+      lo.y = fminf(lo.y, __shfl_xor(lo.y, o, ILCC_WAVE));
+      lo.z = fminf(lo.z, __shfl_xor(lo.z, o, ILCC_WAVE));
+    }
+    float* scf = reinterpret_cast<float*>(sc);
+    __syncthreads();
+    if (lane_id() == 0) {
+      scf[wave_id()] = lo.x;
+      scf[16 + wave_id()] = lo.y;
+      scf[32 + wave_id()] = lo.z;
+    }
+    __syncthreads();
+    for (int w = 0; w < kFrameThreads / ILCC_WAVE; ++w) {
+      lo.x = fminf(lo.x, scf[w]);
+      lo.y = fminf(lo.y, scf[16 + w]);
+      lo.z = fminf(lo.z, scf[32 + w]);
+    }
+    __syncthreads();
+    const float inv_cell = 1.0f / ((float)c.p.cluster_tol * 1.001f);
+    uint32_t* head = c.uf_hash_head + (uint64_t)f * kClusterHashSize;
+    uint32_t* next = c.uf_hash_next + beg;
+    for (uint32_t k = tid; k < (uint32_t)kClusterHashSize; k += kFrameThreads) head[k] = 0xFFFFFFFFu;
+    __syncthreads();
+    for (uint32_t i = tid; i < M; i += kFrameThreads) {
+      const float4 q = P[i];
+      const int cx = (int)floorf((q.x - lo.x) * inv_cell), cy = (int)floorf((q.y - lo.y) * inv_cell),
+                cz = (int)floorf((q.z - lo.z) * inv_cell);
+      next[i] = atomicExch(&head[cell_hash(cx, cy, cz)], i);
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < M; i += kFrameThreads) {
+      const float4 pi = P[i];
+      const int cx = (int)floorf((pi.x - lo.x) * inv_cell), cy = (int)floorf((pi.y - lo.y) * inv_cell),
+                cz = (int)floorf((pi.z - lo.z) * inv_cell);
+      for (int dz = -1; dz <= 1; ++dz)
+        for (int dy = -1; dy <= 1; ++dy)
+          for (int dx = -1; dx <= 1; ++dx) {
+            const int nx = cx + dx, ny = cy + dy, nz = cz + dz;
+            uint32_t j = __hip_atomic_load(&head[cell_hash(nx, ny, nz)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            while (j != 0xFFFFFFFFu) {
+              if (j < i) {   // each pair once
+                const float4 q = P[j];
+                const float ex = q.x - pi.x, ey = q.y - pi.y, ez = q.z - pi.z;
+                float d2 = ex * ex;
+                d2 = d2 + ey * ey;
+                d2 = d2 + ez * ez;
+                if (d2 < tol2) {
+                  const uint32_t qi = __hip_atomic_load(&parent[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                  const uint32_t qj = __hip_atomic_load(&parent[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                  if (qi != qj) uf_unite(parent, i, j);
+                }
+              }
+              j = next[j];
+            }
+          }
+    }
+  } else {
+  // ---- all pairs (j < i), tiles of 1024
+    for (uint32_t ic = 0; ic < M; ic += kFrameThreads) {
+      const uint32_t i = ic + tid;
+      const bool vi = i < M;
+      const float4 pi = vi ? P[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (uint32_t jc = 0; jc <= ic; jc += kFrameThreads) {
+        __syncthreads();
+        if (jc + tid < M) tile[tid] = P[jc + tid];
+        __syncthreads();
+        uint32_t lim = (M - jc < (uint32_t)kFrameThreads) ? M - jc : (uint32_t)kFrameThreads;
+        if (jc == ic) lim = (tid < lim) ? tid : lim;   // only j < i inside the diagonal tile
+        if (!vi) lim = 0;
+        // wave-uniform upper bound so that LDS reads stay broadcast; lanes mask themselves out
+        uint32_t wlim = lim;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+          const uint32_t t = __shfl_xor(wlim, o, ILCC_WAVE);
+          wlim = t > wlim ? t : wlim;
+        }
+        for (uint32_t jj = 0; jj < wlim; ++jj) {
+          const float4 q = tile[jj];
+          const float dx = q.x - pi.x, dy = q.y - pi.y, dz = q.z - pi.z;
+          float d2 = dx * dx;
+          d2 = d2 + dy * dy;
+          d2 = d2 + dz * dz;
+          if (jj < lim && d2 < tol2) {
+            // most neighbours already share a parent after the first few hooks: skip the find loops
+            const uint32_t qi = __hip_atomic_load(&parent[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t qj = __hip_atomic_load(&parent[jc + jj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (qi != qj) uf_unite(parent, i, jc + jj);
+          }
         }
       }
     }
+    __syncthreads();
   }
   __syncthreads();
 
@@ -210,7 +292,9 @@ __device__ void cluster_frame(const Ctx& c, uint32_t f, uint32_t* lds_parent, fl
     }
     const uint32_t nsz = __hip_atomic_load(&count[nn_label], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     uint32_t chosen = r0;                                   // plane_index = 0
-    if (nsz >= cmin && nsz <= cmax) chosen = nn_label;      // cluster containing the click's NN
+    const bool found = nsz >= cmin && nsz <= cmax;          // find_board of get_chessboard_by_point (:91-102)
+    if (found) chosen = nn_label;                           // cluster containing the click's NN
+    r->found_board = found ? 1 : 0;
     sc[33] = chosen;
     sc[34] = (s0 == 0) ? 0u : 1u;
   }

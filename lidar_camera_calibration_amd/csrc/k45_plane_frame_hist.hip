@@ -205,6 +205,7 @@ __global__ __launch_bounds__(kFrameThreads) void k45_plane_frame_hist(Ctx c) {
   const double gz0 = s_gz[0], gz1 = s_gz[1];
   float2* __restrict__ YZ = c.yz + beg;
   uint8_t* __restrict__ LB = c.lab + beg;
+  uint8_t* __restrict__ CL = c.cls + beg;
   uint32_t running = 0, nb = 0, nw = 0;
   for (uint32_t base = 0; base < M; base += kFrameThreads) {
     const uint32_t i = base + tid;
@@ -220,6 +221,7 @@ __global__ __launch_bounds__(kFrameThreads) void k45_plane_frame_hist(Ctx c) {
         keep = true;
         l = 1;
       }
+      CL[i] = keep ? (uint8_t)(2 * l) : (uint8_t)1;   // color_by_gray_zone thresholds (:465-485)
     }
     uint32_t tot, totw;
     const uint32_t rank = block_rank(keep, sc, tot);

@@ -122,6 +122,39 @@ class LidarCornersEst:
         self._lib.ilcc_fetch_cloud(self._h, 0, which, N.fptr(out), n)
         return out[:n]
 
+    def get_chessboard_by_point(self, incloud: np.ndarray, point: Sequence[float], min_plane_points: int = 500):
+        """LidarCornersEst.cpp:72-115 as the online node calls it (lidar_chessboard_online.cpp:91):
+        whole-cloud clustering with ``params.cluster_tol`` (the reference hard-codes 0.10 there),
+        the cluster around ``point``, its plane.  Returns ``(ok, outcloud)`` like the reference's
+        ``bool`` + ``outcloud`` reference argument."""
+        cloud = np.ascontiguousarray(incloud, dtype=np.float32)
+        pt = np.ascontiguousarray(point, dtype=np.float32).reshape(3)
+        off = np.array([0, len(cloud)], dtype=np.uint64)
+        res = (N.Result * 1)()
+        st = self._lib.ilcc_chessboard_by_point_batch(self._handle(), N.fptr(cloud),
+                                                      off.ctypes.data_as(C.POINTER(C.c_uint64)), 1, N.fptr(pt),
+                                                      int(min_plane_points), res)
+        self._check(st)
+        self._result = res[0]
+        out = self._fetch(N.CLOUD_CHESSBOARD) if res[0].status in (N.OK, N.BOARD_NOT_FOUND) else np.zeros((0, 4), np.float32)
+        return res[0].status == N.OK, out
+
+    def get_gray_zone(self, cloud=None, rate: Optional[float] = None) -> np.ndarray:
+        """LidarCornersEst.cpp:303-328 on the plane cloud of the last call (computed on the device
+        with ``params.gray_rate``)."""
+        return np.array(self._result.gray_zone)
+
+    def color_by_gray_zone(self) -> np.ndarray:
+        """LidarCornersEst.cpp:452-499: n x 3 uint8 RGB of the last plane cloud (black 10,10,10 /
+        gray 255,0,0 / white 255,255,255), from the device-side classification."""
+        n = self._lib.ilcc_fetch_classes(self._h, 0, None, 0)
+        if n < 0:
+            raise IlccError(-n)
+        cl = np.zeros(max(n, 1), dtype=np.uint8)
+        self._lib.ilcc_fetch_classes(self._h, 0, cl.ctypes.data_as(C.POINTER(C.c_uint8)), n)
+        lut = np.array([[10, 10, 10], [255, 0, 0], [255, 255, 255]], dtype=np.uint8)
+        return lut[cl[:n]]
+
     def EuclideanCluster(self) -> bool:
         """LidarCornersEst.cpp:124-186.  False when no board plane is found (the reference returns
         False on key 'r' and throws when there is no cluster at all)."""
@@ -243,6 +276,31 @@ class LidarCornersBatch:
         out = np.zeros((max(n, 1), 4), dtype=np.float32)
         self._lib.ilcc_fetch_cloud(self._h, frame, which, N.fptr(out), n)
         return out[:n]
+
+    def chessboard_by_point(self, clouds: np.ndarray, points: np.ndarray, min_plane_points: int = 500,
+                            offsets: Optional[np.ndarray] = None):
+        """Batched ``get_chessboard_by_point`` (host buffers)."""
+        clouds = np.ascontiguousarray(clouds, dtype=np.float32)
+        points = np.ascontiguousarray(points, dtype=np.float32).reshape(-1, 3)
+        f = len(points)
+        if offsets is None:
+            offsets = np.arange(f + 1, dtype=np.uint64) * np.uint64(clouds.shape[-2])
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        res = (N.Result * f)()
+        st = self._lib.ilcc_chessboard_by_point_batch(self._h, N.fptr(clouds),
+                                                      offsets.ctypes.data_as(C.POINTER(C.c_uint64)), f,
+                                                      N.fptr(points), int(min_plane_points), res)
+        if st != N.OK:
+            raise IlccError(st, self._err())
+        return res
+
+    def fetch_classes(self, frame: int) -> np.ndarray:
+        n = self._lib.ilcc_fetch_classes(self._h, frame, None, 0)
+        if n < 0:
+            raise IlccError(-n)
+        cl = np.zeros(max(n, 1), dtype=np.uint8)
+        self._lib.ilcc_fetch_classes(self._h, frame, cl.ctypes.data_as(C.POINTER(C.c_uint8)), n)
+        return cl[:n]
 
     def fetch_labelled(self, frame: int):
         n = self._lib.ilcc_fetch_labelled(self._h, frame, None, None, 0)

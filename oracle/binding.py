@@ -109,6 +109,9 @@ def lib():
         L.orc_corners.restype = C.c_int32
         L.orc_extract.argtypes = [fp, C.c_int32, fp, pp, C.POINTER(Result), fp, fp]
         L.orc_extract.restype = C.c_int32
+        L.orc_chessboard_by_point.argtypes = [fp, C.c_int32, fp, pp, C.c_int32, C.POINTER(Result), fp,
+                                              C.POINTER(C.c_uint8)]
+        L.orc_chessboard_by_point.restype = C.c_int32
         L.orc_format_float.argtypes = [C.c_float, C.c_char_p, C.c_int32]
         L.orc_format_float.restype = C.c_int32
         _lib = L
@@ -239,6 +242,18 @@ def extract(xyzi, click, p, want_clouds=False):
     if want_clouds:
         return res, cb[:res.n_plane].copy(), pc[:res.n_plane].copy()
     return res
+
+
+def chessboard_by_point(xyzi, point, p, min_plane=500):
+    """get_chessboard_by_point + colouring classes -> (Result, plane cloud, classes)"""
+    x, xp = _f(xyzi)
+    c, cp = _f(point)
+    res = Result()
+    cb = np.zeros((len(x), 4), dtype=np.float32)
+    cl = np.zeros(len(x), dtype=np.uint8)
+    lib().orc_chessboard_by_point(xp, len(x), cp, C.byref(p), int(min_plane), C.byref(res),
+                                  cb.ctypes.data_as(C.POINTER(C.c_float)), cl.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return res, cb[:res.n_plane].copy(), cl[:res.n_plane].copy()
 
 
 def result_corners(res: Result) -> np.ndarray:

@@ -124,6 +124,14 @@ static int32_t lower_bound_cell(const cell_ent* e, int32_t m, uint64_t key) {
 
 int32_t orc_cluster(const float* roi, int32_t m, const float click[3], const orc_params* p,
                     int32_t* out_idx, int32_t* labels_out) {
+  return orc_cluster2(roi, m, click, p, out_idx, labels_out, NULL);
+}
+
+/* found_out: 1 when the cluster holding the click's nearest point is admissible (find_board of
+ * get_chessboard_by_point, LidarCornersEst.cpp:91-102) */
+int32_t orc_cluster2(const float* roi, int32_t m, const float click[3], const orc_params* p,
+                     int32_t* out_idx, int32_t* labels_out, int32_t* found_out) {
+  if (found_out) *found_out = 0;
   if (m <= 0) return 0;
   const float tol2 = (float)(p->cluster_tol * p->cluster_tol);
   const double cell = p->cluster_tol;
@@ -212,7 +220,10 @@ int32_t orc_cluster(const float* roi, int32_t m, const float click[3], const orc
       if (cl_size[c] > cl_size[largest]) largest = c;
     chosen = cl_id[largest]; /* plane_index = 0 default */
     for (int32_t c = 0; c < n_clusters; ++c)
-      if (cl_id[c] == label[nn]) chosen = cl_id[c]; /* cluster containing the NN of the click */
+      if (cl_id[c] == label[nn]) {
+        chosen = cl_id[c]; /* cluster containing the NN of the click */
+        if (found_out) *found_out = 1;
+      }
   }
 
   int32_t k = 0;
@@ -1319,6 +1330,71 @@ int32_t orc_extract(const float* xyzi, int32_t n, const float click[3], const or
 
 done:
   out->status = status;
+  free(idx);
+  free(a);
+  free(b);
+  return status;
+}
+
+/* ------------------------------------------------------------------------- */
+/* f2  get_chessboard_by_point (LidarCornersEst.cpp:72-115) + colouring        */
+/* ------------------------------------------------------------------------- */
+/* No ROI crop: the whole (finite) cloud is clustered with p->cluster_tol (the reference hard-codes
+ * 0.10 here), the cluster around `point` goes through getPlane; false (ORC_BOARD_NOT_FOUND) when the
+ * plane has fewer than min_plane points or no admissible cluster holds the nearest point.  The
+ * online node then colours the plane by gray zone (lidar_chessboard_online.cpp:98-99,
+ * LidarCornersEst.cpp:452-499): classes 0 black / 1 gray / 2 white. */
+int32_t orc_chessboard_by_point(const float* xyzi, int32_t n, const float point[3], const orc_params* p,
+                                int32_t min_plane, orc_result* out, float* cloud_chessboard,
+                                uint8_t* classes) {
+  memset(out, 0, sizeof(*out));
+  out->grid_index = -1;
+  if (n <= 0) {
+    out->status = ORC_NO_ROI_POINTS;
+    return out->status;
+  }
+  orc_params q = *p;
+  q.roi_half[0] = q.roi_half[1] = q.roi_half[2] = (double)INFINITY;
+  int32_t* idx = (int32_t*)malloc(sizeof(int32_t) * (size_t)n);
+  float* a = (float*)malloc(sizeof(float) * 4 * (size_t)n);
+  float* b = (float*)malloc(sizeof(float) * 4 * (size_t)n);
+  int32_t status = ORC_OK, found = 0;
+  const int32_t m_all = orc_roi_crop(xyzi, n, point, &q, idx); /* drops non-finite points only */
+  out->n_roi = m_all;
+  if (m_all == 0) { status = ORC_NO_ROI_POINTS; goto done; }
+  for (int32_t i = 0; i < m_all; ++i) memcpy(a + 4 * i, xyzi + 4 * idx[i], 16);
+  const int32_t m_clu = orc_cluster2(a, m_all, point, &q, idx, NULL, &found);
+  out->n_cluster = m_clu;
+  if (m_clu == 0) { status = ORC_NO_CLUSTER; goto done; }
+  for (int32_t i = 0; i < m_clu; ++i) memcpy(b + 4 * i, a + 4 * idx[i], 16);
+  const int32_t m_pl = orc_ransac_plane(b, m_clu, &q, idx, NULL);
+  out->n_plane = m_pl;
+  if (m_pl < 3) { status = ORC_NO_PLANE; goto done; }
+  for (int32_t i = 0; i < m_pl; ++i) memcpy(a + 4 * i, b + 4 * idx[i], 16);
+  if (cloud_chessboard) memcpy(cloud_chessboard, a, sizeof(float) * 4 * (size_t)m_pl);
+  status = orc_plane_frame(a, m_pl, &q, out->pca, NULL);
+  if (status != ORC_OK) goto done;
+  {
+    float* inten = (float*)malloc(sizeof(float) * (size_t)m_pl);
+    for (int32_t i = 0; i < m_pl; ++i) inten[i] = a[4 * i + 3];
+    double rlrh[2];
+    status = orc_gray_zone(inten, m_pl, &q, rlrh, out->gray_zone);
+    if (status == ORC_OK)
+      for (int32_t i = 0; i < m_pl; ++i) {
+        const double v = (double)inten[i];
+        const uint8_t cl = (v < out->gray_zone[0]) ? 0 : ((v > out->gray_zone[1]) ? 2 : 1);
+        if (classes) classes[i] = cl;
+        if (cl == 0) out->n_black++;
+        else if (cl == 1) out->n_gray++;
+        else out->n_white++;
+      }
+    free(inten);
+    if (status != ORC_OK) goto done;
+  }
+  if (m_pl < min_plane || !found) status = ORC_BOARD_NOT_FOUND; /* :111-112 */
+done:
+  out->status = status;
+  out->phase = found; /* reported through the phase field: find_board */
   free(idx);
   free(a);
   free(b);

@@ -40,7 +40,8 @@ enum {
   ORC_NO_PLANE = 3,          /* reference: PCL_ERROR, LidarCornersEst.cpp:206-209 */
   ORC_DEGENERATE_HIST = 4,   /* reference: UB (iter++ past rend), LidarCornersEst.cpp:266-282 */
   ORC_TOO_FEW_POINTS = 5,
-  ORC_BAD_ARGUMENT = 6
+  ORC_BAD_ARGUMENT = 6,
+  ORC_BOARD_NOT_FOUND = 10   /* get_chessboard_by_point returned false, LidarCornersEst.cpp:111-112 */
 };
 
 /* solver selection for orc_extract */
@@ -112,6 +113,9 @@ int32_t orc_roi_crop(const float* xyzi, int32_t n, const float click[3], const o
 int32_t orc_cluster(const float* roi, int32_t m, const float click[3], const orc_params* p,
                     int32_t* out_idx, int32_t* labels_out);
 
+int32_t orc_cluster2(const float* roi, int32_t m, const float click[3], const orc_params* p,
+                     int32_t* out_idx, int32_t* labels_out, int32_t* found_out);
+
 /* a3 getPlane: in = cluster points (m x 4). returns inlier count, indices ascending.
  * plane_out (optional): refit plane nx,ny,nz,d */
 int32_t orc_ransac_plane(const float* pts, int32_t m, const orc_params* p, int32_t* out_idx,
@@ -153,6 +157,12 @@ int32_t orc_corners(const float pca[16], const double theta_t[3], const orc_para
 /* whole path for one frame. debug clouds optional (NULL ok): each n x 4 floats, capacity n. */
 int32_t orc_extract(const float* xyzi, int32_t n, const float click[3], const orc_params* p,
                     orc_result* out, float* cloud_chessboard, float* cloud_pca);
+
+/* f2 get_chessboard_by_point + color_by_gray_zone classes (0 black, 1 gray, 2 white); out->phase
+ * carries find_board.  cloud_chessboard: n x 4 floats, classes: n bytes (NULL ok). */
+int32_t orc_chessboard_by_point(const float* xyzi, int32_t n, const float point[3], const orc_params* p,
+                                int32_t min_plane, orc_result* out, float* cloud_chessboard,
+                                uint8_t* classes);
 
 /* a11 save_corners2txt formatting of one float (ostream default, precision 6) into buf */
 int32_t orc_format_float(float v, char* buf, int32_t cap);

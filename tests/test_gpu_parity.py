@@ -401,3 +401,43 @@ def test_cluster_size_gates_and_non_finite_points(ob, frames):
         if o.status == 0:
             assert np.abs(r.corners_array() - ob.result_corners(o)).max() < 1e-5
         e.close()
+
+
+def test_online_caller_get_chessboard_by_point(ob):
+    """get_chessboard_by_point (no ROI crop, tolerance 0.10, plane >= 500 points) + gray-zone
+    colouring on whole 28 800-point clouds: K2's spatial-hash path vs the oracle's BFS clustering."""
+    clouds, _, _, poses = synth.make_batch(6, fixture_poses=True, seed=900)
+    pts = np.stack([(p.centre + [0.04, -0.05, 0.03]) for p in poses]).astype(np.float32)
+    pts[4] = [-3.0, 2.0, 5.0]                            # predicted centre off the board: whatever surface is nearest wins
+    pts[3] = [0.3, 0.0, -0.9]                            # near the sparse ground rings close to the sensor
+    clouds = clouds.copy()
+    clouds[5, ::5, :3] = np.nan                          # a sparser, partly non-finite cloud
+    p = N.default_params()
+    p.cluster_tol = 0.10                                 # LidarCornersEst.cpp:79
+    p.gray_rate = 2.4                                    # launch/lidar_chessboard_online.launch:14
+    e = LidarCornersBatch(6, 28800, p)
+    res = e.chessboard_by_point(clouds, pts)
+    op = ob.default_params()
+    op.cluster_tol, op.gray_rate = 0.10, 2.4
+    n_ok = 0
+    for f in range(6):
+        o, ocb, ocl = ob.chessboard_by_point(clouds[f], pts[f], op)
+        r = res[f]
+        assert r.status == o.status, (f, r.status, o.status)
+        assert (r.n_roi, r.n_cluster, r.n_plane, r.found_board) == (o.n_roi, o.n_cluster, o.n_plane, o.phase), f
+        if o.status in (0, N.BOARD_NOT_FOUND) and o.n_plane >= 3:
+            assert np.array_equal(e.fetch_cloud(f, N.CLOUD_CHESSBOARD), ocb)
+            assert np.allclose(r.gray_zone, o.gray_zone, rtol=1e-12)
+            assert np.array_equal(e.fetch_classes(f), ocl)
+            assert (r.n_black, r.n_gray, r.n_white) == (o.n_black, o.n_gray, o.n_white)
+        n_ok += int(r.status == 0)
+    assert n_ok >= 3
+    e.close()
+    m = LidarCornersEst(max_points_per_frame=28800, params=p)
+    ok, out = m.get_chessboard_by_point(clouds[0], pts[0])
+    assert ok and len(out) == res[0].n_plane
+    rgb = m.color_by_gray_zone()
+    assert rgb.shape == (len(out), 3) and set(map(tuple, np.unique(rgb, axis=0))) <= {(10, 10, 10), (255, 0, 0), (255, 255, 255)}
+    ok2, out2 = m.get_chessboard_by_point(clouds[4], pts[4])
+    assert ok2 == (res[4].status == 0) and len(out2) == res[4].n_plane
+    m.close()
