@@ -114,6 +114,8 @@ def lib():
         L.orc_chessboard_by_point.restype = C.c_int32
         L.orc_format_float.argtypes = [C.c_float, C.c_char_p, C.c_int32]
         L.orc_format_float.restype = C.c_int32
+        L.orc_solve_pose_3d2d.argtypes = [dp, dp, C.c_int32, dp, dp, dp, dp]
+        L.orc_solve_pose_3d2d.restype = C.c_int32
         _lib = L
     return _lib
 
@@ -264,3 +266,15 @@ def format_float(v: float) -> str:
     buf = C.create_string_buffer(64)
     lib().orc_format_float(C.c_float(v), buf, 64)
     return buf.value.decode()
+
+
+def solve_pose_3d2d(pts3d, pts2d, camera, r0=(0.0, 0.0, 0.0), t0=(0.0, 0.0, 0.0)):
+    """(fx, cx, fy, cy) camera; returns (r, t, final_cost, iterations)."""
+    p3 = np.ascontiguousarray(pts3d, dtype=np.float64)
+    p2 = np.ascontiguousarray(pts2d, dtype=np.float64)
+    cam = np.asarray(camera, dtype=np.float64)
+    r = np.array(r0, dtype=np.float64)
+    t = np.array(t0, dtype=np.float64)
+    fc = C.c_double(0)
+    it = lib().orc_solve_pose_3d2d(_d(p3)[1], _d(p2)[1], len(p3), _d(cam)[1], _d(r)[1], _d(t)[1], C.byref(fc))
+    return r, t, fc.value, it

@@ -1,7 +1,8 @@
 /*
  * ilcc_oracle.c -- CPU restatement of ilcc2's LiDAR chessboard-corner extraction.
- * TEST INFRASTRUCTURE ONLY (see ilcc_oracle.h).  PARITY UNPINNED for input->output:
- * the reference cannot be built here and ships neither tests nor inputs.
+ * TEST INFRASTRUCTURE ONLY (see ilcc_oracle.h).  PARITY UNPINNED for whole-path input->output:
+ * the reference cannot be built here and ships neither tests nor inputs.  The solver part is
+ * pinned against the reference's shipped Ceres output (config/pointgrey.bin), see ilcc_oracle.h.
  *
  * Compile with -ffp-contract=off and without -ffast-math: the float stages are written
  * as plain (unfused) float expressions, which is what an -O3 x86-64 build of PCL computes.
@@ -688,17 +689,29 @@ double orc_cost(const double theta_t[3], const float* y, const float* z, const i
  * Robust loss enters through Ceres' Corrector (rho'' <= 0 for Huber, so residual and
  * Jacobian rows are scaled by sqrt(rho')). */
 
+#define ORC_MAXP 6 /* parameters: 3 (board theta, ty, tz) or 6 (angle-axis + translation) */
+
 typedef struct {
-  int32_t n;       /* labelled points */
+  int32_t kind;    /* 0: VirtualboardError blocks of the path;  1: Pose3d2dError blocks (orc_solve_pose_3d2d) */
+  int32_t n;       /* labelled points / 3-D-2-D pairs */
   const float* y;  /* compacted */
   const float* z;
   const int8_t* lab;
   const orc_params* p;
   int32_t tlw, oob;
+  const double* p3; /* kind 1 */
+  const double* p2;
+  double cam[4];    /* fx cx fy cy */
 } lsq_problem;
 
+static inline int lsq_np(const lsq_problem* q) { return q->kind ? 6 : 3; }
+static inline int32_t lsq_nres(const lsq_problem* q) { return q->kind ? 2 * q->n : q->n; }
+
+static double pose_eval(const lsq_problem* q, const double* x, double* r, double* J);
+
 /* cost and (optionally) corrected residuals r[n] and jacobian J[n*3] at x */
-static double lsq_eval(const lsq_problem* q, const double x[3], double* r, double* J) {
+static double lsq_eval(const lsq_problem* q, const double* x, double* r, double* J) {
+  if (q->kind) return pose_eval(q, x, r, J);
   double cost = 0;
   for (int32_t k = 0; k < q->n; ++k) {
     double jac[3];
@@ -718,12 +731,12 @@ static double lsq_eval(const lsq_problem* q, const double x[3], double* r, doubl
   return cost;
 }
 
-/* 3x3 Cholesky solve (lower), returns 0 on non-positive pivot (Eigen LLT NumericalIssue) */
-static int chol3_solve(const double A[9], const double b[3], double x[3]) {
-  double L[3][3] = {{0}};
-  for (int i = 0; i < 3; ++i)
+/* dense Cholesky solve (lower), returns 0 on non-positive pivot (Eigen LLT NumericalIssue) */
+static int chol_solve(int np, const double* A, const double* b, double* x) {
+  double L[ORC_MAXP][ORC_MAXP] = {{0}};
+  for (int i = 0; i < np; ++i)
     for (int j = 0; j <= i; ++j) {
-      double s = A[3 * i + j];
+      double s = A[np * i + j];
       for (int k = 0; k < j; ++k) s -= L[i][k] * L[j][k];
       if (i == j) {
         if (!(s > 0.0)) return 0;
@@ -732,18 +745,18 @@ static int chol3_solve(const double A[9], const double b[3], double x[3]) {
         L[i][j] = s / L[j][j];
       }
     }
-  double yv[3];
-  for (int i = 0; i < 3; ++i) {
+  double yv[ORC_MAXP];
+  for (int i = 0; i < np; ++i) {
     double s = b[i];
     for (int k = 0; k < i; ++k) s -= L[i][k] * yv[k];
     yv[i] = s / L[i][i];
   }
-  for (int i = 2; i >= 0; --i) {
+  for (int i = np - 1; i >= 0; --i) {
     double s = yv[i];
-    for (int k = i + 1; k < 3; ++k) s -= L[k][i] * x[k];
+    for (int k = i + 1; k < np; ++k) s -= L[k][i] * x[k];
     x[i] = s / L[i][i];
   }
-  for (int i = 0; i < 3; ++i)
+  for (int i = 0; i < np; ++i)
     if (!isfinite(x[i])) return 0;
   return 1;
 }
@@ -821,33 +834,40 @@ static void min_on_circle(const double B[4], const double g[2], double radius, d
 }
 
 typedef struct {
+  int np;
   double radius, mu;
   int reuse;
-  double diagonal[3], gradient[3], gn[3];
+  double diagonal[ORC_MAXP], gradient[ORC_MAXP], gn[ORC_MAXP];
   double alpha, step_norm;
   /* subspace model */
   int one_dim;
-  double basis[3][2], sg[2], sB[4];
+  double basis[ORC_MAXP][2], sg[2], sB[4];
 } dogleg_state;
 
+static inline double vnorm(const double* v, int np) {
+  double s = 0;
+  for (int c = 0; c < np; ++c) s += v[c] * v[c];
+  return sqrt(s);
+}
+
 /* traditional dogleg step in scaled space (fallback only) */
-static void dogleg_traditional(dogleg_state* s, double step[3]) {
-  const double gnn = sqrt(s->gn[0] * s->gn[0] + s->gn[1] * s->gn[1] + s->gn[2] * s->gn[2]);
-  const double gn_ = sqrt(s->gradient[0] * s->gradient[0] + s->gradient[1] * s->gradient[1] +
-                          s->gradient[2] * s->gradient[2]);
+static void dogleg_traditional(dogleg_state* s, double* step) {
+  const int np = s->np;
+  const double gnn = vnorm(s->gn, np);
+  const double gn_ = vnorm(s->gradient, np);
   if (gnn <= s->radius) {
-    for (int c = 0; c < 3; ++c) step[c] = s->gn[c] / s->diagonal[c];
+    for (int c = 0; c < np; ++c) step[c] = s->gn[c] / s->diagonal[c];
     s->step_norm = gnn;
     return;
   }
   if (gn_ * s->alpha >= s->radius) {
-    for (int c = 0; c < 3; ++c) step[c] = -(s->radius / gn_) * s->gradient[c] / s->diagonal[c];
+    for (int c = 0; c < np; ++c) step[c] = -(s->radius / gn_) * s->gradient[c] / s->diagonal[c];
     s->step_norm = s->radius;
     return;
   }
   /* intersect the segment Cauchy -> GN with the boundary */
   double bdota = 0, a2 = 0, bma2 = 0;
-  for (int c = 0; c < 3; ++c) {
+  for (int c = 0; c < np; ++c) {
     const double a = -s->alpha * s->gradient[c];
     bdota += a * s->gn[c];
     a2 += a * a;
@@ -856,99 +876,100 @@ static void dogleg_traditional(dogleg_state* s, double step[3]) {
   const double cc = bdota - a2;
   const double d = sqrt(cc * cc + bma2 * (s->radius * s->radius - a2));
   const double beta = (cc <= 0) ? (d - cc) / bma2 : (s->radius * s->radius - a2) / (d + cc);
-  for (int c = 0; c < 3; ++c) {
+  for (int c = 0; c < np; ++c) {
     const double a = -s->alpha * s->gradient[c];
     step[c] = (a + beta * (s->gn[c] - a)) / s->diagonal[c];
   }
   s->step_norm = s->radius;
 }
 
-/* returns 0 on LINEAR_SOLVER_FAILURE */
+/* returns 0 on LINEAR_SOLVER_FAILURE; n = residual count, J is n x np row-major */
 static int dogleg_compute_step(dogleg_state* s, int32_t n, const double* J, const double* r,
-                               double step[3]) {
+                               double* step) {
+  const int np = s->np;
   if (!s->reuse) {
     s->reuse = 1;
-    double JtJ[9] = {0}, Jtr[3] = {0};
+    double JtJ[ORC_MAXP * ORC_MAXP] = {0}, Jtr[ORC_MAXP] = {0};
     for (int32_t k = 0; k < n; ++k)
-      for (int a = 0; a < 3; ++a) {
-        Jtr[a] += J[3 * k + a] * r[k];
-        for (int b = 0; b < 3; ++b) JtJ[3 * a + b] += J[3 * k + a] * J[3 * k + b];
+      for (int a = 0; a < np; ++a) {
+        Jtr[a] += J[np * k + a] * r[k];
+        for (int b = 0; b < np; ++b) JtJ[np * a + b] += J[np * k + a] * J[np * k + b];
       }
-    for (int c = 0; c < 3; ++c) {
-      double d = JtJ[4 * c];
+    for (int c = 0; c < np; ++c) {
+      double d = JtJ[(np + 1) * c];
       d = fmin(fmax(d, 1e-6), 1e32);
       s->diagonal[c] = sqrt(d);
       s->gradient[c] = Jtr[c] / s->diagonal[c];
     }
     /* Cauchy point: alpha = |g|^2 / |J D^-1 g|^2 */
     {
-      double sgv[3], num = 0, den = 0;
-      for (int c = 0; c < 3; ++c) {
+      double sgv[ORC_MAXP], num = 0, den = 0;
+      for (int c = 0; c < np; ++c) {
         sgv[c] = s->gradient[c] / s->diagonal[c];
         num += s->gradient[c] * s->gradient[c];
       }
-      for (int a = 0; a < 3; ++a)
-        for (int b = 0; b < 3; ++b) den += sgv[a] * JtJ[3 * a + b] * sgv[b];
+      for (int a = 0; a < np; ++a)
+        for (int b = 0; b < np; ++b) den += sgv[a] * JtJ[np * a + b] * sgv[b];
       s->alpha = num / den;
     }
     /* Gauss-Newton step with regulariser mu * diag */
     int ok = 0;
     while (s->mu < 1.0) {
-      double A[9];
+      double A[ORC_MAXP * ORC_MAXP];
       memcpy(A, JtJ, sizeof(A));
-      for (int c = 0; c < 3; ++c) {
+      for (int c = 0; c < np; ++c) {
         const double lm = s->diagonal[c] * sqrt(s->mu);
-        A[4 * c] += lm * lm;
+        A[(np + 1) * c] += lm * lm;
       }
-      if (chol3_solve(A, Jtr, s->gn)) {
+      if (chol_solve(np, A, Jtr, s->gn)) {
         ok = 1;
         break;
       }
       s->mu *= 10.0;
     }
     if (!ok) return 0;
-    for (int c = 0; c < 3; ++c) s->gn[c] *= -s->diagonal[c];
+    for (int c = 0; c < np; ++c) s->gn[c] *= -s->diagonal[c];
     /* subspace model: orthonormal basis of span{gradient, gn} (Gram-Schmidt with pivoting,
      * standing in for Eigen::ColPivHouseholderQR; signs of the basis do not matter) */
     {
-      double v0[3], v1[3];
+      double v0[ORC_MAXP], v1[ORC_MAXP];
       double n0 = 0, n1 = 0;
-      for (int c = 0; c < 3; ++c) {
+      for (int c = 0; c < np; ++c) {
         n0 += s->gradient[c] * s->gradient[c];
         n1 += s->gn[c] * s->gn[c];
       }
       const double* first = (n0 >= n1) ? s->gradient : s->gn;
       const double* second = (n0 >= n1) ? s->gn : s->gradient;
       const double nf = sqrt(fmax(n0, n1));
-      for (int c = 0; c < 3; ++c) v0[c] = first[c] / nf;
+      for (int c = 0; c < np; ++c) v0[c] = first[c] / nf;
       double dot = 0;
-      for (int c = 0; c < 3; ++c) dot += second[c] * v0[c];
+      for (int c = 0; c < np; ++c) dot += second[c] * v0[c];
       double nr = 0;
-      for (int c = 0; c < 3; ++c) {
+      for (int c = 0; c < np; ++c) {
         v1[c] = second[c] - dot * v0[c];
         nr += v1[c] * v1[c];
       }
       nr = sqrt(nr);
       /* rank test as ColPivHouseholderQR: |R11| <= eps * n * |R00| -> rank 1 */
-      s->one_dim = !(nr > 3.0 * DBL_EPSILON * nf);
+      s->one_dim = !(nr > (double)np * DBL_EPSILON * nf);
       if (!s->one_dim) {
-        for (int c = 0; c < 3; ++c) {
+        for (int c = 0; c < np; ++c) {
           v1[c] /= nr;
           s->basis[c][0] = v0[c];
           s->basis[c][1] = v1[c];
         }
-        double u[2][3];
-        for (int c = 0; c < 3; ++c) {
+        double u[2][ORC_MAXP];
+        for (int c = 0; c < np; ++c) {
           u[0][c] = v0[c] / s->diagonal[c];
           u[1][c] = v1[c] / s->diagonal[c];
         }
         for (int a = 0; a < 2; ++a) {
           s->sg[a] = 0;
-          for (int c = 0; c < 3; ++c) s->sg[a] += s->basis[c][a] * s->gradient[c];
+          for (int c = 0; c < np; ++c) s->sg[a] += s->basis[c][a] * s->gradient[c];
           for (int b = 0; b < 2; ++b) {
             double acc = 0;
-            for (int c = 0; c < 3; ++c)
-              for (int d = 0; d < 3; ++d) acc += u[a][c] * JtJ[3 * c + d] * u[b][d];
+            for (int c = 0; c < np; ++c)
+              for (int d = 0; d < np; ++d) acc += u[a][c] * JtJ[np * c + d] * u[b][d];
             s->sB[2 * a + b] = acc;
           }
         }
@@ -956,16 +977,15 @@ static int dogleg_compute_step(dogleg_state* s, int32_t n, const double* J, cons
     }
   }
   /* ComputeSubspaceDoglegStep */
-  const double gnn = sqrt(s->gn[0] * s->gn[0] + s->gn[1] * s->gn[1] + s->gn[2] * s->gn[2]);
+  const double gnn = vnorm(s->gn, np);
   if (gnn <= s->radius) {
-    for (int c = 0; c < 3; ++c) step[c] = s->gn[c] / s->diagonal[c];
+    for (int c = 0; c < np; ++c) step[c] = s->gn[c] / s->diagonal[c];
     s->step_norm = gnn;
     return 1;
   }
   if (s->one_dim) {
-    const double gn_ = sqrt(s->gradient[0] * s->gradient[0] + s->gradient[1] * s->gradient[1] +
-                            s->gradient[2] * s->gradient[2]);
-    for (int c = 0; c < 3; ++c) step[c] = -(s->radius / gn_) * s->gradient[c] / s->diagonal[c];
+    const double gn_ = vnorm(s->gradient, np);
+    for (int c = 0; c < np; ++c) step[c] = -(s->radius / gn_) * s->gradient[c] / s->diagonal[c];
     s->step_norm = s->radius;
     return 1;
   }
@@ -975,57 +995,62 @@ static int dogleg_compute_step(dogleg_state* s, int32_t n, const double* J, cons
     dogleg_traditional(s, step);
     return 1;
   }
-  for (int c = 0; c < 3; ++c)
+  for (int c = 0; c < np; ++c)
     step[c] = (s->basis[c][0] * y2[0] + s->basis[c][1] * y2[1]) / s->diagonal[c];
   s->step_norm = s->radius;
   return 1;
 }
 
-static int32_t trust_region_minimize(const lsq_problem* q, double x[3], double* final_cost) {
-  const int32_t n = q->n;
+/* x has lsq_np(q) entries */
+static int32_t trust_region_minimize(const lsq_problem* q, double* x, double* final_cost) {
+  const int np = lsq_np(q);
+  const int32_t n = lsq_nres(q);
   if (n == 0) {
     *final_cost = 0;
     return 0;
   }
   double* r = (double*)malloc(sizeof(double) * (size_t)n);
-  double* J = (double*)malloc(sizeof(double) * 3 * (size_t)n);
-  double scale[3];
+  double* J = (double*)malloc(sizeof(double) * (size_t)np * (size_t)n);
+  double scale[ORC_MAXP];
   dogleg_state st;
   memset(&st, 0, sizeof(st));
+  st.np = np;
   st.radius = 1e4;
   st.mu = 1e-8;
   st.reuse = 0;
 
   double x_cost = lsq_eval(q, x, r, J);
-  double x_norm = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
-  double grad[3] = {0, 0, 0};
+  double x_norm = vnorm(x, np);
+  double grad[ORC_MAXP] = {0};
   for (int32_t k = 0; k < n; ++k)
-    for (int c = 0; c < 3; ++c) grad[c] += J[3 * k + c] * r[k];
+    for (int c = 0; c < np; ++c) grad[c] += J[np * k + c] * r[k];
   /* jacobi scaling, computed once at iteration 0 */
-  for (int c = 0; c < 3; ++c) {
+  for (int c = 0; c < np; ++c) {
     double sq = 0;
-    for (int32_t k = 0; k < n; ++k) sq += J[3 * k + c] * J[3 * k + c];
+    for (int32_t k = 0; k < n; ++k) sq += J[np * k + c] * J[np * k + c];
     scale[c] = 1.0 / (1.0 + sqrt(sq));
   }
   for (int32_t k = 0; k < n; ++k)
-    for (int c = 0; c < 3; ++c) J[3 * k + c] *= scale[c];
+    for (int c = 0; c < np; ++c) J[np * k + c] *= scale[c];
 
   int32_t iter = 0;
   int invalid = 0;
   for (;;) {
     /* FinalizeIterationAndCheckIfMinimizerCanContinue */
     if (iter >= 50) break;
-    const double gmax = fmax(fabs(grad[0]), fmax(fabs(grad[1]), fabs(grad[2])));
+    double gmax = 0;
+    for (int c = 0; c < np; ++c) gmax = fmax(gmax, fabs(grad[c]));
     if (gmax <= 1e-10) break;
     if (st.radius <= 1e-32) break;
     ++iter;
 
-    double step[3];
+    double step[ORC_MAXP];
     int valid = dogleg_compute_step(&st, n, J, r, step);
     double model_cost_change = 0;
     if (valid) {
       for (int32_t k = 0; k < n; ++k) {
-        const double mr = J[3 * k] * step[0] + J[3 * k + 1] * step[1] + J[3 * k + 2] * step[2];
+        double mr = 0;
+        for (int c = 0; c < np; ++c) mr += J[np * k + c] * step[c];
         model_cost_change -= mr * (r[k] + mr / 2.0);
       }
       valid = model_cost_change > 0.0;
@@ -1037,32 +1062,31 @@ static int32_t trust_region_minimize(const lsq_problem* q, double x[3], double* 
       continue;
     }
     invalid = 0;
-    double cand[3], delta[3];
-    for (int c = 0; c < 3; ++c) {
+    double cand[ORC_MAXP], delta[ORC_MAXP];
+    for (int c = 0; c < np; ++c) {
       delta[c] = step[c] * scale[c];
       cand[c] = x[c] + delta[c];
     }
     const double cand_cost = lsq_eval(q, cand, NULL, NULL);
     /* ParameterToleranceReached */
-    const double step_norm = sqrt((x[0] - cand[0]) * (x[0] - cand[0]) +
-                                  (x[1] - cand[1]) * (x[1] - cand[1]) +
-                                  (x[2] - cand[2]) * (x[2] - cand[2]));
+    double dn = 0;
+    for (int c = 0; c < np; ++c) dn += (x[c] - cand[c]) * (x[c] - cand[c]);
+    const double step_norm = sqrt(dn);
     if (step_norm <= 1e-8 * (x_norm + 1e-8)) break;
     /* FunctionToleranceReached */
     const double cost_change = x_cost - cand_cost;
     if (fabs(cost_change) <= 1e-6 * x_cost) break;
     const double rel = cost_change / model_cost_change;
-    if (getenv("ORC_TRACE")) fprintf(stderr, "it %d cost %.6g cand %.6g model %.3g rel %.3g radius %.3g stepn %.3g x %.5f %.5f %.5f\n", iter, x_cost, cand_cost, model_cost_change, rel, st.radius, st.step_norm, x[0], x[1], x[2]);
     if (rel > 1e-3) {
       /* HandleSuccessfulStep */
-      for (int c = 0; c < 3; ++c) x[c] = cand[c];
-      x_norm = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+      for (int c = 0; c < np; ++c) x[c] = cand[c];
+      x_norm = vnorm(x, np);
       x_cost = lsq_eval(q, x, r, J);
-      for (int c = 0; c < 3; ++c) grad[c] = 0;
+      for (int c = 0; c < np; ++c) grad[c] = 0;
       for (int32_t k = 0; k < n; ++k)
-        for (int c = 0; c < 3; ++c) grad[c] += J[3 * k + c] * r[k];
+        for (int c = 0; c < np; ++c) grad[c] += J[np * k + c] * r[k];
       for (int32_t k = 0; k < n; ++k)
-        for (int c = 0; c < 3; ++c) J[3 * k + c] *= scale[c];
+        for (int c = 0; c < np; ++c) J[np * k + c] *= scale[c];
       /* DoglegStrategy::StepAccepted */
       if (rel < 0.25) st.radius *= 0.5;
       if (rel > 0.75) st.radius = fmax(st.radius, 3.0 * st.step_norm);
@@ -1078,6 +1102,115 @@ static int32_t trust_region_minimize(const lsq_problem* q, double x[3], double* 
   free(r);
   free(J);
   return iter;
+}
+
+/* ---- Pose3d2dError (include/ilcc2/Optimization.h:126-189) with HuberLoss(0.1) per 2-vector block
+ * (src/Optimization.cpp:43-51): the 6-parameter problem the reference's calib_lidar_cam solves with
+ * the SAME Ceres options as the path's board fit.  It exists in the oracle for one reason: the
+ * reference ships inputs AND output of this solve (process_data/pointgrey*.txt ->
+ * config/pointgrey.bin), which pins trust_region_minimize / dogleg / corrector code above against
+ * a real Ceres run (tests/test_oracle_golden.py::test_solver_pinned_by_shipped_extrinsic). */
+static void rodrigues9(const double* w, double R[9], double* b_out, double* c_out) {
+  const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+  const double th = sqrt(th2);
+  double a, b, c;
+  if (th2 > 1e-16) {
+    a = sin(th) / th;
+    b = (1.0 - cos(th)) / th2;
+    c = (th - sin(th)) / (th2 * th);
+  } else {
+    a = 1.0;
+    b = 0.5;
+    c = 1.0 / 6.0;
+  }
+  const double K[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      double k2 = 0;
+      for (int k = 0; k < 3; ++k) k2 += K[3 * i + k] * K[3 * k + j];
+      R[3 * i + j] = a * K[3 * i + j] + b * k2 + (i == j ? 1.0 : 0.0);
+    }
+  if (b_out) *b_out = b;
+  if (c_out) *c_out = c;
+}
+
+static double pose_eval(const lsq_problem* q, const double* x, double* r, double* J) {
+  double R[9], b, c;
+  rodrigues9(x, R, &b, &c);
+  /* right Jacobian of SO(3): d(exp([w]x) X)/dw = -R [X]x Jr,  Jr = I - b K + c K^2 */
+  double Jr[9];
+  {
+    const double K[9] = {0, -x[2], x[1], x[2], 0, -x[0], -x[1], x[0], 0};
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) {
+        double k2 = 0;
+        for (int k = 0; k < 3; ++k) k2 += K[3 * i + k] * K[3 * k + j];
+        Jr[3 * i + j] = -b * K[3 * i + j] + c * k2 + (i == j ? 1.0 : 0.0);
+      }
+  }
+  const double fx = q->cam[0], cx = q->cam[1], fy = q->cam[2], cy = q->cam[3];
+  double cost = 0;
+  for (int32_t i = 0; i < q->n; ++i) {
+    const double* X = q->p3 + 3 * i;
+    double pc[3];
+    for (int k = 0; k < 3; ++k) pc[k] = R[3 * k] * X[0] + R[3 * k + 1] * X[1] + R[3 * k + 2] * X[2] + x[3 + k];
+    const double iz = 1.0 / pc[2];
+    const double r0 = q->p2[2 * i] - (fx * pc[0] * iz + cx);
+    const double r1 = q->p2[2 * i + 1] - (fy * pc[1] * iz + cy);
+    double rho0, rho1;
+    huber(0.1, r0 * r0 + r1 * r1, &rho0, &rho1);
+    cost += 0.5 * rho0;
+    if (!r) continue;
+    const double sr = sqrt(rho1);
+    r[2 * i] = sr * r0;
+    r[2 * i + 1] = sr * r1;
+    if (!J) continue;
+    const double Xx[9] = {0, -X[2], X[1], X[2], 0, -X[0], -X[1], X[0], 0};
+    double RX[9], Jp[9];
+    for (int a = 0; a < 3; ++a)
+      for (int d = 0; d < 3; ++d) {
+        double s = 0;
+        for (int k = 0; k < 3; ++k) s += R[3 * a + k] * Xx[3 * k + d];
+        RX[3 * a + d] = s;
+      }
+    for (int a = 0; a < 3; ++a)
+      for (int d = 0; d < 3; ++d) {
+        double s = 0;
+        for (int k = 0; k < 3; ++k) s += RX[3 * a + k] * Jr[3 * k + d];
+        Jp[3 * a + d] = -s;
+      }
+    const double du[3] = {fx * iz, 0, -fx * pc[0] * iz * iz};
+    const double dv[3] = {0, fy * iz, -fy * pc[1] * iz * iz};
+    double* j0 = J + 12 * i;
+    double* j1 = j0 + 6;
+    for (int d = 0; d < 3; ++d) {
+      j0[d] = -sr * (du[0] * Jp[d] + du[1] * Jp[3 + d] + du[2] * Jp[6 + d]);
+      j1[d] = -sr * (dv[0] * Jp[d] + dv[1] * Jp[3 + d] + dv[2] * Jp[6 + d]);
+      j0[3 + d] = -sr * du[d];
+      j1[3 + d] = -sr * dv[d];
+    }
+  }
+  return cost;
+}
+
+int32_t orc_solve_pose_3d2d(const double* pts3d, const double* pts2d, int32_t n, const double camera[4],
+                            double r[3], double t[3], double* final_cost) {
+  lsq_problem q;
+  memset(&q, 0, sizeof(q));
+  q.kind = 1;
+  q.n = n;
+  q.p3 = pts3d;
+  q.p2 = pts2d;
+  for (int c = 0; c < 4; ++c) q.cam[c] = camera[c];
+  double x[6] = {r[0], r[1], r[2], t[0], t[1], t[2]};
+  double fc = 0;
+  const int32_t it = trust_region_minimize(&q, x, &fc);
+  for (int c = 0; c < 3; ++c) {
+    r[c] = x[c];
+    t[c] = x[3 + c];
+  }
+  if (final_cost) *final_cost = fc;
+  return it;
 }
 
 /* classification of Optimization.cpp:114-125 ; returns labelled count, fills compact arrays */
@@ -1114,6 +1247,7 @@ int32_t orc_get_theta_t(const float* pts_pca, int32_t m, const double gray_zone[
   int8_t* lab = (int8_t*)malloc((size_t)(m > 0 ? m : 1));
   int32_t counts[3];
   lsq_problem q;
+  memset(&q, 0, sizeof(q));
   q.n = classify(pts_pca, m, gray_zone, y, z, lab, counts);
   q.y = y;
   q.z = z;
@@ -1288,6 +1422,7 @@ int32_t orc_extract(const float* xyzi, int32_t n, const float click[3], const or
       th[2] = p->tz_min + bz * p->tz_step;
     }
     lsq_problem q;
+    memset(&q, 0, sizeof(q));
     q.n = nl;
     q.y = y;
     q.z = z;

@@ -6,10 +6,13 @@
  *   load this library.  The product (libilcc_hip.so) never links, includes or
  *   calls anything in oracle/.
  *
- * PARITY STATUS: **parity unpinned** for input->output.  The reference cannot be
- * compiled here (needs PCL/Eigen/Ceres/OpenCV/ROS, all absent), ships no tests
- * and its six input bags are stripped.  What IS pinned, and what
+ * PARITY STATUS: **parity unpinned** for whole-path input->output.  The reference
+ * cannot be compiled here (needs PCL/Eigen/Ceres/OpenCV/ROS, all absent), ships no
+ * tests and its six input bags are stripped.  What IS pinned, and what
  * tests/test_oracle_golden.py checks this file against:
+ *   - the Ceres trust-region restatement against an OUTPUT OF THE REFERENCE: run on the
+ *     shipped corner-file pairs (ilcc2/process_data/pointgrey*.txt) it reproduces the
+ *     shipped extrinsic ilcc2/config/pointgrey.bin to 3e-16 (orc_solve_pose_3d2d),
  *   - the cost functor's hand-derived known-answer table (SURVEY.md App. C,
  *     derived from ilcc2/include/ilcc2/Optimization.h:31-107),
  *   - the six bundled output files ilcc2/process_data/pointgrey_lidar_{1..6}.txt
@@ -166,6 +169,12 @@ int32_t orc_chessboard_by_point(const float* xyzi, int32_t n, const float point[
 
 /* a11 save_corners2txt formatting of one float (ostream default, precision 6) into buf */
 int32_t orc_format_float(float v, char* buf, int32_t cap);
+
+/* Pose3d2dError + HuberLoss(0.1) through the SAME trust-region code as the path's board fit
+ * (src/Optimization.cpp:13-91).  Not on the hot path: it is here because the reference ships the
+ * inputs and the output of this solve, which pins the solver restatement against a real Ceres run. */
+int32_t orc_solve_pose_3d2d(const double* pts3d, const double* pts2d, int32_t n, const double camera[4],
+                            double r[3], double t[3], double* final_cost);
 
 #ifdef __cplusplus
 }

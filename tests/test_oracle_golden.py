@@ -395,3 +395,61 @@ def test_config1_synthetic_frame_at_fixture_pose(ob, golden_dir, n, tmp_path):
     assert res.status == 0 and res.n_corners == 35
     err = synth.corner_error(ob.result_corners(res), pts, board)
     assert err < 0.010, err
+
+
+# ----------------------------------------------------------------------------------------------
+# Solver pin: the reference ships the inputs (process_data/pointgrey{N}.txt, pointgrey_lidar_{N}.txt)
+# AND the output (config/pointgrey.bin) of one Ceres solve made with exactly the options of the
+# path's board fit (src/Optimization.cpp:55-66 vs :146-157).  The oracle's trust-region code, run on
+# that 6-parameter problem, must land on the shipped matrix.
+def _shipped_pairs(GOLD):
+    cam = (1061.37439737547, 980.706836288949, 1061.02435228316, 601.685030610243)   # fx cx fy cy (pointgrey.yaml K)
+    w, h = 7, 5
+
+    def rot(axis, a):
+        c, s = np.cos(a), np.sin(a)
+        return {"x": np.array([[1, 0, 0], [0, c, -s], [0, s, c]]),
+                "y": np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]])}[axis]
+
+    rough = rot("y", -1.57) @ rot("x", 1.57)                      # test/calib_lidar_cam.cpp:56-58
+    p3_all, p2_all = [], []
+    for i in range(1, 7):
+        raw = np.loadtxt(os.path.join(GOLD, f"pointgrey{i}.txt"))
+        assert raw.shape in ((14, 5), (10, 7))
+        X, Y = raw[:len(raw) // 2], raw[len(raw) // 2:]
+        if len(X) != h:                                             # column-major read (ImageCornersEst.cpp:262-266)
+            X, Y = X.T, Y.T
+        p2 = np.stack([X.reshape(-1), Y.reshape(-1)], 1)
+        # read_lidar_corners parses into float and widens (src/ImageCornersEst.cpp:290-292)
+        p3 = np.loadtxt(os.path.join(GOLD, f"pointgrey_lidar_{i}.txt"), dtype=np.float32).astype(np.float64) @ rough.T
+        # check_order_lidar / check_order_cam (src/ImageCornersEst.cpp:430-488)
+        g3, g2 = p3.reshape(h, w, 3), p2.reshape(h, w, 2)
+        if p3[0, 1] > p3[w + 1, 1]:
+            g3 = g3[::-1]
+        if p3[0, 0] > p3[1, 0]:
+            g3 = g3[:, ::-1]
+        if p2[0, 1] > p2[w + 1, 1]:
+            g2 = g2[::-1]
+        if p2[0, 0] > p2[1, 0]:
+            g2 = g2[:, ::-1]
+        p3_all.append(g3.reshape(-1, 3))
+        p2_all.append(g2.reshape(-1, 2))
+    return np.concatenate(p3_all), np.concatenate(p2_all), cam, rough
+
+
+def test_solver_pinned_by_shipped_extrinsic(ob, golden_dir):
+    from scipy.spatial.transform import Rotation
+    GOLD = golden_dir
+    p3, p2, cam, rough = _shipped_pairs(GOLD)
+    r, t, cost, it = ob.solve_pose_3d2d(p3, p2, cam)
+    T = np.eye(4)
+    T[:3, :3] = Rotation.from_rotvec(r).as_matrix()
+    T[:3, 3] = t
+    R4 = np.eye(4)
+    R4[:3, :3] = rough
+    T = T @ R4
+    ref = np.fromfile(os.path.join(GOLD, "pointgrey.bin"), dtype=np.float64).reshape(4, 4, order="F")
+    dev = np.abs(T - ref).max()
+    print("iterations", it, "cost", cost, "max |T - shipped|", dev)
+    assert 0 < it <= 50
+    assert dev < 1e-12     # measured 4e-16: the shipped matrix is this solve, to the last bit or two
