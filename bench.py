@@ -216,6 +216,9 @@ def main():
                          "frac": valu_rate / VALU_ISSUE_PEAK_T},
             },
         }
+        if world == 1:
+            out["pcie_inclusive"] = pcie_inclusive_rate(torch, est, clouds, d_clicks, F, lidar.n_points, depth,
+                                                        max(10, min(60, args.steps)))
         if world == 1 and not args.no_cpu_baseline:
             # the reference's own trajectory on the GPU (ILCC_SOLVER_REFERENCE_LOCAL), to compare corner for
             # corner with the CPU port below (BASELINE.json: <= 1e-3 m vs the reference CPU path)
@@ -233,6 +236,62 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pcie_inclusive_rate(torch, est, clouds, d_clicks, F, n_points, depth, steps):
+    """Same pipeline, but every batch starts in pinned HOST memory and crosses PCIe first (copy on its own
+    stream into one of `depth` rotating device buffers, overlapped with the previous batches' kernels).
+    Reported beside `value`, never as `value` (SURVEY.md 8d counts the copy; the bench contract does not)."""
+    h = torch.from_numpy(clouds).pin_memory()
+    bufs = [torch.empty(h.shape, dtype=h.dtype, device="cuda") for _ in range(depth)]
+    cs = torch.cuda.Stream()
+
+    def go(n):
+        tickets = []
+        for i in range(n):
+            b = bufs[i % depth]           # its previous ticket was waited for below before we get here
+            with torch.cuda.stream(cs):
+                b.copy_(h, non_blocking=True)
+            cs.synchronize()              # the C-ABI wants complete inputs
+            tickets.append(est.submit_device(b.data_ptr(), F, n_points, d_clicks.data_ptr()))
+            if len(tickets) == depth:
+                est.wait(tickets.pop(0))
+        while tickets:
+            est.wait(tickets.pop(0))
+
+    go(5)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    go(steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"value": F * steps / dt, "unit": "frames/s", "steps": steps, "ms_per_step": 1e3 * dt / steps,
+            "h2d_bytes_per_step": int(h.numel() * 4),
+            "h2d_GBps_if_copy_bound": h.numel() * 4 * steps / dt / 1e9,
+            "note": "pinned host -> device copy of the XYZI batch per step, overlapped with compute"}
+
+
+def _cpu_all_cores(clouds, clicks, p, budget_s):
+    """The same CPU path on every host core (frames in parallel; ctypes releases the GIL)."""
+    import concurrent.futures as cf
+    from oracle import binding as ob
+    cores = os.cpu_count() or 1
+    ob.extract(clouds[0], clicks[0], p)
+    stop = time.perf_counter() + budget_s
+
+    def worker(w):
+        n, f = 0, w
+        while time.perf_counter() < stop:
+            ob.extract(clouds[f % len(clouds)], clicks[f % len(clouds)], p)
+            n += 1
+            f += cores
+        return n
+
+    t0 = time.perf_counter()
+    with cf.ThreadPoolExecutor(cores) as ex:
+        n = sum(ex.map(worker, range(cores)))
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "frames/s", "cores": cores, "sample": "%d frames in %.1f s on %d threads" % (n, dt, cores)}
 
 
 def cpu_baseline(clouds, clicks, gts, board, budget_s, gpu_ref=None):
@@ -265,6 +324,7 @@ def cpu_baseline(clouds, clicks, gts, board, budget_s, gpu_ref=None):
         "unit": "frames/s",
         "cores": 1,
         "kind": "port",
+        "all_cores": _cpu_all_cores(clouds, clicks, p, min(6.0, budget_s)),
         "sample": "%d frames of the same batch (cycled), %.1f s, single thread; restatement of the reference "
                   "path (crop, cluster, RANSAC, PCA, gray zone, 2 phases x Ceres-style pass A+B); omits "
                   "Ceres autodiff/heap and PCL kd-tree overheads, so it is faster than the real reference" % (n, dt),

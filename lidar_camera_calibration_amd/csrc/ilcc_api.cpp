@@ -407,6 +407,11 @@ int32_t finish(ilcc_handle* h, int si, ilcc_result* out) {
 
 }  // namespace
 
+namespace ilcc {
+// text behind ilcc_last_error(NULL) for the handle-less entry points in other translation units
+void set_global_error(const std::string& s) { g_err = s; }
+}  // namespace ilcc
+
 extern "C" {
 
 int32_t ilcc_abi_version(void) { return ILCC_ABI_VERSION; }

@@ -2,7 +2,9 @@
 // box): one frame (raw float32 x,y,z,intensity records) + one click -> process_data-format file.
 //   ilcc_corners --cloud frame.bin --click x y z --yaml pointgrey.yaml --out pointgrey_lidar_1.txt
 //                [--solver grid|reference] [--device N]
-// Mirrors the per-bag body of /root/reference/ilcc2/test/get_lidar_corners.cpp:163-204.
+//   ilcc_corners --bag 20181101_1.bag [--topic /velodyne_points] --click x y z ... (first PointCloud2
+//                of the bag, read without ROS: include/ilcc_ingest.h)
+// Mirrors the per-bag body of /root/reference/ilcc2/test/get_lidar_corners.cpp:133-204.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -11,17 +13,20 @@
 #include <string>
 
 #include "LidarCornersEst.h"
+#include "ilcc_ingest.h"
 
 using namespace ilcc_host;
 
 int main(int argc, char** argv) {
-  std::string cloud_path, yaml_path, out_path, solver = "grid";
+  std::string cloud_path, bag_path, topic = "/velodyne_points", yaml_path, out_path, solver = "grid";
   PointXYZI click{0, 0, 0, 0};
   int device = -1;
   bool have_click = false;
   for (int i = 1; i < argc; ++i) {
     const std::string a = argv[i];
     if (a == "--cloud" && i + 1 < argc) cloud_path = argv[++i];
+    else if (a == "--bag" && i + 1 < argc) bag_path = argv[++i];
+    else if (a == "--topic" && i + 1 < argc) topic = argv[++i];
     else if (a == "--yaml" && i + 1 < argc) yaml_path = argv[++i];
     else if (a == "--out" && i + 1 < argc) out_path = argv[++i];
     else if (a == "--solver" && i + 1 < argc) solver = argv[++i];
@@ -36,20 +41,35 @@ int main(int argc, char** argv) {
       return 2;
     }
   }
-  if (cloud_path.empty() || out_path.empty() || !have_click) {
-    std::fprintf(stderr, "usage: ilcc_corners --cloud frame.bin --click x y z [--yaml board.yaml] --out file.txt "
-                         "[--solver grid|reference] [--device N]\n");
+  if ((cloud_path.empty() == bag_path.empty()) || out_path.empty() || !have_click) {
+    std::fprintf(stderr, "usage: ilcc_corners (--cloud frame.bin | --bag file.bag [--topic /velodyne_points]) --click x y z "
+                         "[--yaml board.yaml] --out file.txt [--solver grid|reference] [--device N]\n");
     return 2;
   }
-  std::ifstream in(cloud_path, std::ios::binary | std::ios::ate);
-  if (!in.is_open()) {
-    std::fprintf(stderr, "can not open %s\n", cloud_path.c_str());
-    return 1;
+  myPointCloudPtr cloud(new myPointCloud);
+  if (!bag_path.empty()) {   // get_lidar_corners.cpp:136-164
+    uint32_t n = 0;
+    int32_t st = ilcc_bag_first_cloud(device < 0 ? 0 : device, bag_path.c_str(), topic.c_str(), nullptr, 0, &n);
+    if (st == ILCC_CAPACITY || st == ILCC_OK) {
+      cloud->resize(n);
+      st = ilcc_bag_first_cloud(device < 0 ? 0 : device, bag_path.c_str(), topic.c_str(),
+                                reinterpret_cast<float*>(cloud->data()), n, &n);
+    }
+    if (st != ILCC_OK) {
+      std::fprintf(stderr, "can't read lidar topic: %s\n", ilcc_last_error(nullptr));   // :157-161
+      return 1;
+    }
+  } else {
+    std::ifstream in(cloud_path, std::ios::binary | std::ios::ate);
+    if (!in.is_open()) {
+      std::fprintf(stderr, "can not open %s\n", cloud_path.c_str());
+      return 1;
+    }
+    const std::streamsize bytes = in.tellg();
+    in.seekg(0);
+    cloud->resize((size_t)bytes / sizeof(PointXYZI));
+    in.read(reinterpret_cast<char*>(cloud->data()), (std::streamsize)(cloud->size() * sizeof(PointXYZI)));
   }
-  const std::streamsize bytes = in.tellg();
-  in.seekg(0);
-  myPointCloudPtr cloud(new myPointCloud((size_t)bytes / sizeof(PointXYZI)));
-  in.read(reinterpret_cast<char*>(cloud->data()), (std::streamsize)(cloud->size() * sizeof(PointXYZI)));
 
   LidarCornersEst est(device, (uint32_t)cloud->size() + 1);
   est.params().solver = (solver == "reference") ? ILCC_SOLVER_REFERENCE_LOCAL : ILCC_SOLVER_GRID;

@@ -1,0 +1,212 @@
+"""rosbag / PointCloud2 ingestion.  The bag reader and message parser are host
+code (CPU tests); the field gather K0 is a HIP kernel (gpu tests), checked bit for bit against a
+numpy restatement of pcl::fromROSMsg's field mapping."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from lidar_camera_calibration_amd import _native as N
+from lidar_camera_calibration_amd import ingest
+
+import rosbag_writer as W
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PC2 = ("sensor_msgs/PointCloud2", W.POINTCLOUD2_MD5)
+
+
+def _cloud(n, seed):
+    rng = np.random.default_rng(seed)
+    return rng.normal(0, 5, (n, 4)).astype(np.float32)
+
+
+def _msg(xyzi, **kw):
+    a, fields, step = W.velodyne_points(xyzi)
+    return W.pointcloud2(a, fields, step, **kw)
+
+
+def from_ros_msg_numpy(raw: bytes, lay) -> np.ndarray:
+    """pcl::fromROSMsg restated: per point, memcpy of each matched FLOAT32 field; unmatched stay 0."""
+    data = np.frombuffer(raw, np.uint8, lay.data_bytes, lay.data_offset)
+    out = np.zeros((lay.height * lay.width, 4), np.float32)
+    for k, off in enumerate((lay.off_x, lay.off_y, lay.off_z, lay.off_intensity)):
+        if off == ingest.FIELD_ABSENT:
+            continue
+        idx = (np.arange(lay.height)[:, None] * lay.row_step + np.arange(lay.width)[None, :] * lay.point_step).reshape(-1)
+        b = np.stack([data[idx + off + j] for j in range(4)], 1)
+        out[:, k] = np.ascontiguousarray(b).view("<f4").reshape(-1)
+    return out
+
+
+def test_ingest_library_exports_every_declared_symbol():
+    import re
+    header = open(os.path.join(ROOT, "include", "ilcc_ingest.h")).read()
+    body = header[header.index('extern "C"'):]
+    declared = set(re.findall(r"\b(ilcc_[a-z0-9_]+)\s*\(", body))
+    assert declared == set(ingest.INGEST_EXPORTS)
+    lib = N.lib()
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_layout_struct_size():
+    import ctypes as C
+    assert C.sizeof(ingest.Layout) == 14 * 4 + 16 + 64
+
+
+@pytest.mark.parametrize("compression", ["none", "bz2", "lz4"])
+def test_first_message_in_time_order_across_chunks(tmp_path, compression):
+    a, b, c = _msg(_cloud(50, 1), seq=1), _msg(_cloud(60, 2), seq=2), _msg(_cloud(70, 3), seq=3)
+    bag = W.BagWriter(str(tmp_path / "t.bag"), compression)
+    # chunk order on disk is not time order; another topic and an Imu message on the lidar topic come first
+    bag.add_chunk([("/velodyne_points", *PC2, (100, 500), b), ("/other", *PC2, (1, 0), c)])
+    bag.add_chunk([("/velodyne_points", "sensor_msgs/Imu", "6a62c6daae103f4ff57a132d6f95cec2", (5, 0), b"junk"),
+                   ("/velodyne_points", *PC2, (100, 20), a)])
+    bag.add_chunk([("/velodyne_points", *PC2, (200, 0), c)])
+    bag.write()
+    got = ingest.bag_first_message(str(tmp_path / "t.bag"), "/velodyne_points")
+    assert got == a                      # earliest PointCloud2 on the topic; the Imu is skipped like instantiate<>() == NULL
+    assert ingest.bag_first_message(str(tmp_path / "t.bag"), "/other") == c
+    lay = ingest.parse_pointcloud2(got)
+    assert (lay.seq, lay.width, lay.height, lay.point_step) == (1, 50, 1, 32)
+    with pytest.raises(ingest.IngestError) as e:
+        ingest.bag_first_message(str(tmp_path / "t.bag"), "/nonesuch")
+    assert e.value.status == N.BAD_ARGUMENT
+
+
+def test_bad_bags(tmp_path):
+    p = tmp_path / "x.bag"
+    with pytest.raises(ingest.IngestError) as e:
+        ingest.bag_first_message(str(p), "/velodyne_points")
+    assert e.value.status == N.IO_ERROR
+    p.write_bytes(b"#ROSBAG V1.2\n" + b"\0" * 100)
+    with pytest.raises(ingest.IngestError):
+        ingest.bag_first_message(str(p), "/velodyne_points")
+    bag = W.BagWriter(str(p))
+    bag.add_chunk([("/velodyne_points", *PC2, (1, 0), _msg(_cloud(5, 1)))])
+    bag.write(indexed=False)
+    with pytest.raises(ingest.IngestError) as e:
+        ingest.bag_first_message(str(p), "/velodyne_points")
+    assert "unindexed" in str(e.value)
+    bag.write()
+    raw = p.read_bytes()
+    p.write_bytes(raw[:len(raw) - 40])          # truncated index section
+    with pytest.raises(ingest.IngestError):
+        ingest.bag_first_message(str(p), "/velodyne_points")
+
+
+def test_parse_layout_and_field_matching():
+    xyzi = _cloud(33, 4)
+    lay = ingest.parse_pointcloud2(_msg(xyzi, seq=9, stamp=(12, 34), frame_id="/velodyne"))
+    assert (lay.off_x, lay.off_y, lay.off_z, lay.off_intensity) == (0, 4, 8, 16)
+    assert (lay.stamp_sec, lay.stamp_nsec, lay.frame_id, lay.n_fields) == (12, 34, b"/velodyne", 5)
+    assert lay.data_bytes == 33 * 32 and lay.is_dense == 1 and lay.is_bigendian == 0
+    # an intensity field that is not FLOAT32 does not feed PointXYZI::intensity (pcl::FieldMatches)
+    dt = np.dtype({"names": ["x", "y", "z", "intensity"], "formats": ["<f4", "<f4", "<f4", "u1"], "offsets": [0, 4, 8, 12],
+                   "itemsize": 16})
+    a = np.zeros(4, dt)
+    m = W.pointcloud2(a, [("x", 0, 7, 1), ("y", 4, 7, 1), ("z", 8, 7, 1), ("intensity", 12, W.UINT8, 1)], 16)
+    lay = ingest.parse_pointcloud2(m)
+    assert lay.off_intensity == ingest.FIELD_ABSENT and lay.off_z == 8
+    for bad in (b"", m[:40], m[:-3]):
+        with pytest.raises(ingest.IngestError):
+            ingest.parse_pointcloud2(bad)
+    # a field that pokes outside point_step is refused
+    m2 = W.pointcloud2(a, [("x", 0, 7, 1), ("y", 4, 7, 1), ("z", 14, 7, 1)], 16)
+    with pytest.raises(ingest.IngestError):
+        ingest.parse_pointcloud2(m2)
+
+
+# ------------------------------------------------------------------------------------------ GPU
+def _unpack_gpu(msg, lay, misalign=0):
+    import torch
+    raw = np.frombuffer(msg, np.uint8, lay.data_bytes, lay.data_offset)
+    d_buf = torch.zeros(lay.data_bytes + 64, dtype=torch.uint8, device="cuda")
+    d_in = d_buf[misalign:misalign + lay.data_bytes]
+    d_in.copy_(torch.from_numpy(raw.copy()))
+    d_out = torch.full((lay.height * lay.width, 4), -7.0, dtype=torch.float32, device="cuda")
+    ingest.unpack_device(d_in.data_ptr(), lay, d_out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    return d_out.cpu().numpy()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 63, 1024, 1025, 28800])
+def test_k0_velodyne_layout_bit_exact(n):
+    xyzi = _cloud(n, n)
+    xyzi[::7, 0] = np.nan
+    xyzi[3::11, 3] = np.inf
+    msg = _msg(xyzi)
+    lay = ingest.parse_pointcloud2(msg)
+    got = _unpack_gpu(msg, lay)
+    want = from_ros_msg_numpy(msg, lay)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert np.array_equal(want.view(np.uint32), xyzi.view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_k0_generic_layouts_bit_exact():
+    rng = np.random.default_rng(8)
+    # (a) 16-ring organised cloud with row padding; (b) point_step 22 with odd offsets and no intensity;
+    # (c) aligned layout on a misaligned device pointer; (d) xyz + uint8 intensity (unmatched -> 0); (e) 48-byte points
+    cases = []
+    xyzi = _cloud(16 * 90, 5)
+    a, fields, step = W.velodyne_points(xyzi)
+    cases.append((W.pointcloud2(a, fields, step, height=16, row_pad=24), 0))
+    raw = rng.integers(0, 256, (777, 22), dtype=np.uint8)
+    cases.append((W.pointcloud2(raw, [("z", 1, 7, 1), ("x", 9, 7, 1), ("y", 17, 7, 1)], 22), 0))
+    cases.append((_msg(_cloud(2000, 6)), 4))
+    raw = rng.integers(0, 256, (500, 16), dtype=np.uint8)
+    cases.append((W.pointcloud2(raw, [("x", 0, 7, 1), ("y", 4, 7, 1), ("z", 8, 7, 1), ("intensity", 12, W.UINT8, 1)], 16), 0))
+    raw = rng.integers(0, 256, (3000, 48), dtype=np.uint8)
+    cases.append((W.pointcloud2(raw, [("x", 32, 7, 1), ("y", 4, 7, 1), ("z", 44, 7, 1), ("intensity", 20, 7, 1)], 48), 0))
+    for msg, mis in cases:
+        lay = ingest.parse_pointcloud2(msg)
+        got = _unpack_gpu(msg, lay, mis)
+        want = from_ros_msg_numpy(msg, lay)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_bag_to_corners_end_to_end(tmp_path):
+    """get_lidar_corners.cpp:130-204 without ROS: bag -> first cloud -> corner path -> same corners as from the array."""
+    from lidar_camera_calibration_amd import LidarCornersBatch, synth
+    board = synth.Board()
+    pose = synth.pose_from_fixture(2)
+    cloud = synth.make_frame(synth.vlp16(), board, pose, 77)
+    click = synth.make_click(pose, 77)
+    bag = W.BagWriter(str(tmp_path / "20181101_1.bag"), "bz2")
+    bag.add_chunk([("/velodyne_points", *PC2, (10, 0), _msg(cloud)), ("/velodyne_points", *PC2, (11, 0), _msg(cloud[::-1]))])
+    bag.write()
+    got = ingest.bag_first_cloud(str(tmp_path / "20181101_1.bag"), "/velodyne_points")
+    assert np.array_equal(got.view(np.uint32), cloud.view(np.uint32))
+    est = LidarCornersBatch(1, len(cloud), N.default_params(), device=0)
+    r_bag = est.extract(got[None], click[None])[0]
+    r_arr = est.extract(cloud[None], click[None])[0]
+    assert r_bag.status == 0 and np.array_equal(r_bag.corners_array(), r_arr.corners_array())
+    est.close()
+
+
+@pytest.mark.gpu
+def test_k0_throughput_report():
+    """Not a pass/fail on speed: prints the achieved HBM rate of K0 for a 128-message batch."""
+    import torch
+    n = 128 * 28800
+    d_in = torch.randint(0, 255, (n * 32,), dtype=torch.uint8, device="cuda")
+    d_out = torch.empty((n, 4), dtype=torch.float32, device="cuda")
+    lay = ingest.parse_pointcloud2(_msg(_cloud(8, 1)))
+    lay.width, lay.height, lay.row_step, lay.data_bytes = 28800, 128, 28800 * 32, n * 32
+    s = torch.cuda.current_stream().cuda_stream
+    for _ in range(3):
+        ingest.unpack_device(d_in.data_ptr(), lay, d_out.data_ptr(), s)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        ingest.unpack_device(d_in.data_ptr(), lay, d_out.data_ptr(), s)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 20
+    gbps = n * 48 / ms / 1e6
+    print("K0 unpack: %.3f ms per 128 x 28800 points, %.0f GB/s (algorithmic 48 B/point)" % (ms, gbps))
+    assert gbps > 500
