@@ -116,6 +116,12 @@ def lib():
         L.orc_format_float.restype = C.c_int32
         L.orc_solve_pose_3d2d.argtypes = [dp, dp, C.c_int32, dp, dp, dp, dp]
         L.orc_solve_pose_3d2d.restype = C.c_int32
+        L.orc_hsv_to_rgb.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_uint8)]
+        L.orc_hsv_to_rgb.restype = None
+        L.orc_project_intensity.argtypes = [fp, C.c_int32, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_void_p]
+        L.orc_project_intensity.restype = C.c_int32
+        L.orc_colourise.argtypes = [fp, C.c_int32, C.c_void_p, C.c_double, C.POINTER(C.c_uint8), C.c_uint32, fp]
+        L.orc_colourise.restype = C.c_int32
         _lib = L
     return _lib
 
@@ -278,3 +284,29 @@ def solve_pose_3d2d(pts3d, pts2d, camera, r0=(0.0, 0.0, 0.0), t0=(0.0, 0.0, 0.0)
     fc = C.c_double(0)
     it = lib().orc_solve_pose_3d2d(_d(p3)[1], _d(p2)[1], len(p3), _d(cam)[1], _d(r)[1], _d(t)[1], C.byref(fc))
     return r, t, fc.value, it
+
+
+HIT_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("r", "u1"), ("g", "u1"), ("b", "u1"), ("pad", "u1"), ("index", "<u4")])
+
+
+def hsv_to_rgb(h, s=100, v=100):
+    out = (C.c_uint8 * 3)()
+    lib().orc_hsv_to_rgb(int(h), int(s), int(v), out)
+    return tuple(out)
+
+
+def project_intensity(xyzi, cam, dis=50.0, lo=0.0, hi=60.0):
+    """cam: any ctypes struct laid out like orc_camera_model (the product's CameraModel is)."""
+    a, ap = _f(xyzi)
+    hits = np.zeros(len(a), HIT_DTYPE)
+    m = lib().orc_project_intensity(ap, len(a), C.addressof(cam), dis, lo, hi, hits.ctypes.data)
+    return hits[:m]
+
+
+def colourise(xyzi, cam, image_bgr, dis=50.0):
+    a, ap = _f(xyzi)
+    img = np.ascontiguousarray(image_bgr, dtype=np.uint8)
+    out = np.zeros((len(a), 4), np.float32)
+    m = lib().orc_colourise(ap, len(a), C.addressof(cam), dis, img.ctypes.data_as(C.POINTER(C.c_uint8)), img.strides[0],
+                            out.ctypes.data_as(C.POINTER(C.c_float)))
+    return out[:m]

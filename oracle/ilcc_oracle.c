@@ -1544,3 +1544,85 @@ done:
 int32_t orc_format_float(float v, char* buf, int32_t cap) {
   return (int32_t)snprintf(buf, (size_t)cap, "%g", (double)v);
 }
+
+
+/* ------------------------------------------------------------------------- */
+/* f4: LiDAR -> image projection (after calibration)                          */
+/* ------------------------------------------------------------------------- */
+
+/* ImageCornersEst::spaceToPlane (src/ImageCornersEst.cpp:135-155) */
+static int space_to_plane(const orc_camera_model* c, const float* q, double dis, double* cu, double* cv) {
+  const double X = (double)q[0], Y = (double)q[1], Z = (double)q[2];
+  const double pc0 = c->R[0] * X + c->R[1] * Y + c->R[2] * Z + c->t[0];
+  const double pc1 = c->R[3] * X + c->R[4] * Y + c->R[5] * Z + c->t[1];
+  const double pc2 = c->R[6] * X + c->R[7] * Y + c->R[8] * Z + c->t[2];
+  if (pc2 < 0 || pc2 > dis) return 0;
+  const double u = pc0 / pc2, v = pc1 / pc2;
+  *cu = c->fx * u + c->cx;
+  *cv = c->fy * v + c->cy;
+  return (*cu > 0 && *cu < (double)c->width && *cv > 0 && *cv < (double)c->height) ? 1 : 0;
+}
+
+/* what `unsigned char = float` / `int = double` compile to on x86-64 (cvttss2si / cvttsd2si) */
+static uint8_t to_u8(float v) { return (uint8_t)(int32_t)v; }
+static int32_t x86_d2i(double v) {
+  return (v > -2147483649.0 && v < 2147483648.0) ? (int32_t)v : (int32_t)0x80000000;
+}
+
+/* ImageCornersEst::HSVtoRGB (src/ImageCornersEst.cpp:373-428) */
+void orc_hsv_to_rgb(int32_t h, int32_t s, int32_t v, uint8_t rgb[3]) {
+  const float rgb_max = v * 2.55f;
+  const float rgb_min = rgb_max * (100 - s) / 100.0f;
+  const int32_t i = h / 60;
+  const int32_t difs = h % 60;
+  const float adj = (rgb_max - rgb_min) * difs / 60.0f;
+  switch (i) {
+    case 0: rgb[0] = to_u8(rgb_max); rgb[1] = to_u8(rgb_min + adj); rgb[2] = to_u8(rgb_min); break;
+    case 1: rgb[0] = to_u8(rgb_max - adj); rgb[1] = to_u8(rgb_max); rgb[2] = to_u8(rgb_min); break;
+    case 2: rgb[0] = to_u8(rgb_min); rgb[1] = to_u8(rgb_max); rgb[2] = to_u8(rgb_min + adj); break;
+    case 3: rgb[0] = to_u8(rgb_min); rgb[1] = to_u8(rgb_max - adj); rgb[2] = to_u8(rgb_max); break;
+    case 4: rgb[0] = to_u8(rgb_min + adj); rgb[1] = to_u8(rgb_min); rgb[2] = to_u8(rgb_max); break;
+    default: rgb[0] = to_u8(rgb_max); rgb[1] = to_u8(rgb_min); rgb[2] = to_u8(rgb_max - adj); break;
+  }
+}
+
+/* test/pcd2image.cpp:56-82 without the drawing: one record per accepted point */
+int32_t orc_project_intensity(const float* xyzi, int32_t n, const orc_camera_model* cam, double dis, double lo,
+                              double hi, orc_pixel_hit* hits) {
+  int32_t m = 0;
+  for (int32_t i = 0; i < n; ++i) {
+    double cu, cv;
+    if (!space_to_plane(cam, xyzi + 4 * i, dis, &cu, &cv)) continue;
+    const double h = ((double)xyzi[4 * i + 3] - lo) / (hi - lo) * 255;
+    uint8_t rgb[3];
+    orc_hsv_to_rgb(x86_d2i(h), 100, 100, rgb);
+    hits[m].x = (int32_t)cu;
+    hits[m].y = (int32_t)cv;
+    hits[m].r = rgb[0];
+    hits[m].g = rgb[1];
+    hits[m].b = rgb[2];
+    hits[m].pad = 0;
+    hits[m].index = (uint32_t)i;
+    ++m;
+  }
+  return m;
+}
+
+/* test/rgblidar.cpp:50-74: XYZ + packed rgb of the BGR image at the truncated pixel */
+int32_t orc_colourise(const float* xyzi, int32_t n, const orc_camera_model* cam, double dis, const uint8_t* image_bgr,
+                      uint32_t image_step, float* xyzrgb) {
+  int32_t m = 0;
+  for (int32_t i = 0; i < n; ++i) {
+    double cu, cv;
+    if (!space_to_plane(cam, xyzi + 4 * i, dis, &cu, &cv)) continue;
+    const int32_t x = (int32_t)cu, y = (int32_t)cv;
+    const uint8_t* p = image_bgr + (size_t)y * image_step + (size_t)x * 3;
+    const uint32_t rgb = ((uint32_t)p[2] << 16) | ((uint32_t)p[1] << 8) | (uint32_t)p[0];
+    xyzrgb[4 * m + 0] = xyzi[4 * i + 0];
+    xyzrgb[4 * m + 1] = xyzi[4 * i + 1];
+    xyzrgb[4 * m + 2] = xyzi[4 * i + 2];
+    memcpy(&xyzrgb[4 * m + 3], &rgb, 4);
+    ++m;
+  }
+  return m;
+}

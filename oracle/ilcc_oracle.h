@@ -176,6 +176,24 @@ int32_t orc_format_float(float v, char* buf, int32_t cap);
 int32_t orc_solve_pose_3d2d(const double* pts3d, const double* pts2d, int32_t n, const double camera[4],
                             double r[3], double t[3], double* final_cost);
 
+/* f4 projection (after calibration): spaceToPlane + HSVtoRGB + the per-point loops of
+ * test/pcd2image.cpp:56-82 and test/rgblidar.cpp:50-74 (no drawing). */
+typedef struct orc_camera_model {
+  double R[9], t[3];
+  double fx, cx, fy, cy;
+  int32_t width, height;
+} orc_camera_model;
+typedef struct orc_pixel_hit {
+  int32_t x, y;
+  uint8_t r, g, b, pad;
+  uint32_t index;
+} orc_pixel_hit;
+void orc_hsv_to_rgb(int32_t h, int32_t s, int32_t v, uint8_t rgb[3]);
+int32_t orc_project_intensity(const float* xyzi, int32_t n, const orc_camera_model* cam, double dis, double lo,
+                              double hi, orc_pixel_hit* hits);
+int32_t orc_colourise(const float* xyzi, int32_t n, const orc_camera_model* cam, double dis, const uint8_t* image_bgr,
+                      uint32_t image_step, float* xyzrgb);
+
 #ifdef __cplusplus
 }
 #endif
