@@ -68,19 +68,23 @@ def main():
     backend = os.environ.get("ILCC_BENCH_BACKEND", "nccl")
     if os.environ.get("ILCC_BENCH_SINGLE_DEVICE"):
         local_rank = 0
+    # ILCC_BENCH_FORCE_DIST=1: take the N > 1 code path (process group, per-step gather, barriers) even with
+    # one rank, so that the RCCL side can be exercised on a 1-GPU box
+    dist_on = world > 1 or bool(os.environ.get("ILCC_BENCH_FORCE_DIST"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: libilcc_hip has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     rec_dev = dev if backend == "nccl" else torch.device("cpu")
-    if world > 1:
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group(backend=backend, rank=rank, world_size=world,
                                 **({"device_id": dev} if backend == "nccl" else {}))
 
     from lidar_camera_calibration_amd import LidarCornersBatch, synth
     from lidar_camera_calibration_amd import _native as N
-    from lidar_camera_calibration_amd.sharding import RECORD_FLOATS, gather_records, pack_records
+    from lidar_camera_calibration_amd.sharding import gather_records
 
     F = args.frames_per_gpu
     board = synth.Board()
@@ -97,14 +101,26 @@ def main():
 
     pending = []   # the previous step's gather, still in flight (one RCCL gather per step)
 
+    # the path's only collective ships fixed-size corner records.  They are packed ON the GPU
+    # (ilcc_wait_records_device) into one of a few rotating device buffers and handed to RCCL from there:
+    # no host round trip, nothing on the null stream
+    rec_w = 16 + 3 * board.n_corners
+    rec_bufs = [torch.zeros((F, rec_w), dtype=torch.float32, device=dev) for _ in range(4)] if dist_on else []
+    side = torch.cuda.Stream(device=dev) if dist_on else None
+    step_no = [0]
+
     def finish(ticket):
-        res = est.wait(ticket)
-        if world > 1:   # the path's only collective: one gather of this step's corner records
-            rec = torch.from_numpy(pack_records(res, F, board.n_corners)).to(rec_dev)
+        if not dist_on:
+            return est.wait(ticket)
+        buf = rec_bufs[step_no[0] % len(rec_bufs)]   # last used by the gather issued 4 steps ago, long complete
+        step_no[0] += 1
+        res = est.wait(ticket, buf.data_ptr(), board.n_corners)
+        with torch.cuda.stream(side):           # never the null stream: it would serialise with the batches in flight
+            rec = buf if rec_dev.type == "cuda" else buf.cpu()      # (gloo test hook: CPU tensors)
             while pending:                       # at most one collective outstanding
                 w, _ = pending.pop(0)
                 w.wait()
-            pending.append(gather_records(rec, world, rank, async_op=True))
+            pending.append(gather_records(rec, world, rank, async_op=True, force_collective=dist_on))
         return res
 
     def run(n_steps):
@@ -120,23 +136,30 @@ def main():
         gathered = None
         while pending:
             w, bufs = pending.pop(0)
-            if w is not None:
-                w.wait()
-            gathered = torch.cat(bufs, 0) if bufs is not None else None
+            if side is not None:
+                with torch.cuda.stream(side):
+                    if w is not None:
+                        w.wait()
+                    gathered = torch.cat(bufs, 0) if bufs is not None else None
+                side.synchronize()
+            else:
+                if w is not None:
+                    w.wait()
+                gathered = torch.cat(bufs, 0) if bufs is not None else None
         return last, gathered
 
     run(args.warmup)
     est.reset_timing()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     t0 = time.perf_counter()
     res, gathered = run(args.steps)
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         t = torch.tensor([elapsed], dtype=torch.float64, device=rec_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -233,7 +256,7 @@ def main():
             out["cpu_baseline"]["gpu_reference_local_mode_frames_per_s_single_call"] = F / t_ref
         print(json.dumps(out), flush=True)
     est.close()
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -180,6 +180,12 @@ int32_t ilcc_extract_batch_device(ilcc_handle* h, const float* d_xyzi, const uin
 int32_t ilcc_submit_batch_device(ilcc_handle* h, const float* d_xyzi, const uint64_t* offsets,
                                  uint32_t n_frames, const float* d_clicks, int32_t* ticket);
 int32_t ilcc_wait(ilcc_handle* h, int32_t ticket, ilcc_result* out);
+/* ilcc_wait that also leaves, in device memory, the fixed-size records the multi-GPU gather ships
+ * (one collective of corner records per step): d_records[n_frames][16 + 3*n_corners]
+ * floats = status, n_corners, phase, grid_index, iters_a, iters_b, cost_a, cost_b, sel_cost, theta,
+ * ty, tz, n_plane, n_black, n_white, 0, then x y z per corner (zero beyond the frame's n_corners).
+ * Complete on return, so the caller can hand the buffer to RCCL on any stream. */
+int32_t ilcc_wait_records_device(ilcc_handle* h, int32_t ticket, ilcc_result* out, void* d_records, uint32_t n_corners);
 
 /* LidarCornersEst::get_chessboard_by_point (LidarCornersEst.cpp:72-115), the front half of the path as
  * the online node uses it (ilcc2/test/lidar_chessboard_online.cpp:91-101): NO ROI crop, Euclidean

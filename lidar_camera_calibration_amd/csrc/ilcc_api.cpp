@@ -362,8 +362,9 @@ int32_t enqueue(ilcc_handle* h, int si, const float4* d_xyzi, const uint64_t* of
 }
 
 // wait for the slot's batch, hand the records over, account the timing
-int32_t finish(ilcc_handle* h, int si, ilcc_result* out) {
+int32_t finish(ilcc_handle* h, int si, ilcc_result* out, float* d_records = nullptr, uint32_t n_corners = 0) {
   Slot& sl = h->slots[si];
+  if (d_records) launch_pack_records(sl.d_res, sl.n_frames, n_corners, d_records, sl.stream);   // same stream: after K7
   HIP_TRY(h, hipStreamSynchronize(sl.stream));
   sl.busy = false;
   h->last_slot = si;
@@ -632,6 +633,15 @@ int32_t ilcc_wait(ilcc_handle* h, int32_t ticket, ilcc_result* out) {
   }
   HIP_TRY(h, hipSetDevice(h->device));
   return finish(h, ticket, out);
+}
+
+int32_t ilcc_wait_records_device(ilcc_handle* h, int32_t ticket, ilcc_result* out, void* d_records, uint32_t n_corners) {
+  if (!h || !out || !d_records || n_corners > ILCC_MAX_CORNERS || ticket < 0 || ticket >= kSlots || !h->slots[ticket].busy) {
+    if (h) h->err = "ilcc_wait_records_device: bad argument or no batch in flight under this ticket";
+    return ILCC_BAD_ARGUMENT;
+  }
+  HIP_TRY(h, hipSetDevice(h->device));
+  return finish(h, ticket, out, static_cast<float*>(d_records), n_corners);
 }
 
 int32_t ilcc_extract_batch_device(ilcc_handle* h, const float* d_xyzi, const uint64_t* offsets,

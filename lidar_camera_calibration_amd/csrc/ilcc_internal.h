@@ -143,6 +143,7 @@ void launch_plane_frame_hist(const Ctx& c, hipStream_t s);
 void launch_grid_cost(const Ctx& c, hipStream_t s, int32_t use_oob, float* cost_volume /*nullable*/,
                       bool prune);
 void launch_refine_corners(const Ctx& c, hipStream_t s);
+void launch_pack_records(const ilcc_result* d_res, uint32_t n_frames, uint32_t n_corners, float* d_out, hipStream_t s);
 // stand-alone local solve on the labelled points of frame 0 (test entry)
 void launch_local_solve(const Ctx& c, hipStream_t s, int32_t tlw, int32_t use_oob, double* theta_t,
                         double* cost_iters /*[2]: cost, iterations*/);

@@ -721,4 +721,46 @@ void launch_local_solve(const Ctx& c, hipStream_t s, int32_t tlw, int32_t use_oo
   hipLaunchKernelGGL(k7_local_solve_test, dim3(1), dim3(kSolveThreads), 0, s, c, tlw, use_oob, theta_t, cost_iters);
 }
 
+// K9 pack_records: ilcc_result[] (device) -> fixed-size float records [n_frames, 16 + 3 * n_corners]
+// for the path's single collective (the gather of corner records): the records go from
+// this GPU's HBM straight into RCCL, no host round trip.  Layout = sharding.pack_records.
+__global__ __launch_bounds__(128) void k9_pack_records(const ilcc_result* __restrict__ res, uint32_t n_corners,
+                                                       float* __restrict__ out) {
+  const ilcc_result& r = res[blockIdx.x];
+  const uint32_t width = 16u + 3u * n_corners;
+  float* o = out + (uint64_t)blockIdx.x * width;
+  const uint32_t have = (uint32_t)(r.n_corners < 0 ? 0 : r.n_corners);
+  for (uint32_t k = threadIdx.x; k < width; k += blockDim.x) {
+    float v = 0.f;
+    if (k >= 16u) {
+      const uint32_t c = k - 16u;
+      v = (c < 3u * have) ? r.corners[c] : 0.f;
+    } else {
+      switch (k) {
+        case 0: v = (float)r.status; break;
+        case 1: v = (float)r.n_corners; break;
+        case 2: v = (float)r.phase; break;
+        case 3: v = (float)r.grid_index; break;
+        case 4: v = (float)r.iters_a; break;
+        case 5: v = (float)r.iters_b; break;
+        case 6: v = (float)r.cost_a; break;
+        case 7: v = (float)r.cost_b; break;
+        case 8: v = (float)r.sel_cost; break;
+        case 9: v = (float)r.theta_t[0]; break;
+        case 10: v = (float)r.theta_t[1]; break;
+        case 11: v = (float)r.theta_t[2]; break;
+        case 12: v = (float)r.n_plane; break;
+        case 13: v = (float)r.n_black; break;
+        case 14: v = (float)r.n_white; break;
+        default: v = 0.f;
+      }
+    }
+    o[k] = v;
+  }
+}
+
+void launch_pack_records(const ilcc_result* d_res, uint32_t n_frames, uint32_t n_corners, float* d_out, hipStream_t s) {
+  if (n_frames) hipLaunchKernelGGL(k9_pack_records, dim3(n_frames), dim3(128), 0, s, d_res, n_corners, d_out);
+}
+
 }  // namespace ilcc

@@ -261,10 +261,15 @@ class LidarCornersBatch:
             raise IlccError(st, self._err())
         return ticket.value, n_frames
 
-    def wait(self, ticket):
+    def wait(self, ticket, d_records_ptr: Optional[int] = None, n_corners: int = 0):
+        """Results of a submitted batch.  With ``d_records_ptr`` (device memory, n_frames x (16 + 3*n_corners)
+        float32) the fixed-size gather records are also packed on the GPU (``ilcc_wait_records_device``)."""
         t, n_frames = ticket
         res = (N.Result * n_frames)()
-        st = self._lib.ilcc_wait(self._h, t, res)
+        if d_records_ptr is not None:
+            st = self._lib.ilcc_wait_records_device(self._h, t, res, C.c_void_p(d_records_ptr), n_corners)
+        else:
+            st = self._lib.ilcc_wait(self._h, t, res)
         if st != N.OK:
             raise IlccError(st, self._err())
         return res

@@ -85,14 +85,14 @@ def unpack_corners(records: np.ndarray) -> List[np.ndarray]:
     return out
 
 
-def gather_records(local, world: int, rank: int, dst: int = 0, async_op: bool = False):
+def gather_records(local, world: int, rank: int, dst: int = 0, async_op: bool = False, force_collective: bool = False):
     """One ``torch.distributed.gather`` of this rank's [F_local, R] record tensor to ``dst``.
     Every rank must pass the same shape (pad the last shard).  Returns [world*F_local, R] on dst
     (None elsewhere); with ``async_op`` returns ``(work, bufs)`` so the caller can overlap the
     collective with the next batch and ``work.wait()`` later."""
     import torch
     import torch.distributed as dist
-    if world == 1:
+    if world == 1 and not force_collective:   # (force_collective: run the 1-rank collective anyway, a bench test hook)
         return (None, [local]) if async_op else local
     bufs = [torch.empty_like(local) for _ in range(world)] if rank == dst else None
     work = dist.gather(local, gather_list=bufs, dst=dst, async_op=async_op)

@@ -441,3 +441,29 @@ def test_online_caller_get_chessboard_by_point(ob):
     ok2, out2 = m.get_chessboard_by_point(clouds[4], pts[4])
     assert ok2 == (res[4].status == 0) and len(out2) == res[4].n_plane
     m.close()
+
+
+@pytest.mark.gpu
+def test_device_records_equal_host_packing():
+    """ilcc_wait_records_device (K9: records packed on the GPU for the RCCL gather) == sharding.pack_records
+    of the same results, including failed frames (zero corners) -- SURVEY.md 8e."""
+    import torch
+    from lidar_camera_calibration_amd import LidarCornersBatch, synth
+    from lidar_camera_calibration_amd import _native as N
+    from lidar_camera_calibration_amd.sharding import pack_records, record_floats
+    board, lidar = synth.Board(), synth.vlp16()
+    F = 12
+    clouds, clicks, _, _ = synth.make_batch(F, lidar, board, seed=321)
+    clicks[3] = (50.0, 50.0, 50.0)          # nothing in the ROI
+    clouds[7, :, 3] = 40.0                  # flat intensity -> degenerate histogram
+    est = LidarCornersBatch(F, lidar.n_points, N.default_params(), device=0)
+    d_clouds = torch.from_numpy(clouds).cuda()
+    d_clicks = torch.from_numpy(clicks).cuda()
+    d_rec = torch.full((F, record_floats(board.n_corners)), -3.0, dtype=torch.float32, device="cuda")
+    t = est.submit_device(d_clouds.data_ptr(), F, lidar.n_points, d_clicks.data_ptr())
+    res = est.wait(t, d_rec.data_ptr(), board.n_corners)
+    want = pack_records(res, F, board.n_corners)
+    got = d_rec.cpu().numpy()
+    assert res[3].status != 0 and res[7].status != 0 and res[0].status == 0
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    est.close()
