@@ -35,15 +35,15 @@ sys.path.insert(0, ROOT)
 
 BYTES_PER_FRAME_CFG2 = 16 * 28800 + 12 * 35 + 64   # 461 284 B
 HBM_PEAK_GBPS = 8000.0                              # MI355X_MICROARCH.md: 8 TB/s spec
-# HBM bytes of the K6 stage (seed + full launch) for the default 128-frame step, from the PMC passes
-# committed in profiles/r01_hbm_traffic_pmc.csv: 2 x (5145254 + 5549811) + 508685 + 348941
-K6_HBM_TRAFFIC_BYTES_128 = 22247756
+# HBM bytes of the K6 stage (seed + refinement + full launch) for the default 128-frame step, from the PMC
+# passes committed in profiles/r01g_k6_pmc.csv: 6302813 + 10141080 + 10195261
+K6_HBM_TRAFFIC_BYTES_128 = 26639154
 # VALU issue peak: 256 CU x 4 SIMD x 32 lanes x 2.4 GHz = 78.6 T lane-instructions/s
 # (= the 157.3 TFLOP/s fp32 vector peak of MI355X_MICROARCH.md when every instruction is an FMA)
 VALU_ISSUE_PEAK_T = 78.6
 # VALU instructions per (point, candidate) evaluation of k6_grid_cost (both phases), counted from
-# the gfx950 ISA of the inner loop: 232 per 64-point x 16-candidate trip (DESIGN.md "K6")
-K6_VALU_OPS_PER_EVAL = 14.5
+# the gfx950 ISA of the inner loop: 110 per 4 points of a lane (DESIGN.md "K6")
+K6_VALU_OPS_PER_EVAL = 27.5
 
 
 def main():
@@ -222,14 +222,16 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": K6_HBM_TRAFFIC_BYTES_128 if (F == 128 and lidar.n_points == 28800) else None,
-                "traffic_note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (profiles/r01_hbm_traffic_pmc.csv): "
-                                "(2 x FETCH_SIZE + WRITE_SIZE) x 1024 summed over the stage's two launches (seed + full pass)",
+                "traffic_note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (profiles/r01g_k6_pmc.csv): "
+                                "(2 x FETCH_SIZE + WRITE_SIZE) x 1024 summed over the stage's three launches "
+                                "(seed, refinement, full pass)",
                 "launch_ms": k6_ms,
                 "algorithmic_bytes_per_launch": k6_bytes,
                 "note": "k6_grid_cost is VALU-bound by construction (points staged once in LDS, ~1e8 nominal "
                         "point-candidate evaluations per frame, no MFMA); the HBM fraction is reported because "
-                        "BASELINE.json asks for it.  launch = the K6 stage of one step (seed launch + full launch), "
-                        "timed by HIP events on the library's stream",
+                        "BASELINE.json asks for it.  launch = the K6 stage of one step (seed + refinement + full launch), "
+                        "timed by HIP events on the library's stream (the wait for the previous batch's full pass "
+                        "between the refinement and the full launch is excluded)",
                 "valu": {"evals_executed_per_launch": evals_per_launch,
                          "evals_nominal_per_launch": evals_nominal,
                          "executed_fraction": evals_per_launch / evals_nominal if evals_nominal else None,

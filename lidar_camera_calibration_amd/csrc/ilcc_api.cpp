@@ -21,7 +21,7 @@ constexpr int kSlots = 3;   // batches in flight per handle (submit/wait); slot 
 // One in-flight batch: its own stream, events, stage buffers and pinned result staging.
 struct Slot {
   hipStream_t stream = nullptr;
-  hipEvent_t ev[8]{};
+  hipEvent_t ev[10]{};   // 0..6 stage boundaries; 7, 8: end of K6's seed + refinement passes / start of its full pass
   hipEvent_t k6_done = nullptr;
   bool allocated = false;
   // device buffers
@@ -34,7 +34,7 @@ struct Slot {
   uint8_t *d_lab = nullptr, *d_cls = nullptr;
   uint32_t *d_nlab = nullptr, *d_counts = nullptr, *d_parent = nullptr, *d_count = nullptr;
   uint32_t *d_hash_head = nullptr, *d_hash_next = nullptr;
-  GridPartial *d_partial = nullptr, *d_partial2 = nullptr;
+  GridPartial *d_partial = nullptr, *d_partial2 = nullptr, *d_partial3 = nullptr;
   SolveRec* d_solverec = nullptr;
   uint32_t* d_bound = nullptr;
   unsigned long long* d_iters = nullptr;
@@ -63,7 +63,8 @@ struct ilcc_handle {
   // decimated subset of the same tables: seeding pass of K6's branch and bound
   float *d_cth2 = nullptr, *d_sth2 = nullptr, *d_ay2 = nullptr, *d_az2 = nullptr;
   int32_t n_th2 = 0, n_ty2 = 0, n_tz2 = 0, seed_stride_th = 12, seed_stride_t = 2;
-  bool seed_stride_env = false;
+  bool seed_stride_env = false, seed_stride_t_env = false;
+  bool refine_pass = true;   // (experiment hook: ILCC_K6_REFINE=0 skips the refinement pass)
   // (experiment hooks: ILCC_SEED_STRIDE_TH / ILCC_SEED_STRIDE_T override the seed decimation)
   double* d_solve = nullptr;   // 3 theta_t + 2 (cost, iterations) for the test entry
   uint32_t grid_lds_points = 2048;
@@ -139,10 +140,13 @@ int32_t upload_tables(ilcc_handle* h) {
   HIP_TRY(h, hipMemcpyAsync(h->d_sth, sth.data(), sizeof(float) * p.n_th, hipMemcpyHostToDevice, st));
   HIP_TRY(h, hipMemcpyAsync(h->d_ay, ay.data(), sizeof(float) * p.n_ty, hipMemcpyHostToDevice, st));
   HIP_TRY(h, hipMemcpyAsync(h->d_az, az.data(), sizeof(float) * p.n_tz, hipMemcpyHostToDevice, st));
-  // seed subset: ~5 thetas (centred, so theta = 0 is one of them for a symmetric grid), every 2nd ty / tz --
-  // the same float values as the full tables.  Measured on the 128-frame VLP-16 batch: theta stride 12 of 61
-  // minimises seed + full time (4: 1.10 ms, 8: 0.98, 12: 0.89, 16: 0.92); denser ty/tz seeds do not pay.
+  // seed subset: ~5 thetas (centred, so theta = 0 is one of them for a symmetric grid) x 8 x 8 translations --
+  // the same float values as the full tables.  The seed only has to land in the right basin: the refinement
+  // pass then evaluates everything around its argmin (theta +- half a seed stride, 8 x 8 translations), which
+  // on the synthetic VLP-16 set yields the exact grid minimum as the bound in 46 of 46 frames (seed alone:
+  // 3-20 x the minimum).  Measured on the 128-frame batch (K6 ms): translation stride 2: 1.05, 4: 0.91, 5: 0.83.
   if (!h->seed_stride_env) h->seed_stride_th = std::max(2, p.n_th / 5);
+  if (!h->seed_stride_t_env) h->seed_stride_t = std::max(1, std::min(p.n_ty, p.n_tz) / 8);
   std::vector<float> cth2, sth2, ay2, az2;
   for (int k = h->seed_stride_th / 2; k < p.n_th; k += h->seed_stride_th) {
     cth2.push_back(cth[k]);
@@ -165,7 +169,7 @@ int32_t upload_tables(ilcc_handle* h) {
 
 void free_slot(Slot& sl) {
   void* bufs[] = {sl.d_xyzi, sl.d_clicks, sl.d_off, sl.d_res, sl.d_roi, sl.d_cluster, sl.d_board, sl.d_pca, sl.d_optim,
-                  sl.d_yz, sl.d_lab, sl.d_cls, sl.d_nlab, sl.d_counts, sl.d_parent, sl.d_count, sl.d_hash_head, sl.d_hash_next, sl.d_partial, sl.d_partial2,
+                  sl.d_yz, sl.d_lab, sl.d_cls, sl.d_nlab, sl.d_counts, sl.d_parent, sl.d_count, sl.d_hash_head, sl.d_hash_next, sl.d_partial, sl.d_partial2, sl.d_partial3,
                   sl.d_solverec, sl.d_bound, sl.d_iters};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -206,6 +210,7 @@ int32_t alloc_slot(ilcc_handle* h, Slot& sl) {
   ALLOC(sl.d_hash_next, sizeof(uint32_t) * np);
   ALLOC(sl.d_partial, sizeof(GridPartial) * (size_t)mf * h->max_theta);
   ALLOC(sl.d_partial2, sizeof(GridPartial) * (size_t)mf * h->max_theta);
+  ALLOC(sl.d_partial3, sizeof(GridPartial) * (size_t)mf * h->max_theta);
   ALLOC(sl.d_solverec, sizeof(SolveRec) * 2 * (size_t)mf);
   ALLOC(sl.d_bound, sizeof(uint32_t) * mf);
   ALLOC(sl.d_iters, sizeof(unsigned long long) * kIterSlots);
@@ -249,6 +254,9 @@ Ctx make_ctx(ilcc_handle* h, Slot& sl, const float4* d_xyzi, const float* d_clic
   c.seed_blocks = 0;
   c.seed_n_ty = c.seed_n_tz = 1;
   c.seed_stride_t = 1;
+  c.seed_stride_th = 1;
+  c.seed_off_th = 0;
+  c.refine_radius_th = 0;
   c.cth = h->d_cth;
   c.sth = h->d_sth;
   c.ay = h->d_ay;
@@ -318,10 +326,6 @@ int32_t enqueue(ilcc_handle* h, int si, const float4* d_xyzi, const uint64_t* of
   sl.grid = !front_only && h->p.solver == ILCC_SOLVER_GRID;
   if (sl.grid) {
     HIP_TRY(h, hipMemsetAsync(sl.d_iters, 0, sizeof(unsigned long long) * kIterSlots, s));
-    // K6 launches of different slots are chained so that they never share the chip: the small
-    // latency-bound stages of the other batches are what overlaps with a K6, not another K6
-    if (h->k6_last >= 0 && h->k6_last != si && h->slots[h->k6_last].busy)
-      HIP_TRY(h, hipStreamWaitEvent(s, h->slots[h->k6_last].k6_done, 0));
   }
   HIP_TRY(h, hipEventRecord(sl.ev[4], s));
   if (sl.grid) {
@@ -346,7 +350,24 @@ int32_t enqueue(ilcc_handle* h, int si, const float4* d_xyzi, const uint64_t* of
       full.seed_n_ty = h->n_ty2;
       full.seed_n_tz = h->n_tz2;
       full.seed_stride_t = h->seed_stride_t;
+      full.seed_stride_th = h->seed_stride_th;
+      full.seed_off_th = h->seed_stride_th / 2;
+      if (h->refine_pass) {
+        // refinement pass: all candidates around the seed argmin (theta +- half a seed stride, 16 x 16 translations)
+        Ctx refine = full;
+        refine.refine_radius_th = std::max(1, h->seed_stride_th / 2);
+        refine.grid_blocks = std::min((uint32_t)(2 * refine.refine_radius_th + 1), h->max_theta);
+        refine.partial = sl.d_partial3;
+        launch_grid_cost(refine, s, /*use_oob=*/1, nullptr, true);
+      }
     }
+    // The FULL passes of different slots are chained so that they never share the chip (their HIP-event
+    // durations stay clean and they do not fight for LDS); the seed and refinement passes above are small,
+    // latency-bound launches and are left free to overlap with another batch's full pass, like K2/K3/K7.
+    HIP_TRY(h, hipEventRecord(sl.ev[7], s));
+    if (h->k6_last >= 0 && h->k6_last != si && h->slots[h->k6_last].busy)
+      HIP_TRY(h, hipStreamWaitEvent(s, h->slots[h->k6_last].k6_done, 0));
+    HIP_TRY(h, hipEventRecord(sl.ev[8], s));
     launch_grid_cost(full, s, /*use_oob=*/1, nullptr, prune);
     HIP_TRY(h, hipEventRecord(sl.k6_done, s));
     h->k6_last = si;
@@ -372,6 +393,12 @@ int32_t finish(ilcc_handle* h, int si, ilcc_result* out, float* d_records = null
   std::memcpy(out, sl.h_res, sizeof(ilcc_result) * n_frames);
   float ms[6];
   for (int k = 0; k < 6; ++k) HIP_TRY(h, hipEventElapsedTime(&ms[k], sl.ev[k], sl.ev[k + 1]));
+  if (sl.grid) {   // K6 = (seed + refinement passes) + (full pass); the wait for the previous batch's full pass in between is not K6 time
+    float pre = 0.f, fullp = 0.f;
+    HIP_TRY(h, hipEventElapsedTime(&pre, sl.ev[4], sl.ev[7]));
+    HIP_TRY(h, hipEventElapsedTime(&fullp, sl.ev[8], sl.ev[5]));
+    ms[4] = pre + fullp;
+  }
   float tot = 0;
   HIP_TRY(h, hipEventElapsedTime(&tot, sl.ev[0], sl.ev[6]));
   ilcc_timing& t = h->timing;
@@ -394,10 +421,10 @@ int32_t finish(ilcc_handle* h, int si, ilcc_result* out, float* d_records = null
     t.grid_cost_launches += 1;
     t.grid_cost_ms_sum += ms[4];
     t.grid_cost_evals_nominal_sum += evals;
-    // one wavefront-iteration = 64 points x (kTileA x kTileB) candidates (both phases = 1 evaluation)
+    // (both colour phases of a (point, candidate) pair = 1 evaluation)
     unsigned long long iters = 0;
     for (int k = 0; k < kIterSlots; ++k) iters += sl.h_iters[k];
-    t.grid_cost_evals_sum += (uint64_t)iters * ILCC_WAVE * kTileA * kTileB;
+    t.grid_cost_evals_sum += (uint64_t)iters * grid_cost_evals_per_count();
   }
   // adapt the K6 LDS staging size to the labelled-point counts actually seen (later calls)
   uint32_t want = 1024;
@@ -546,7 +573,11 @@ ilcc_handle* ilcc_create(int32_t device, const ilcc_params* p, uint32_t max_fram
     h->seed_stride_th = std::max(1, std::atoi(e1));
     h->seed_stride_env = true;
   }
-  if (const char* e2 = std::getenv("ILCC_SEED_STRIDE_T")) h->seed_stride_t = std::max(1, std::atoi(e2));
+  if (const char* e3 = std::getenv("ILCC_K6_REFINE")) h->refine_pass = std::atoi(e3) != 0;
+  if (const char* e2 = std::getenv("ILCC_SEED_STRIDE_T")) {
+    h->seed_stride_t = std::max(1, std::atoi(e2));
+    h->seed_stride_t_env = true;
+  }
   h->crop_chunks_cap =
       (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, max_total_points / kCropChunk + (uint64_t)max_frames + 1);
   auto fail = [&](const std::string& what) {

@@ -21,10 +21,13 @@ constexpr int kTileA = 4;              // K6 candidate tile: ty values per wavef
 #define ILCC_TILE_B 4
 #endif
 constexpr int kTileB = ILCC_TILE_B;    // K6 candidate tile: tz values per wavefront pass (4 or 8)
-constexpr int kGridLdsPointsMax = 16384;  // K6 LDS staging upper bound (9 B per point -> 144 KiB)
+constexpr int kGridLdsPointsMax = 8192;   // K6 LDS staging upper bound (12 B per point -> 96 KiB)
 constexpr int kSolveThreads = 256;     // K7: 4 wavefronts per frame
 constexpr int kIterSlots = 64;         // K6 executed-iteration counters (spread to avoid one hot atomic)
-constexpr int kClusterAllPairsMax = 4096;   // K2: above this many points the spatial hash finds neighbours
+#ifndef ILCC_K2_ALLPAIRS_MAX
+#define ILCC_K2_ALLPAIRS_MAX 4096
+#endif
+constexpr int kClusterAllPairsMax = ILCC_K2_ALLPAIRS_MAX;   // K2: above this many points the spatial hash finds neighbours
 constexpr int kClusterHashSize = 1 << 17;    // K2: hash buckets per frame (global memory)
 constexpr int kClusterLdsParents = 16384;  // K2 union-find parents kept in LDS (64 KiB)
 
@@ -71,11 +74,15 @@ struct Ctx {
   uint32_t grid_blocks;      // K6 workgroups per frame
   uint32_t grid_lds_points;  // K6 points staged in LDS per workgroup (multiple of 64)
   uint32_t* grid_bound;      // per frame: float bits of the best complete candidate cost so far (K6 pruning)
-  unsigned long long* grid_iters;  // executed K6 wavefront-iterations (64 points x one tile), for the VALU rate
+  unsigned long long* grid_iters;  // executed K6 work in counts of grid_cost_evals_per_count() evaluations, for the VALU rate
   // seeding pass of the branch-and-bound (a decimated subset of the same grid, evaluated first)
   const GridPartial* seed_partial; // n_frames x seed_blocks, nullptr when this launch is the seed pass / unused
   uint32_t seed_blocks;
   int32_t seed_n_ty, seed_n_tz, seed_stride_t;   // seed (a2,b2) -> grid (a2*stride, b2*stride)
+  int32_t seed_stride_th, seed_off_th;           // seed k2 -> grid theta index seed_off_th + k2*seed_stride_th
+  // refinement pass (between seed and full pass): workgroup j evaluates the 16 x 16 (ty, tz) window around
+  // the seed argmin at theta index (seed theta) + j - refine_radius_th; 0 = this launch is not a refinement
+  int32_t refine_radius_th;
   // candidate tables (device)
   const float* cth;          // cos(theta_k)/g
   const float* sth;          // sin(theta_k)/g
@@ -142,6 +149,7 @@ void launch_ransac_plane(const Ctx& c, hipStream_t s);
 void launch_plane_frame_hist(const Ctx& c, hipStream_t s);
 void launch_grid_cost(const Ctx& c, hipStream_t s, int32_t use_oob, float* cost_volume /*nullable*/,
                       bool prune);
+uint32_t grid_cost_evals_per_count();   // (point, candidate) evaluations behind one count of Ctx::grid_iters
 void launch_refine_corners(const Ctx& c, hipStream_t s);
 void launch_pack_records(const ilcc_result* d_res, uint32_t n_frames, uint32_t n_corners, float* d_out, hipStream_t s);
 // stand-alone local solve on the labelled points of frame 0 (test entry)
