@@ -25,7 +25,7 @@ constexpr int kGridLdsPointsMax = 8192;   // K6 LDS staging upper bound (12 B pe
 constexpr int kSolveThreads = 256;     // K7: 4 wavefronts per frame
 constexpr int kIterSlots = 64;         // K6 executed-iteration counters (spread to avoid one hot atomic)
 #ifndef ILCC_K2_ALLPAIRS_MAX
-#define ILCC_K2_ALLPAIRS_MAX 4096
+#define ILCC_K2_ALLPAIRS_MAX 256
 #endif
 constexpr int kClusterAllPairsMax = ILCC_K2_ALLPAIRS_MAX;   // K2: above this many points the spatial hash finds neighbours
 constexpr int kClusterHashSize = 1 << 17;    // K2: hash buckets per frame (global memory)

@@ -7,15 +7,22 @@
 // global scratch array); neighbours are found by tiled all-pairs: 1024 "j" points staged in
 // LDS per tile, every lane holds its own "i" point in registers, LDS reads are wave-uniform
 // (broadcast).  Roots are always the smallest member index, so the labelling is
-// deterministic.  Above 4096 points the neighbour search switches from all-pairs to a spatial
-// hash (cell = tolerance, 27 cells per point, chained buckets in global memory), which is what
-// un-cropped clouds (the online caller get_chessboard_by_point, LidarCornersEst.cpp:72-115) need.
+// deterministic.  Neighbour search, three ways with identical results: all-pairs up to
+// ILCC_K2_ALLPAIRS_MAX points; cell lists held entirely in LDS (points, heads, links) up to 4096
+// points -- the ROI case; above that a spatial hash with chained buckets in global memory, which is
+// what un-cropped clouds (the online caller get_chessboard_by_point, LidarCornersEst.cpp:72-115) need.
 // Cluster choice follows the reference: components with
 // cluster_min <= size <= cluster_max, sorted by size (largest = index 0); the one containing
 // the exact 1-NN of the click wins, otherwise index 0.  Members are emitted in index order.
 #include "ilcc_internal.h"
 
 namespace ilcc {
+
+#ifdef ILCC_K2_TIMING
+#define K2_MARK(k) do { __syncthreads(); if (f == 0 && threadIdx.x == 0) tmark[k] = __builtin_readcyclecounter(); } while (0)
+#else
+#define K2_MARK(k) do {} while (0)
+#endif
 
 // find with path halving.  Parents only ever point to smaller indices (the larger root is hooked
 // under the smaller), so replacing parent[x] by its grandparent keeps it an ancestor: safe against
@@ -63,9 +70,12 @@ __device__ __forceinline__ bool nn_less(const NnKey& x, const NnKey& y) {
   return x.d2 < y.d2 || (x.d2 == y.d2 && x.idx < y.idx);
 }
 
+constexpr int kClusterGridMax = 4096;     // <= this many ROI points: cell lists entirely in LDS
+constexpr int kClusterGridBuckets = 8192;
+
 template <bool LDS_PARENT>
 __device__ void cluster_frame(const Ctx& c, uint32_t f, uint32_t* lds_parent, float4* tile,
-                              uint32_t* sc) {
+                              uint32_t* sc, float4* s_pts) {
   ilcc_result* r = &c.res[f];
   if (r->status != ILCC_OK) return;
   const uint32_t M = (uint32_t)r->n_roi;
@@ -77,10 +87,126 @@ __device__ void cluster_frame(const Ctx& c, uint32_t f, uint32_t* lds_parent, fl
   const float tol2 = (float)(c.p.cluster_tol * c.p.cluster_tol);
   const uint32_t tid = threadIdx.x;
 
+#ifdef ILCC_K2_TIMING
+  __shared__ unsigned long long tmark[12];
+#endif
+  K2_MARK(0);
   for (uint32_t i = tid; i < M; i += kFrameThreads) parent[i] = i;
   __syncthreads();
+  K2_MARK(1);
 
-  if (M > (uint32_t)kClusterAllPairsMax) {
+  if (LDS_PARENT && M <= (uint32_t)kClusterGridMax && M > (uint32_t)kClusterAllPairsMax) {
+    // ---- cell lists in LDS (the ROI case): points, union-find parents, bucket heads and chain links all
+    // live in LDS, so a chain hop costs an LDS round trip instead of two dependent L2 loads.  Cells of
+    // (slightly more than) the tolerance; one task per (point, neighbouring cell).  Same pairs, same
+    // distance arithmetic, same partition as the other two searches.
+    uint32_t* nxt = lds_parent + kClusterGridMax;
+    uint32_t* head = lds_parent + 2 * kClusterGridMax;   // kClusterGridBuckets words
+    float3 lo = make_float3(3.0e38f, 3.0e38f, 3.0e38f);
+    for (uint32_t i = tid; i < M; i += kFrameThreads) {
+      const float4 q = P[i];
+      s_pts[i] = q;
+      lo.x = fminf(lo.x, q.x);
+      lo.y = fminf(lo.y, q.y);
+      lo.z = fminf(lo.z, q.z);
+    }
+    for (uint32_t k = tid; k < (uint32_t)kClusterGridBuckets; k += kFrameThreads) head[k] = 0xFFFFFFFFu;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      lo.x = fminf(lo.x, __shfl_xor(lo.x, o, ILCC_WAVE));
+      lo.y = fminf(lo.y, __shfl_xor(lo.y, o, ILCC_WAVE));
+      lo.z = fminf(lo.z, __shfl_xor(lo.z, o, ILCC_WAVE));
+    }
+    float* scf = reinterpret_cast<float*>(sc);
+    __syncthreads();
+    if (lane_id() == 0) {
+      scf[wave_id()] = lo.x;
+      scf[16 + wave_id()] = lo.y;
+      scf[32 + wave_id()] = lo.z;
+    }
+    __syncthreads();
+    for (int w = 0; w < kFrameThreads / ILCC_WAVE; ++w) {
+      lo.x = fminf(lo.x, scf[w]);
+      lo.y = fminf(lo.y, scf[16 + w]);
+      lo.z = fminf(lo.z, scf[32 + w]);
+    }
+    __syncthreads();
+    const float inv_cell = 1.0f / ((float)c.p.cluster_tol * 1.001f);
+    for (uint32_t i = tid; i < M; i += kFrameThreads) {
+      const float4 q = s_pts[i];
+      const int cx = (int)floorf((q.x - lo.x) * inv_cell), cy = (int)floorf((q.y - lo.y) * inv_cell),
+                cz = (int)floorf((q.z - lo.z) * inv_cell);
+      nxt[i] = atomicExch(&head[cell_hash(cx, cy, cz) & (uint32_t)(kClusterGridBuckets - 1)], i);
+    }
+    __syncthreads();
+    K2_MARK(8);
+#ifdef ILCC_K2_TIMING
+    unsigned long long n_hops = 0, n_hits = 0, n_unite = 0, t_unite = 0;
+#endif
+    // one task per (neighbouring cell, point); a wavefront takes 64 CONSECUTIVE points under the same cell
+    // offset: scan neighbours fall into the same or adjacent cells, so the chains the 64 lanes walk have
+    // similar lengths (the wavefront pays for the longest).  Per hop the link, the point and its parent are
+    // three independent LDS reads issued together: one LDS latency per hop, not three.
+    uint32_t cidx = 0, i = tid;
+    while (i >= M && cidx < 27u) {
+      i -= M;
+      ++cidx;
+    }
+    while (cidx < 27u) {
+      const float4 pi = s_pts[i];
+      const int dz = (int)(cidx / 9u) - 1, dy = (int)((cidx / 3u) % 3u) - 1, dx = (int)(cidx % 3u) - 1;
+      const int nx = (int)floorf((pi.x - lo.x) * inv_cell) + dx, ny = (int)floorf((pi.y - lo.y) * inv_cell) + dy,
+                nz = (int)floorf((pi.z - lo.z) * inv_cell) + dz;
+      uint32_t j = head[cell_hash(nx, ny, nz) & (uint32_t)(kClusterGridBuckets - 1)];
+      // i's parent as of now: equal parents mean "same set" for good, so a stale copy only costs a redundant unite
+      uint32_t qi = __hip_atomic_load(&parent[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      while (j != 0xFFFFFFFFu) {
+        const uint32_t jn = nxt[j];
+        const float4 q = s_pts[j];
+        const uint32_t qj = __hip_atomic_load(&parent[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#ifdef ILCC_K2_TIMING
+        ++n_hops;
+#endif
+        const float ex = q.x - pi.x, ey = q.y - pi.y, ez = q.z - pi.z;
+        float d2 = ex * ex;
+        d2 = d2 + ey * ey;
+        d2 = d2 + ez * ez;
+        if (j < i && d2 < tol2 && qi != qj) {   // each pair once
+#ifdef ILCC_K2_TIMING
+          ++n_hits;
+          ++n_unite;
+          const unsigned long long t0 = __builtin_readcyclecounter();
+#endif
+          uf_unite(parent, i, j);
+          qi = __hip_atomic_load(&parent[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#ifdef ILCC_K2_TIMING
+          t_unite += __builtin_readcyclecounter() - t0;
+#endif
+        }
+        j = jn;
+      }
+      i += kFrameThreads;
+      while (i >= M && cidx < 27u) {
+        i -= M;
+        ++cidx;
+      }
+    }
+#ifdef ILCC_K2_TIMING
+    {
+      __shared__ unsigned long long agg[4];
+      if (tid == 0) agg[0] = agg[1] = agg[2] = agg[3] = 0;
+      __syncthreads();
+      atomicAdd(&agg[0], n_hops);
+      atomicAdd(&agg[1], n_hits);
+      atomicAdd(&agg[2], n_unite);
+      atomicMax(&agg[3], t_unite);
+      __syncthreads();
+      if (f == 0 && tid == 0)
+        printf("K2 f0 walk: build %llu cycles, hops %llu hits %llu unite calls %llu, max per-thread cycles inside uf_unite %llu\n",
+               tmark[8] - tmark[1], agg[0], agg[1], agg[2], agg[3]);
+    }
+#endif
+  } else if (M > (uint32_t)kClusterAllPairsMax) {
     // ---- spatial hash: cells of (slightly more than) the tolerance, buckets chained through
     // `next`; every point tests the 27 cells around its own.  Bucket order depends on the race of
     // the insertions, the resulting partition does not.
@@ -188,6 +314,7 @@ __device__ void cluster_frame(const Ctx& c, uint32_t f, uint32_t* lds_parent, fl
   }
   __syncthreads();
 
+  K2_MARK(2);
   // ---- flatten: label = root (smallest member index)
   for (uint32_t base = 0; base < M; base += kFrameThreads) {
     const uint32_t i = base + tid;
@@ -201,6 +328,7 @@ __device__ void cluster_frame(const Ctx& c, uint32_t f, uint32_t* lds_parent, fl
     __syncthreads();
   }
 
+  K2_MARK(3);
   // ---- component sizes (wave-aggregated atomics on the root's counter)
   for (uint32_t base = 0; base < M; base += kFrameThreads) {
     const uint32_t i = base + tid;
@@ -217,6 +345,7 @@ __device__ void cluster_frame(const Ctx& c, uint32_t f, uint32_t* lds_parent, fl
   }
   __syncthreads();
 
+  K2_MARK(4);
   // ---- exact 1-NN of the click (float squared distance, ties -> lowest index)
   const float cx = c.clicks[3 * f], cy = c.clicks[3 * f + 1], cz = c.clicks[3 * f + 2];
   NnKey best{3.402823466e38f, 0xFFFFFFFFu};
@@ -254,6 +383,7 @@ __device__ void cluster_frame(const Ctx& c, uint32_t f, uint32_t* lds_parent, fl
   const uint32_t nn = sc[32];
   const uint32_t nn_label = parent[nn];
 
+  K2_MARK(5);
   // ---- largest valid component (ties -> smallest root), i.e. sorted index 0
   const uint32_t cmin = (uint32_t)c.p.cluster_min, cmax = (uint32_t)c.p.cluster_max;
   uint32_t bsz = 0, broot = 0xFFFFFFFFu;
@@ -306,6 +436,7 @@ __device__ void cluster_frame(const Ctx& c, uint32_t f, uint32_t* lds_parent, fl
     return;
   }
 
+  K2_MARK(6);
   // ---- stable compaction of the chosen component
   float4* __restrict__ dst = c.cluster + beg;
   uint32_t running = 0;
@@ -318,6 +449,13 @@ __device__ void cluster_frame(const Ctx& c, uint32_t f, uint32_t* lds_parent, fl
     running += tot;
   }
   if (tid == 0) r->n_cluster = (int32_t)running;
+  K2_MARK(7);
+#ifdef ILCC_K2_TIMING
+  if (f == 0 && tid == 0)
+    printf("K2 f0 M=%u cycles: init %llu search %llu flatten %llu count %llu nn %llu largest %llu compact %llu total %llu\n", M,
+           tmark[1] - tmark[0], tmark[2] - tmark[1], tmark[3] - tmark[2], tmark[4] - tmark[3], tmark[5] - tmark[4],
+           tmark[6] - tmark[5], tmark[7] - tmark[6], tmark[7] - tmark[0]);
+#endif
 }
 
 __global__ __launch_bounds__(kFrameThreads) void k2_seeded_cluster(Ctx c) {
@@ -325,19 +463,20 @@ __global__ __launch_bounds__(kFrameThreads) void k2_seeded_cluster(Ctx c) {
   float4* tile = reinterpret_cast<float4*>(smem);                          // 16 KiB
   uint32_t* sc = reinterpret_cast<uint32_t*>(smem + sizeof(float4) * kFrameThreads);  // 64 words
   uint32_t* lds_parent = sc + 64;                                           // 64 KiB
+  float4* s_pts = reinterpret_cast<float4*>(lds_parent + kClusterLdsParents);  // 64 KiB (cell-list path)
   const uint32_t f = blockIdx.x;
   const uint32_t M = (uint32_t)c.res[f].n_roi;
   if (M <= (uint32_t)kClusterLdsParents)
-    cluster_frame<true>(c, f, lds_parent, tile, sc);
+    cluster_frame<true>(c, f, lds_parent, tile, sc, s_pts);
   else
-    cluster_frame<false>(c, f, lds_parent, tile, sc);
+    cluster_frame<false>(c, f, lds_parent, tile, sc, s_pts);
 }
 
 void launch_cluster(const Ctx& c, hipStream_t s) {
   const size_t lds = sizeof(float4) * kFrameThreads + 64 * sizeof(uint32_t) +
-                     sizeof(uint32_t) * kClusterLdsParents;
+                     sizeof(uint32_t) * kClusterLdsParents + sizeof(float4) * kClusterGridMax;
   static bool attr_done = false;
-  if (!attr_done) {   // 80 KiB of dynamic LDS (> the 64 KiB default cap)
+  if (!attr_done) {   // 144 KiB of dynamic LDS (> the 64 KiB default cap; one 1024-thread workgroup per CU either way)
     (void)hipFuncSetAttribute((const void*)k2_seeded_cluster, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }

@@ -95,11 +95,48 @@ struct Problem {
   int* flip;             // per-thread toggle (register copy lives in the caller)
 };
 
-template <typename T>
-__device__ __forceinline__ T wave_allsum(T v) {
-#pragma unroll
-  for (int o = ILCC_WAVE / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, ILCC_WAVE);
-  return v;   // identical in every lane (each step adds the same two operands in both partners)
+// v[lane ^ MASK] for a 64-bit value, in registers only: v_permlane32_swap / v_permlane16_swap (gfx950) and
+// DPP row rotations / quad permutes on the two dwords -- no ds_bpermute round trips.  (An evaluate() reduces
+// ten doubles over six butterfly steps: 120 LDS permutes before, ~200 VALU instructions now.)
+template <int CTRL, int BANK = 0xf>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t old, uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, 0xf, BANK, false);
+}
+template <int MASK>
+__device__ __forceinline__ uint32_t xor_lane_u32(uint32_t v) {
+  if constexpr (MASK == 32) {
+    const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return (lane_id() & 32) ? r[0] : r[1];   // swap exchanges the upper half of operand 0 with the lower half of operand 1
+  } else if constexpr (MASK == 16) {
+    const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    return (lane_id() & 16) ? r[0] : r[1];
+  } else if constexpr (MASK == 8) {
+    return dpp_u32<0x128>(0u, v);                       // row_ror:8
+  } else if constexpr (MASK == 4) {
+    const uint32_t lo = dpp_u32<0x124, 0xa>(0u, v);     // row_ror:4 -> banks 1,3 take lane i-4
+    return dpp_u32<0x12C, 0x5>(lo, v);                  // row_ror:12 -> banks 0,2 take lane i+4
+  } else if constexpr (MASK == 2) {
+    return dpp_u32<0x4E>(0u, v);                        // quad_perm [2,3,0,1]
+  } else {
+    return dpp_u32<0xB1>(0u, v);                        // quad_perm [1,0,3,2]
+  }
+}
+template <int MASK>
+__device__ __forceinline__ double xor_lane_f64(double v) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  const uint32_t lo = xor_lane_u32<MASK>((uint32_t)b), hi = xor_lane_u32<MASK>((uint32_t)(b >> 32));
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+// butterfly in the order 32, 16, 8, 4, 2, 1: identical in every lane (each step adds the same two operands
+// in both partners), and bit-identical to the __shfl_xor butterfly it replaces
+__device__ __forceinline__ double wave_allsum(double v) {
+  v += xor_lane_f64<32>(v);
+  v += xor_lane_f64<16>(v);
+  v += xor_lane_f64<8>(v);
+  v += xor_lane_f64<4>(v);
+  v += xor_lane_f64<2>(v);
+  v += xor_lane_f64<1>(v);
+  return v;
 }
 
 // sums[0] = cost ; if JAC: sums[1..3] = J^T r, sums[4..9] = upper J^T J (00,01,02,11,12,22),
