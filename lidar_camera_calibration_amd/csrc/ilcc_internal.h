@@ -22,7 +22,10 @@ constexpr int kTileA = 4;              // K6 candidate tile: ty values per wavef
 #endif
 constexpr int kTileB = ILCC_TILE_B;    // K6 candidate tile: tz values per wavefront pass (4 or 8)
 constexpr int kGridLdsPointsMax = 8192;   // K6 LDS staging upper bound (12 B per point -> 96 KiB)
-constexpr int kSolveThreads = 256;     // K7: 4 wavefronts per frame
+#ifndef ILCC_K7_THREADS
+#define ILCC_K7_THREADS 256
+#endif
+constexpr int kSolveThreads = ILCC_K7_THREADS;     // K7: wavefronts x 64 per (frame, phase)
 constexpr int kIterSlots = 64;         // K6 executed-iteration counters (spread to avoid one hot atomic)
 #ifndef ILCC_K2_ALLPAIRS_MAX
 #define ILCC_K2_ALLPAIRS_MAX 256
