@@ -68,6 +68,7 @@ struct Ctx {
   uint32_t* n_lab;           // per frame
   uint8_t* cls;              // color_by_gray_zone class of every plane point: 0 black, 1 gray, 2 white
   uint32_t* crop_counts;     // n_frames x crop_chunks
+  unsigned long long* crop_masks;  // n_frames x crop_chunks x (kCropChunk / 64) keep-bits of the count pass
   uint32_t* uf_parent;       // K2 scratch (global fallback / labels)
   uint32_t* uf_count;        // K2 component sizes
   uint32_t* uf_hash_head;    // K2 spatial hash: n_frames x kClusterHashSize bucket heads

@@ -2,14 +2,18 @@
 // (/root/reference/ilcc2/src/LidarCornersEst.cpp:48-70).
 //
 // HBM-bound: every input point (16 B XYZI, float4, coalesced 1 KiB per wavefront load) is read
-// once per kernel; survivors (a few thousand per frame) are written in input order.
-// Two kernels: count per 4096-point chunk, then an order-preserving scatter whose base is the
-// prefix of the chunk counts.  The second read of the cloud is served by the 256 MiB
-// Infinity Cache for the batch sizes of BASELINE.json (128 x 460 KB = 59 MB).
+// ONCE; survivors (a few thousand per frame) are written in input order.
+// Two kernels: the count pass tests every point and leaves, per 4096-point chunk, the survivor
+// count and the 64 keep-masks of its wavefront loads (512 B); the order-preserving scatter works
+// from the masks alone -- ranks are popcounts, no workgroup barriers -- and re-reads only the ~5 %
+// of the points that survive.  Reading the cloud once is what lets the kernel be fed straight
+// from pinned host memory over PCIe at link rate (PCIe-inclusive rate).
 // Launch: grid = (chunks, frames) -> >= 1024 workgroups for a 128-frame VLP-16 batch.
 #include "ilcc_internal.h"
 
 namespace ilcc {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct Box {
   float lo[3], hi[3];
@@ -58,14 +62,30 @@ __global__ __launch_bounds__(kCropThreads) void k1_roi_count(Ctx c) {
   }
   const uint64_t cbeg = (uint64_t)s * kCropChunk;
   uint32_t cnt = 0;
+  unsigned long long* masks = c.crop_masks + ((uint64_t)f * c.crop_chunks + s) * (kCropChunk / ILCC_WAVE);
   if (cbeg < n) {
     const Box b = make_box(c, f);
     const uint64_t cend = (cbeg + kCropChunk < n) ? cbeg + kCropChunk : n;
     const float4* __restrict__ src = c.xyzi + beg;
-#pragma unroll 4
-    for (uint64_t i = cbeg + threadIdx.x; i < cend; i += kCropThreads) {
-      const float4 q = src[i];
-      cnt += keep_point(q, b) ? 1u : 0u;
+    constexpr int kTrips = kCropChunk / kCropThreads;   // 16: all loads of a thread are independent
+    float4 q[kTrips];
+#pragma unroll
+    for (int k = 0; k < kTrips; ++k) {
+      const uint64_t i = cbeg + (uint64_t)k * kCropThreads + threadIdx.x;
+      if (i < cend) {   // streamed once: keep it out of the way of the later stages' working set
+        const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + i));
+        q[k] = make_float4(v.x, v.y, v.z, v.w);
+      } else {
+        q[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < kTrips; ++k) {
+      const uint64_t i = cbeg + (uint64_t)k * kCropThreads + threadIdx.x;
+      const bool keep = (i < cend) && keep_point(q[k], b);
+      const unsigned long long m = __ballot(keep);
+      if (lane_id() == 0) masks[k * (kCropThreads / ILCC_WAVE) + wave_id()] = m;   // order (trip, wavefront) = input order
+      cnt += keep ? 1u : 0u;
     }
   }
   __shared__ uint32_t sc[17];
@@ -89,26 +109,26 @@ __global__ __launch_bounds__(kCropThreads) void k1_roi_scatter(Ctx c) {
     if (all == 0) c.res[f].status = ILCC_NO_ROI_POINTS;
   }
   const uint64_t cbeg = (uint64_t)s * kCropChunk;
-  if (cbeg >= n) return;
-  const Box b = make_box(c, f);
-  const uint64_t cend = (cbeg + kCropChunk < n) ? cbeg + kCropChunk : n;
+  if (cbeg >= n || counts[s] == 0) return;
   const float4* __restrict__ src = c.xyzi + beg;
   float4* __restrict__ dst = c.roi + beg;
-  __shared__ uint32_t sc[17];
-  uint32_t running = base;
-  for (uint64_t t = cbeg; t < cend; t += kCropThreads) {  // uniform trip count per workgroup
-    const uint64_t i = t + threadIdx.x;
-    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-    bool keep = false;
-    if (i < cend) {
-      q = src[i];
-      keep = keep_point(q, b);
+  const unsigned long long* masks = c.crop_masks + ((uint64_t)f * c.crop_chunks + s) * (kCropChunk / ILCC_WAVE);
+  constexpr int kWaves = kCropThreads / ILCC_WAVE, kMasks = kCropChunk / ILCC_WAVE;
+  const int lane = lane_id(), w = wave_id();
+  // this wavefront's loads are masks w, w + 4, ...; the rank of a survivor = survivors in all earlier masks
+  // (input order = mask order) + survivors below it in its own mask
+  uint32_t before = base;
+  int m = 0;
+  for (int k = 0; k < kCropChunk / kCropThreads; ++k) {
+    const int mine = k * kWaves + w;
+    for (; m < mine; ++m) before += (uint32_t)__popcll(masks[m]);
+    const unsigned long long mk = masks[mine];
+    if ((mk >> lane) & 1ull) {
+      const uint64_t i = cbeg + (uint64_t)k * kCropThreads + threadIdx.x;
+      dst[before + (uint32_t)__popcll(mk & ((1ull << lane) - 1ull))] = src[i];
     }
-    uint32_t tot;
-    const uint32_t rank = block_rank(keep, sc, tot);
-    if (keep) dst[running + rank] = q;
-    running += tot;
   }
+  (void)kMasks;
 }
 
 void launch_roi_crop(const Ctx& c, hipStream_t s) {
