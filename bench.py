@@ -30,6 +30,10 @@ import time
 
 import numpy as np
 
+# One HIP stream per batch in flight (4) + torch's streams: with the runtime's default of 4 hardware queues two
+# of them would share a queue and serialise.  Must be set before the HIP runtime initialises (i.e. before torch).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -54,7 +58,7 @@ def main():
     ap.add_argument("--frames-per-gpu", type=int, default=128)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline time budget (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--in-flight", type=int, default=3, help="batches in flight per GPU (1 = fully synchronous steps)")
+    ap.add_argument("--in-flight", type=int, default=4, help="batches in flight per GPU (1 = fully synchronous steps)")
     args = ap.parse_args()
 
     import torch
@@ -97,7 +101,7 @@ def main():
     est = LidarCornersBatch(F, lidar.n_points, params, device=local_rank)
     n_cand = params.n_th * params.n_ty * params.n_tz * 2
 
-    depth = max(1, min(args.in_flight, 3))
+    depth = max(1, min(args.in_flight, 4))
 
     pending = []   # the previous step's gather, still in flight (one RCCL gather per step)
 

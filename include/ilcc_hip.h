@@ -172,7 +172,8 @@ int32_t ilcc_extract_batch_device(ilcc_handle* h, const float* d_xyzi, const uin
                                   uint32_t n_frames, const float* d_clicks, ilcc_result* out);
 
 /* Asynchronous form of ilcc_extract_batch_device: enqueue the whole path for one batch and return;
- * up to 3 batches may be in flight per handle (each in its own buffers and stream), so the short
+ * up to 4 batches may be in flight per handle (each in its own buffers and stream; run the process with
+ * GPU_MAX_HW_QUEUES >= 5, HIP's default of 4 makes two of the streams share a hardware queue), so the short
  * latency-bound stages of one batch overlap with the grid search of another.  *ticket identifies the
  * batch; ilcc_wait blocks until it is complete and copies its records to out (n_frames entries).
  * Tickets must be waited for in submission order once all slots are taken (ILCC_CAPACITY otherwise).

@@ -16,7 +16,9 @@
 
 using namespace ilcc;
 
-constexpr int kSlots = 3;   // batches in flight per handle (submit/wait); slot 0 serves the synchronous calls
+constexpr int kSlots = 4;   // batches in flight per handle (submit/wait); slot 0 serves the synchronous calls.
+                            // Every slot has its own stream: the process needs GPU_MAX_HW_QUEUES >= 5 (HIP default: 4), otherwise two
+                            // slot streams share one hardware queue and serialise (measured: 113 k instead of 164 k frames/s)
 
 // One in-flight batch: its own stream, events, stage buffers and pinned result staging.
 struct Slot {

@@ -251,7 +251,7 @@ class LidarCornersBatch:
         return res
 
     def submit_device(self, d_xyzi_ptr: int, n_frames: int, n_points: int, d_clicks_ptr: int):
-        """Asynchronous ``extract_device``: returns a ticket; up to 3 batches in flight per handle."""
+        """Asynchronous ``extract_device``: returns a ticket; up to 4 batches in flight per handle."""
         offsets = np.arange(n_frames + 1, dtype=np.uint64) * np.uint64(n_points)
         ticket = C.c_int32(-1)
         st = self._lib.ilcc_submit_batch_device(self._h, C.c_void_p(d_xyzi_ptr),

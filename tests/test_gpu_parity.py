@@ -272,12 +272,12 @@ def test_branch_and_bound_does_not_change_the_result(ob, frames):
 
 
 def test_async_submit_wait_matches_synchronous_calls(frames):
-    """Three batches in flight (submit/wait) return exactly what three synchronous calls return."""
+    """Four batches in flight (submit/wait) return exactly what four synchronous calls return."""
     import torch
     clouds, clicks, _ = frames
     dev = torch.device("cuda", 0)
     e = LidarCornersBatch(8, 28800, N.default_params())
-    sets = [(0, 6), (6, 11), (11, 16)]
+    sets = [(0, 5), (5, 9), (9, 13), (13, 16)]
     sync = [[r.corners_array() for r in e.extract(clouds[a:b], clicks[a:b])] for a, b in sets]
     d = [(torch.from_numpy(clouds[a:b].copy()).to(dev), torch.from_numpy(clicks[a:b].copy()).to(dev)) for a, b in sets]
     torch.cuda.synchronize()
