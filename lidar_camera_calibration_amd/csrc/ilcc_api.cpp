@@ -40,6 +40,8 @@ struct Slot {
   GridPartial *d_partial = nullptr, *d_partial2 = nullptr, *d_partial3 = nullptr;
   SolveRec* d_solverec = nullptr;
   uint32_t* d_bound = nullptr;
+  uint32_t* d_tie_count = nullptr;
+  GridPartial* d_tie_list = nullptr;
   unsigned long long* d_iters = nullptr;
   // pinned host staging
   ilcc_result* h_res = nullptr;
@@ -173,7 +175,7 @@ int32_t upload_tables(ilcc_handle* h) {
 void free_slot(Slot& sl) {
   void* bufs[] = {sl.d_xyzi, sl.d_clicks, sl.d_off, sl.d_res, sl.d_roi, sl.d_cluster, sl.d_board, sl.d_pca, sl.d_optim,
                   sl.d_yz, sl.d_lab, sl.d_cls, sl.d_nlab, sl.d_counts, sl.d_parent, sl.d_count, sl.d_hash_head, sl.d_hash_next, sl.d_partial, sl.d_partial2, sl.d_partial3, sl.d_masks,
-                  sl.d_solverec, sl.d_bound, sl.d_iters};
+                  sl.d_solverec, sl.d_bound, sl.d_iters, sl.d_tie_count, sl.d_tie_list};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (sl.h_res) (void)hipHostFree(sl.h_res);
@@ -217,6 +219,8 @@ int32_t alloc_slot(ilcc_handle* h, Slot& sl) {
   ALLOC(sl.d_partial3, sizeof(GridPartial) * (size_t)mf * h->max_theta);
   ALLOC(sl.d_solverec, sizeof(SolveRec) * 2 * (size_t)mf);
   ALLOC(sl.d_bound, sizeof(uint32_t) * mf);
+  ALLOC(sl.d_tie_count, sizeof(uint32_t) * mf);
+  ALLOC(sl.d_tie_list, sizeof(GridPartial) * (size_t)mf * kTieCap);
   ALLOC(sl.d_iters, sizeof(unsigned long long) * kIterSlots);
 #undef ALLOC
   HIP_TRY(h, hipHostMalloc((void**)&sl.h_res, sizeof(ilcc_result) * mf, hipHostMallocDefault));
@@ -254,6 +258,8 @@ Ctx make_ctx(ilcc_handle* h, Slot& sl, const float4* d_xyzi, const float* d_clic
   c.grid_blocks = (uint32_t)h->p.n_th;
   c.grid_lds_points = h->grid_lds_points;
   c.grid_bound = sl.d_bound;
+  c.tie_count = nullptr;   // only the full pass of K6 collects; K7a gets the pointers below
+  c.tie_list = sl.d_tie_list;
   c.grid_iters = sl.d_iters;
   c.seed_partial = nullptr;
   c.seed_blocks = 0;
@@ -331,12 +337,15 @@ int32_t enqueue(ilcc_handle* h, int si, const float4* d_xyzi, const uint64_t* of
   sl.grid = !front_only && h->p.solver == ILCC_SOLVER_GRID;
   if (sl.grid) {
     HIP_TRY(h, hipMemsetAsync(sl.d_iters, 0, sizeof(unsigned long long) * kIterSlots, s));
+    HIP_TRY(h, hipMemsetAsync(sl.d_tie_count, 0, sizeof(uint32_t) * n_frames, s));
   }
   HIP_TRY(h, hipEventRecord(sl.ev[4], s));
   if (sl.grid) {
     const bool prune = h->p.grid_prune != 0;
     Ctx full = c;
-    if (prune && h->n_th2 > 0 && h->p.n_th >= 8 && h->p.n_ty >= 8 && h->p.n_tz >= 8) {
+    // (grid_prune = 0 keeps the two small passes: they only initialise the frame's bound, which the cut-free full
+    // pass still needs to recognise near ties; it never cuts a tile)
+    if (h->n_th2 > 0 && h->p.n_th >= 8 && h->p.n_ty >= 8 && h->p.n_tz >= 8) {
       // seeding pass: a decimated subset of the SAME candidates, fully evaluated (with pruning
       // among themselves) -> per-frame bound + where to start the full pass
       Ctx seed = c;
@@ -373,12 +382,17 @@ int32_t enqueue(ilcc_handle* h, int si, const float4* d_xyzi, const uint64_t* of
     if (h->k6_last >= 0 && h->k6_last != si && h->slots[h->k6_last].busy)
       HIP_TRY(h, hipStreamWaitEvent(s, h->slots[h->k6_last].k6_done, 0));
     HIP_TRY(h, hipEventRecord(sl.ev[8], s));
+    full.tie_count = sl.d_tie_count;
     launch_grid_cost(full, s, /*use_oob=*/1, nullptr, prune);
     HIP_TRY(h, hipEventRecord(sl.k6_done, s));
     h->k6_last = si;
   }
   HIP_TRY(h, hipEventRecord(sl.ev[5], s));
-  if (!front_only) launch_refine_corners(c, s);
+  if (!front_only) {
+    Ctx c7 = c;
+    c7.tie_count = sl.grid ? sl.d_tie_count : nullptr;   // near ties of the full pass, recounted in fp64 by K7a
+    launch_refine_corners(c7, s);
+  }
   HIP_TRY(h, hipEventRecord(sl.ev[6], s));
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipMemcpyAsync(sl.h_res, sl.d_res, sizeof(ilcc_result) * n_frames, hipMemcpyDeviceToHost, s));

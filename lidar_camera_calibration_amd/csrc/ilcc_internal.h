@@ -26,6 +26,8 @@ constexpr int kGridLdsPointsMax = 8192;   // K6 LDS staging upper bound (12 B pe
 #define ILCC_K7_THREADS 256
 #endif
 constexpr int kSolveThreads = ILCC_K7_THREADS;     // K7: wavefronts x 64 per (frame, phase)
+constexpr int kTieCap = 256;           // K6 -> K7a: near-tie candidates kept per frame for the fp64 recount
+constexpr float kTieEps = 2e-5f;       // relative cost window of a near-tie (fp32 sums of ~1e3 terms agree to ~1e-6)
 constexpr int kIterSlots = 64;         // K6 executed-iteration counters (spread to avoid one hot atomic)
 #ifndef ILCC_K2_ALLPAIRS_MAX
 #define ILCC_K2_ALLPAIRS_MAX 256
@@ -78,6 +80,10 @@ struct Ctx {
   uint32_t grid_blocks;      // K6 workgroups per frame
   uint32_t grid_lds_points;  // K6 points staged in LDS per workgroup (multiple of 64)
   uint32_t* grid_bound;      // per frame: float bits of the best complete candidate cost so far (K6 pruning)
+  // near ties: candidates of the full pass whose fp32 cost is within kTieEps of the bound at the time they
+  // complete; K7a recounts them in fp64 so that the argmin is the fp64 oracle's even when fp32 cannot order them
+  uint32_t* tie_count;       // per frame (nullptr: this launch does not collect)
+  GridPartial* tie_list;     // n_frames x kTieCap: cost (fp32), d2, flat
   unsigned long long* grid_iters;  // executed K6 work in counts of grid_cost_evals_per_count() evaluations, for the VALU rate
   // seeding pass of the branch-and-bound (a decimated subset of the same grid, evaluated first)
   const GridPartial* seed_partial; // n_frames x seed_blocks, nullptr when this launch is the seed pass / unused

@@ -232,7 +232,9 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
     // the shared bound is fetched ahead of its use (an L2 round trip is longer than a cut-short tile, and a
     // slightly stale bound only delays a cut): this tile starts with the word loaded during the previous
     // one and issues the load for the next refresh right away
-    float lim2 = 2.f * fminf(__uint_as_float(gb_bits), best.cost);   // sums are 2 x cost
+    // sums are 2 x cost.  The test keeps everything within kTieEps of the bound alive: fp32 sums cannot order
+    // such candidates reliably, K7a recounts them in fp64
+    float lim2 = 2.f * (1.f + kTieEps) * fminf(__uint_as_float(gb_bits), best.cost);
     if (PRUNE) gb_bits = __hip_atomic_load(bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // lane's points: walk positions my_s, my_s + 4, ...  (LDS_POINTS = false: point index (pos * S) mod M)
     uint32_t idx = (uint32_t)(((uint64_t)my_s * S) % M);
@@ -273,7 +275,7 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
           break;
         }
         if (((pos + kStep) & (kBoundRefresh - 1)) == 0) {
-          lim2 = 2.f * fminf(__uint_as_float(gb_bits), best.cost);
+          lim2 = 2.f * (1.f + kTieEps) * fminf(__uint_as_float(gb_bits), best.cost);
           gb_bits = __hip_atomic_load(bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next refresh
         }
       }
@@ -297,6 +299,19 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
       const uint32_t cell = ((uint32_t)k * (uint32_t)n_ty + (uint32_t)ia) * (uint32_t)n_tz + (uint32_t)ib;
       const uint32_t d2 = dk + (uint32_t)((ia - c.c_ty) * (ia - c.c_ty)) + (uint32_t)((ib - c.c_tz) * (ib - c.c_tz));
       const float c0 = 0.5f * t0s, c1 = 0.5f * t1s;
+      if (c.tie_count != nullptr && my_s == 0 && fminf(c0, c1) <= 0.5f * lim2) {   // full pass: near ties of the bound
+        // completions are rare: afford a fresh look at the frame's bound so that little junk is listed while it is loose
+        const float fresh = __uint_as_float(__hip_atomic_load(bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        const float thr = (1.f + kTieEps) * fminf(fresh, fminf(best.cost, fminf(c0, c1)));
+        if (c0 <= thr) {
+          const uint32_t at = atomicAdd(c.tie_count + f, 1u);
+          c.tie_list[(uint64_t)f * kTieCap + (at % (uint32_t)kTieCap)] = GridPartial{c0, d2, 2u * cell, 0u};   // ring: the newest (lowest) survive
+        }
+        if (c1 <= thr) {
+          const uint32_t at = atomicAdd(c.tie_count + f, 1u);
+          c.tie_list[(uint64_t)f * kTieCap + (at % (uint32_t)kTieCap)] = GridPartial{c1, d2, 2u * cell + 1u, 0u};
+        }
+      }
       if (better(c0, d2, 2u * cell, best)) best = Best{c0, d2, 2u * cell};
       if (better(c1, d2, 2u * cell + 1u, best)) best = Best{c1, d2, 2u * cell + 1u};
       if (VOLUME && my_s == 0) {

@@ -581,6 +581,46 @@ __device__ void solve_body(const Ctx& c, SolveRec* rec, float2* s_yz, uint8_t* s
       if (threadIdx.x == 0) out->valid = 0;
       return;
     }
+    // Near ties: fp32 sums of ~1e3 terms cannot order candidates whose costs agree to ~1e-6; the fp64 oracle
+    // can.  K6's full pass listed every candidate within kTieEps of the bound; recount the ones within kTieEps
+    // of the fp32 minimum in fp64 (the solver's own cost evaluation) and apply the tie-break on those values.
+    if (c.tie_count != nullptr) {
+      const uint32_t nt = min(c.tie_count[f], (uint32_t)kTieCap);
+      const GridPartial* tl = c.tie_list + (uint64_t)f * kTieCap;
+      const float window = b.cost * (1.f + kTieEps);
+      uint32_t close = 0;
+      for (uint32_t e = 0; e < nt; ++e) close += (tl[e].cost <= window && tl[e].flat != b.flat) ? 1u : 0u;
+      if (close > 0) {   // uniform across the workgroup
+        double best64 = 0.0;
+        GridPartial pick = b;
+        bool have = false;
+        for (uint32_t e = 0; e <= nt; ++e) {   // e == nt: the fp32 argmin itself (it may have been dropped by the cap)
+          const GridPartial t = (e < nt) ? tl[e] : b;
+          if (!(t.cost <= window)) continue;
+          if (e < nt && t.flat == b.flat) continue;
+          const uint32_t cl = t.flat >> 1;
+          const uint32_t tz = cl % (uint32_t)c.p.n_tz, ty = (cl / (uint32_t)c.p.n_tz) % (uint32_t)c.p.n_ty,
+                         tk = cl / ((uint32_t)c.p.n_tz * (uint32_t)c.p.n_ty);
+          const double xe[3] = {c.p.th_min + tk * c.p.th_step, c.p.ty_min + ty * c.p.ty_step, c.p.tz_min + tz * c.p.tz_step};
+          q.tlw = (t.flat & 1u) != 0;
+          q.oob = true;
+          double cs64[10];
+          evaluate<false>(q, xe, cs64);
+          const bool take = !have || cs64[0] < best64 ||
+                            (cs64[0] == best64 && (t.d2 < pick.d2 || (t.d2 == pick.d2 && t.flat < pick.flat)));
+          if (take) {
+            have = true;
+            best64 = cs64[0];
+            pick = t;
+          }
+        }
+        b = pick;
+        if (threadIdx.x == 0) {
+          r->grid_index = (int32_t)b.flat;
+          r->grid_cost = b.cost;
+        }
+      }
+    }
     const uint32_t cell = b.flat >> 1;
     const uint32_t bz = cell % (uint32_t)c.p.n_tz, ay = (cell / (uint32_t)c.p.n_tz) % (uint32_t)c.p.n_ty,
                    k = cell / ((uint32_t)c.p.n_tz * (uint32_t)c.p.n_ty);

@@ -443,7 +443,6 @@ def test_online_caller_get_chessboard_by_point(ob):
     m.close()
 
 
-@pytest.mark.gpu
 def test_device_records_equal_host_packing():
     """ilcc_wait_records_device (K9: records packed on the GPU for the RCCL gather) == sharding.pack_records
     of the same results, including failed frames (zero corners) -- SURVEY.md 8e."""
@@ -467,3 +466,25 @@ def test_device_records_equal_host_packing():
     assert res[3].status != 0 and res[7].status != 0 and res[0].status == 0
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
     est.close()
+
+
+def test_near_tie_is_ordered_like_the_fp64_oracle(ob):
+    """Seed 0xBEEF + 125 is a frame whose two best grid candidates (different translation basins, 137 mm apart in
+    the corners) cost 0.121899381 and 0.121899392: fp32 sums cannot order them.  K6 lists the near ties of the
+    bound, K7a recounts them in fp64 -- the argmin must be the oracle's (found by tools/grid_parity_sweep.py)."""
+    from lidar_camera_calibration_amd import LidarCornersBatch, synth
+    from lidar_camera_calibration_amd import _native as N
+    clouds, clicks, _, _ = synth.make_batch(1, seed=0xBEEF + 125)
+    op = ob.default_params()
+    op.solver = ob.SOLVER_GRID
+    op.accum_float = 0
+    ref = ob.extract(clouds[0], clicks[0], op)
+    for prune in (1, 0):
+        p = N.default_params()
+        p.grid_prune = prune
+        e = LidarCornersBatch(1, clouds.shape[1], p)
+        r = e.extract(clouds, clicks)[0]
+        e.close()
+        assert r.status == 0 and ref.status == 0
+        assert r.grid_index == ref.grid_index == 34756
+        assert np.abs(r.corners_array() - ob.result_corners(ref)).max() < 1e-6
