@@ -96,21 +96,23 @@ __device__ void cluster_frame(const Ctx& c, uint32_t f, uint32_t* lds_parent, fl
   K2_MARK(1);
 
   if (LDS_PARENT && M <= (uint32_t)kClusterGridMax && M > (uint32_t)kClusterAllPairsMax) {
-    // ---- cell lists in LDS (the ROI case): points, union-find parents, bucket heads and chain links all
-    // live in LDS, so a chain hop costs an LDS round trip instead of two dependent L2 loads.  Cells of
-    // (slightly more than) the tolerance; one task per (point, neighbouring cell).  Same pairs, same
-    // distance arithmetic, same partition as the other two searches.
-    uint32_t* nxt = lds_parent + kClusterGridMax;
-    uint32_t* head = lds_parent + 2 * kClusterGridMax;   // kClusterGridBuckets words
+    // ---- cell lists in LDS (the ROI case).  Cells of (slightly more than) the tolerance, hashed into 8192
+    // buckets; the points are counting-sorted by bucket INTO LDS (xyz + original index), so a bucket is a
+    // contiguous run.  One task per (neighbouring cell offset, point in sorted order): the 64 lanes of a
+    // wavefront are 64 consecutive sorted points, i.e. a handful of cells -- lanes of the same cell scan the
+    // same run (identical LDS addresses: broadcasts, no bank conflicts, equal trip counts).  Same pairs, same
+    // distance arithmetic, same partition as the other two searches; union-find indices stay the original
+    // ones, so roots (smallest member index) and labels are unchanged.
+    uint32_t* key = lds_parent + kClusterGridMax;          // bucket of point i
+    uint32_t* cur = lds_parent + 2 * kClusterGridMax;      // kClusterGridBuckets words: counts -> run ends
     float3 lo = make_float3(3.0e38f, 3.0e38f, 3.0e38f);
     for (uint32_t i = tid; i < M; i += kFrameThreads) {
       const float4 q = P[i];
-      s_pts[i] = q;
       lo.x = fminf(lo.x, q.x);
       lo.y = fminf(lo.y, q.y);
       lo.z = fminf(lo.z, q.z);
     }
-    for (uint32_t k = tid; k < (uint32_t)kClusterGridBuckets; k += kFrameThreads) head[k] = 0xFFFFFFFFu;
+    for (uint32_t k = tid; k < (uint32_t)kClusterGridBuckets; k += kFrameThreads) cur[k] = 0u;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
       lo.x = fminf(lo.x, __shfl_xor(lo.x, o, ILCC_WAVE));
@@ -132,80 +134,126 @@ __device__ void cluster_frame(const Ctx& c, uint32_t f, uint32_t* lds_parent, fl
     }
     __syncthreads();
     const float inv_cell = 1.0f / ((float)c.p.cluster_tol * 1.001f);
+    // counts per bucket
     for (uint32_t i = tid; i < M; i += kFrameThreads) {
-      const float4 q = s_pts[i];
+      const float4 q = P[i];
       const int cx = (int)floorf((q.x - lo.x) * inv_cell), cy = (int)floorf((q.y - lo.y) * inv_cell),
                 cz = (int)floorf((q.z - lo.z) * inv_cell);
-      nxt[i] = atomicExch(&head[cell_hash(cx, cy, cz) & (uint32_t)(kClusterGridBuckets - 1)], i);
+      const uint32_t b = cell_hash(cx, cy, cz) & (uint32_t)(kClusterGridBuckets - 1);
+      key[i] = b;
+      atomicAdd(&cur[b], 1u);
+    }
+    __syncthreads();
+    // exclusive scan of the 8192 counts (8 consecutive buckets per thread): cur[b] := start of run b
+    {
+      constexpr int kPer = kClusterGridBuckets / kFrameThreads;
+      uint32_t v[kPer], sum = 0;
+#pragma unroll
+      for (int k = 0; k < kPer; ++k) {
+        v[k] = cur[tid * kPer + k];
+        sum += v[k];
+      }
+      uint32_t incl = sum;   // inclusive scan over the wavefront
+#pragma unroll
+      for (int o = 1; o < ILCC_WAVE; o <<= 1) {
+        const uint32_t t = __shfl_up(incl, o, ILCC_WAVE);
+        if (lane_id() >= o) incl += t;
+      }
+      if (lane_id() == ILCC_WAVE - 1) sc[wave_id()] = incl;
+      __syncthreads();
+      uint32_t base = 0;
+      for (int w = 0; w < wave_id(); ++w) base += sc[w];
+      uint32_t run = base + incl - sum;
+#pragma unroll
+      for (int k = 0; k < kPer; ++k) {
+        cur[tid * kPer + k] = run;
+        run += v[k];
+      }
+    }
+    __syncthreads();
+    // placement: afterwards cur[b] = END of run b (= start of run b + 1)
+    for (uint32_t i = tid; i < M; i += kFrameThreads) {
+      const float4 q = P[i];
+      const uint32_t at = atomicAdd(&cur[key[i]], 1u);
+      s_pts[at] = make_float4(q.x, q.y, q.z, __uint_as_float(i));
     }
     __syncthreads();
     K2_MARK(8);
-#ifdef ILCC_K2_TIMING
-    unsigned long long n_hops = 0, n_hits = 0, n_unite = 0, t_unite = 0;
-#endif
-    // one task per (neighbouring cell, point); a wavefront takes 64 CONSECUTIVE points under the same cell
-    // offset: scan neighbours fall into the same or adjacent cells, so the chains the 64 lanes walk have
-    // similar lengths (the wavefront pays for the longest).  Per hop the link, the point and its parent are
-    // three independent LDS reads issued together: one LDS latency per hop, not three.
-    uint32_t cidx = 0, i = tid;
-    while (i >= M && cidx < 27u) {
-      i -= M;
+    // Unions are the expensive part (two finds = chains of dependent LDS atomics, ~1-2 k cycles), and inside the
+    // scan at most a lane or two need one at any step: done in place they would stall the other 60-odd lanes
+    // every time (measured: 96 % of the kernel).  Instead a wavefront QUEUES the (i, j) pairs that pass the
+    // cheap parent test and unites 64 of them at once, one per lane, whenever the queue fills.  The scan loop
+    // runs a wave-uniform trip count (the longest run among the 64 lanes) so the queue length stays uniform.
+    uint2* wq = reinterpret_cast<uint2*>(tile) + wave_id() * 128;   // 16 wavefronts x 128 entries = the 16 KiB tile
+    const int lane = lane_id();
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    uint32_t qn = 0;
+    uint32_t cidx = 0, sp = tid;
+    while (sp >= M && cidx < 27u) {
+      sp -= M;
       ++cidx;
     }
-    while (cidx < 27u) {
-      const float4 pi = s_pts[i];
-      const int dz = (int)(cidx / 9u) - 1, dy = (int)((cidx / 3u) % 3u) - 1, dx = (int)(cidx % 3u) - 1;
-      const int nx = (int)floorf((pi.x - lo.x) * inv_cell) + dx, ny = (int)floorf((pi.y - lo.y) * inv_cell) + dy,
-                nz = (int)floorf((pi.z - lo.z) * inv_cell) + dz;
-      uint32_t j = head[cell_hash(nx, ny, nz) & (uint32_t)(kClusterGridBuckets - 1)];
-      // i's parent as of now: equal parents mean "same set" for good, so a stale copy only costs a redundant unite
-      uint32_t qi = __hip_atomic_load(&parent[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      while (j != 0xFFFFFFFFu) {
-        const uint32_t jn = nxt[j];
-        const float4 q = s_pts[j];
-        const uint32_t qj = __hip_atomic_load(&parent[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#ifdef ILCC_K2_TIMING
-        ++n_hops;
-#endif
-        const float ex = q.x - pi.x, ey = q.y - pi.y, ez = q.z - pi.z;
-        float d2 = ex * ex;
-        d2 = d2 + ey * ey;
-        d2 = d2 + ez * ez;
-        if (j < i && d2 < tol2 && qi != qj) {   // each pair once
-#ifdef ILCC_K2_TIMING
-          ++n_hits;
-          ++n_unite;
-          const unsigned long long t0 = __builtin_readcyclecounter();
-#endif
-          uf_unite(parent, i, j);
-          qi = __hip_atomic_load(&parent[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#ifdef ILCC_K2_TIMING
-          t_unite += __builtin_readcyclecounter() - t0;
-#endif
+    // every lane of a wavefront makes the same number of trips through the task loop (inactive ones idle)
+    const uint32_t n_tasks = (27u * M + kFrameThreads - 1) / kFrameThreads;
+    for (uint32_t task = 0; task < n_tasks; ++task) {
+      const bool live = cidx < 27u;
+      float4 pi = make_float4(0.f, 0.f, 0.f, 0.f);
+      uint32_t i = 0, at = 0, len = 0, qi = 0;
+      if (live) {
+        pi = s_pts[sp];
+        i = __float_as_uint(pi.w);
+        const int dz = (int)(cidx / 9u) - 1, dy = (int)((cidx / 3u) % 3u) - 1, dx = (int)(cidx % 3u) - 1;
+        const int nx = (int)floorf((pi.x - lo.x) * inv_cell) + dx, ny = (int)floorf((pi.y - lo.y) * inv_cell) + dy,
+                  nz = (int)floorf((pi.z - lo.z) * inv_cell) + dz;
+        const uint32_t b = cell_hash(nx, ny, nz) & (uint32_t)(kClusterGridBuckets - 1);
+        at = b ? cur[b - 1] : 0u;
+        len = cur[b] - at;
+        // i's parent as of now: equal parents mean "same set" for good, so a stale copy only costs a redundant unite
+        qi = __hip_atomic_load(&parent[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      uint32_t wmax = len;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t t = __shfl_xor(wmax, o, ILCC_WAVE);
+        wmax = t > wmax ? t : wmax;
+      }
+      for (uint32_t st = 0; st < wmax; ++st) {
+        bool need = false;
+        uint32_t j = 0;
+        if (st < len) {
+          const float4 q = s_pts[at + st];
+          j = __float_as_uint(q.w);
+          const float ex = q.x - pi.x, ey = q.y - pi.y, ez = q.z - pi.z;
+          float d2 = ex * ex;
+          d2 = d2 + ey * ey;
+          d2 = d2 + ez * ez;
+          if (j < i && d2 < tol2)   // each pair once
+            need = qi != __hip_atomic_load(&parent[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-        j = jn;
+        const unsigned long long m = __ballot(need);
+        if (m) {
+          if (need) wq[qn + (uint32_t)__popcll(m & lt)] = make_uint2(i, j);
+          qn += (uint32_t)__popcll(m);
+          if (qn >= 64u) {   // unite the newest 64 pairs, one per lane
+            qn -= 64u;
+            const uint2 e = wq[qn + lane];
+            uf_unite(parent, e.x, e.y);
+            if (live) qi = __hip_atomic_load(&parent[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+        }
       }
-      i += kFrameThreads;
-      while (i >= M && cidx < 27u) {
-        i -= M;
-        ++cidx;
+      if (live) {
+        sp += kFrameThreads;
+        while (sp >= M && cidx < 27u) {
+          sp -= M;
+          ++cidx;
+        }
       }
     }
-#ifdef ILCC_K2_TIMING
-    {
-      __shared__ unsigned long long agg[4];
-      if (tid == 0) agg[0] = agg[1] = agg[2] = agg[3] = 0;
-      __syncthreads();
-      atomicAdd(&agg[0], n_hops);
-      atomicAdd(&agg[1], n_hits);
-      atomicAdd(&agg[2], n_unite);
-      atomicMax(&agg[3], t_unite);
-      __syncthreads();
-      if (f == 0 && tid == 0)
-        printf("K2 f0 walk: build %llu cycles, hops %llu hits %llu unite calls %llu, max per-thread cycles inside uf_unite %llu\n",
-               tmark[8] - tmark[1], agg[0], agg[1], agg[2], agg[3]);
+    if ((uint32_t)lane < qn) {
+      const uint2 e = wq[lane];
+      uf_unite(parent, e.x, e.y);
     }
-#endif
   } else if (M > (uint32_t)kClusterAllPairsMax) {
     // ---- spatial hash: cells of (slightly more than) the tolerance, buckets chained through
     // `next`; every point tests the 27 cells around its own.  Bucket order depends on the race of
