@@ -55,6 +55,18 @@ __device__ __forceinline__ void uf_unite(P* parent, uint32_t a, uint32_t b) {
   }
 }
 
+// unite, then point both endpoints straight at the common root (only non-roots are rewritten: a root's parent
+// word belongs to the hooks).  Makes the cheap "parents equal?" test of the batched search effective.
+template <typename P>
+__device__ __forceinline__ void uf_unite_compress(P* parent, uint32_t a, uint32_t b) {
+  uf_unite(parent, a, b);
+  const uint32_t r = uf_find(parent, a);
+  if (__hip_atomic_load(&parent[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a)
+    __hip_atomic_store(&parent[a], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (__hip_atomic_load(&parent[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != b)
+    __hip_atomic_store(&parent[b], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // bucket of an integer cell; different cells may share a bucket (a far cell's points then simply
 // fail the distance test)
 __device__ __forceinline__ uint32_t cell_hash(int cx, int cy, int cz) {
@@ -72,6 +84,7 @@ __device__ __forceinline__ bool nn_less(const NnKey& x, const NnKey& y) {
 
 constexpr int kClusterGridMax = 4096;     // <= this many ROI points: cell lists entirely in LDS
 constexpr int kClusterGridBuckets = 8192;
+constexpr int kClusterCells = 16384;       // direct cell grid of the wave-cooperative search (u16 run ends: 32 KiB)
 
 template <bool LDS_PARENT>
 __device__ void cluster_frame(const Ctx& c, uint32_t f, uint32_t* lds_parent, float4* tile,
@@ -95,7 +108,216 @@ __device__ void cluster_frame(const Ctx& c, uint32_t f, uint32_t* lds_parent, fl
   __syncthreads();
   K2_MARK(1);
 
+  // bounding box of the ROI points (every path below the all-pairs threshold skips it)
+  bool direct = false;
+  float3 blo = make_float3(0.f, 0.f, 0.f);
+  int gnx = 1, gny = 1, gnz = 1;
+  const float inv_cell_d = 1.0f / ((float)c.p.cluster_tol * 1.001f);
   if (LDS_PARENT && M <= (uint32_t)kClusterGridMax && M > (uint32_t)kClusterAllPairsMax) {
+    float3 lo = make_float3(3.0e38f, 3.0e38f, 3.0e38f), hi = make_float3(-3.0e38f, -3.0e38f, -3.0e38f);
+    for (uint32_t i = tid; i < M; i += kFrameThreads) {
+      const float4 q = P[i];
+      lo.x = fminf(lo.x, q.x); lo.y = fminf(lo.y, q.y); lo.z = fminf(lo.z, q.z);
+      hi.x = fmaxf(hi.x, q.x); hi.y = fmaxf(hi.y, q.y); hi.z = fmaxf(hi.z, q.z);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      lo.x = fminf(lo.x, __shfl_xor(lo.x, o, ILCC_WAVE)); lo.y = fminf(lo.y, __shfl_xor(lo.y, o, ILCC_WAVE));
+      lo.z = fminf(lo.z, __shfl_xor(lo.z, o, ILCC_WAVE));
+      hi.x = fmaxf(hi.x, __shfl_xor(hi.x, o, ILCC_WAVE)); hi.y = fmaxf(hi.y, __shfl_xor(hi.y, o, ILCC_WAVE));
+      hi.z = fmaxf(hi.z, __shfl_xor(hi.z, o, ILCC_WAVE));
+    }
+    float* scf = reinterpret_cast<float*>(sc);
+    __syncthreads();
+    if (lane_id() == 0) {
+      scf[wave_id()] = lo.x; scf[16 + wave_id()] = lo.y; scf[32 + wave_id()] = lo.z;
+      scf[64 + wave_id()] = hi.x; scf[80 + wave_id()] = hi.y; scf[96 + wave_id()] = hi.z;
+    }
+    __syncthreads();
+    for (int w = 0; w < kFrameThreads / ILCC_WAVE; ++w) {
+      lo.x = fminf(lo.x, scf[w]); lo.y = fminf(lo.y, scf[16 + w]); lo.z = fminf(lo.z, scf[32 + w]);
+      hi.x = fmaxf(hi.x, scf[64 + w]); hi.y = fmaxf(hi.y, scf[80 + w]); hi.z = fmaxf(hi.z, scf[96 + w]);
+    }
+    __syncthreads();
+    blo = lo;
+    gnx = (int)floorf((hi.x - lo.x) * inv_cell_d) + 1;
+    gny = (int)floorf((hi.y - lo.y) * inv_cell_d) + 1;
+    gnz = (int)floorf((hi.z - lo.z) * inv_cell_d) + 1;
+    direct = (long long)gnx * gny * gnz <= (long long)kClusterCells;   // uniform: every thread holds the same box
+  }
+  if (direct) {
+    // ---- wave-cooperative search on a direct cell grid in LDS (the ROI case: a 2 x 3 x 4 m box at 0.12 m
+    // cells is ~15 k cells).  Points are counting-sorted by cell into LDS (xyz + original index); a wavefront
+    // takes one occupied cell at a time: its 64 LANES HOLD THE CANDIDATES (the points of the 27 surrounding
+    // cells, one 16-byte LDS read per lane and 64 candidates) and the cell's own points are broadcast one after
+    // the other -- every lane busy, a fifth of the LDS traffic of a per-point scan.  Pairs that pass the cheap
+    // parent test are queued and united 64 at a time (a union is two chains of dependent LDS atomics; done in
+    // place it would stall the wavefront for one lane).  Same pairs, same distance arithmetic, same partition.
+    uint32_t* key = lds_parent + kClusterGridMax;                               // cell of point i
+    uint16_t* cur16 = reinterpret_cast<uint16_t*>(lds_parent + 2 * kClusterGridMax);   // kClusterCells run ends
+    uint32_t* cur32 = lds_parent + 2 * kClusterGridMax;                          // the same words, two cells each
+    uint16_t* occ = reinterpret_cast<uint16_t*>(s_pts + kClusterGridMax);       // occupied cells (<= M), 8 KiB
+    uint32_t* n_occ = sc + 120;
+    if (tid == 0) *n_occ = 0;
+    for (uint32_t k = tid; k < (uint32_t)kClusterCells / 2; k += kFrameThreads) cur32[k] = 0u;
+    __syncthreads();
+    for (uint32_t i = tid; i < M; i += kFrameThreads) {
+      const float4 q = P[i];
+      const int cx = (int)floorf((q.x - blo.x) * inv_cell_d), cy = (int)floorf((q.y - blo.y) * inv_cell_d),
+                cz = (int)floorf((q.z - blo.z) * inv_cell_d);
+      const uint32_t cell = (uint32_t)(cx + gnx * (cy + gny * cz));
+      key[i] = cell;
+      const uint32_t sh = (cell & 1u) * 16u;
+      const uint32_t old = atomicAdd(&cur32[cell >> 1], 1u << sh);
+      if (((old >> sh) & 0xFFFFu) == 0u) occ[atomicAdd(n_occ, 1u)] = (uint16_t)cell;   // first point of the cell
+    }
+    __syncthreads();
+    {   // exclusive scan of the 16384 counts (16 consecutive cells per thread): cur16[c] := start of run c
+      constexpr int kPer = kClusterCells / kFrameThreads;
+      uint32_t v[kPer], sum = 0;
+#pragma unroll
+      for (int k = 0; k < kPer; ++k) {
+        v[k] = cur16[tid * kPer + k];
+        sum += v[k];
+      }
+      uint32_t incl = sum;
+#pragma unroll
+      for (int o = 1; o < ILCC_WAVE; o <<= 1) {
+        const uint32_t t = __shfl_up(incl, o, ILCC_WAVE);
+        if (lane_id() >= o) incl += t;
+      }
+      if (lane_id() == ILCC_WAVE - 1) sc[wave_id()] = incl;
+      __syncthreads();
+      uint32_t base = 0;
+      for (int w = 0; w < wave_id(); ++w) base += sc[w];
+      uint32_t run = base + incl - sum;
+#pragma unroll
+      for (int k = 0; k < kPer; ++k) {
+        cur16[tid * kPer + k] = (uint16_t)run;
+        run += v[k];
+      }
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < M; i += kFrameThreads) {   // placement: afterwards cur16[c] = END of run c
+      const float4 q = P[i];
+      const uint32_t cell = key[i], sh = (cell & 1u) * 16u;
+      const uint32_t at = (atomicAdd(&cur32[cell >> 1], 1u << sh) >> sh) & 0xFFFFu;
+      s_pts[at] = make_float4(q.x, q.y, q.z, __uint_as_float(i));
+    }
+    __syncthreads();
+    K2_MARK(8);
+    uint2* wq = reinterpret_cast<uint2*>(tile) + wave_id() * 128;   // 16 wavefronts x 128 entries = the 16 KiB tile
+    const int lane = lane_id();
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    uint32_t qn = 0;
+#ifdef ILCC_K2_TIMING
+    unsigned long long n_push = 0, n_flush = 0, n_iter = 0, t_flush = 0;
+#endif
+    const uint32_t cells_occ = *n_occ;
+    for (uint32_t t = wave_id(); t < cells_occ; t += kFrameThreads / ILCC_WAVE) {
+      const uint32_t cell = occ[t];
+      const int cz = (int)(cell / (uint32_t)(gnx * gny)), rem = (int)(cell - (uint32_t)cz * (uint32_t)(gnx * gny));
+      const int cy = rem / gnx, cx = rem - cy * gnx;
+      const uint32_t cbeg = cell ? cur16[cell - 1] : 0u, clen = cur16[cell] - cbeg;
+      // lanes 0..26: run (start, length) of neighbour cell r = lane; inclusive scan of the lengths over the lanes
+      uint32_t rst = 0, rln = 0;
+      if (lane < 27) {
+        const int dz = lane / 9 - 1, dy = (lane / 3) % 3 - 1, dx = lane % 3 - 1;
+        const int nx = cx + dx, ny = cy + dy, nz = cz + dz;
+        if (nx >= 0 && nx < gnx && ny >= 0 && ny < gny && nz >= 0 && nz < gnz) {
+          const uint32_t nc = (uint32_t)(nx + gnx * (ny + gny * nz));
+          rst = nc ? cur16[nc - 1] : 0u;
+          rln = cur16[nc] - rst;
+        }
+      }
+      uint32_t incl = rln;
+#pragma unroll
+      for (int o = 1; o < 32; o <<= 1) {
+        const uint32_t u = __shfl_up(incl, o, ILCC_WAVE);
+        if (lane >= o) incl += u;
+      }
+      const uint32_t total = __shfl(incl, 26, ILCC_WAVE);
+      // the cell's own points, 64 at a time, one per lane; they are handed to all lanes with v_readlane
+      // (the inner loop touches LDS only to queue a pair)
+      for (uint32_t qb = 0; qb < clen; qb += ILCC_WAVE) {
+        const uint32_t nq = (clen - qb < (uint32_t)ILCC_WAVE) ? clen - qb : (uint32_t)ILCC_WAVE;
+        float4 own = make_float4(0.f, 0.f, 0.f, 0.f);
+        uint32_t own_par = 0;
+        if ((uint32_t)lane < nq) {
+          own = s_pts[cbeg + qb + lane];
+          own_par = __hip_atomic_load(&parent[__float_as_uint(own.w)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        for (uint32_t g0 = 0; g0 < total; g0 += ILCC_WAVE) {
+          const uint32_t g = g0 + (uint32_t)lane;
+          const bool valid = g < total;
+          // run r of candidate g: the first r with incl[r] > g (binary search over lanes 0..26 through shuffles)
+          int r = 0;
+#pragma unroll
+          for (int step = 16; step > 0; step >>= 1) {
+            const int probe = r + step - 1;
+            const uint32_t e = __shfl(incl, probe < 26 ? probe : 26, ILCC_WAVE);
+            if (probe <= 26 && e <= g) r += step;
+          }
+          r = r < 26 ? r : 26;
+          const uint32_t r_incl = __shfl(incl, r, ILCC_WAVE), r_len = __shfl(rln, r, ILCC_WAVE), r_st = __shfl(rst, r, ILCC_WAVE);
+          float4 cand = make_float4(0.f, 0.f, 0.f, 0.f);
+          uint32_t j = 0xFFFFFFFFu, pj = 0;
+          if (valid) {
+            cand = s_pts[r_st + (g - (r_incl - r_len))];
+            j = __float_as_uint(cand.w);
+            pj = __hip_atomic_load(&parent[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+          for (uint32_t qk = 0; qk < nq; ++qk) {
+            const float px = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(own.x), qk));
+            const float py = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(own.y), qk));
+            const float pz = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(own.z), qk));
+            const uint32_t i = __builtin_amdgcn_readlane(__float_as_uint(own.w), qk);
+            const uint32_t qi = __builtin_amdgcn_readlane(own_par, qk);
+            const float ex = cand.x - px, ey = cand.y - py, ez = cand.z - pz;
+            float d2 = ex * ex;
+            d2 = d2 + ey * ey;
+            d2 = d2 + ez * ez;
+            const bool need = valid && j < i && d2 < tol2 && qi != pj;   // each pair once; equal parents = same set for good
+#ifdef ILCC_K2_TIMING
+            ++n_iter;
+#endif
+            const unsigned long long m = __ballot(need);
+            if (m) {
+              if (need) wq[qn + (uint32_t)__popcll(m & lt)] = make_uint2(i, j);
+              qn += (uint32_t)__popcll(m);
+#ifdef ILCC_K2_TIMING
+              n_push += __popcll(m);
+#endif
+              if (qn >= 64u) {   // unite the newest 64 pairs, one per lane
+                qn -= 64u;
+                const uint2 e = wq[qn + lane];
+#ifdef ILCC_K2_TIMING
+                ++n_flush;
+                const unsigned long long tf0 = __builtin_readcyclecounter();
+#endif
+                uf_unite(parent, e.x, e.y);
+#ifdef ILCC_K2_TIMING
+                t_flush += __builtin_readcyclecounter() - tf0;
+#endif
+                if (valid) pj = __hip_atomic_load(&parent[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if ((uint32_t)lane < nq)
+                  own_par = __hip_atomic_load(&parent[__float_as_uint(own.w)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              }
+            }
+          }
+        }
+      }
+    }
+    if ((uint32_t)lane < qn) {
+      const uint2 e = wq[lane];
+      uf_unite(parent, e.x, e.y);
+    }
+#ifdef ILCC_K2_TIMING
+    K2_MARK(9);
+    if (f == 0 && lane == 0) printf("K2 f0 wave %d: iterations %llu pushes %llu flushes %llu cycles in flushes %llu\n", (int)wave_id(), n_iter, n_push, n_flush, t_flush);
+    if (f == 0 && tid == 0) printf("K2 f0 direct: box+build %llu walk %llu cycles, occupied cells %u, grid %d x %d x %d\n", tmark[8] - tmark[1], tmark[9] - tmark[8], cells_occ, gnx, gny, gnz);
+#endif
+  } else if (LDS_PARENT && M <= (uint32_t)kClusterGridMax && M > (uint32_t)kClusterAllPairsMax) {
     // ---- cell lists in LDS (the ROI case).  Cells of (slightly more than) the tolerance, hashed into 8192
     // buckets; the points are counting-sorted by bucket INTO LDS (xyz + original index), so a bucket is a
     // contiguous run.  One task per (neighbouring cell offset, point in sorted order): the 64 lanes of a
@@ -509,8 +731,8 @@ __device__ void cluster_frame(const Ctx& c, uint32_t f, uint32_t* lds_parent, fl
 __global__ __launch_bounds__(kFrameThreads) void k2_seeded_cluster(Ctx c) {
   extern __shared__ __align__(16) unsigned char smem[];
   float4* tile = reinterpret_cast<float4*>(smem);                          // 16 KiB
-  uint32_t* sc = reinterpret_cast<uint32_t*>(smem + sizeof(float4) * kFrameThreads);  // 64 words
-  uint32_t* lds_parent = sc + 64;                                           // 64 KiB
+  uint32_t* sc = reinterpret_cast<uint32_t*>(smem + sizeof(float4) * kFrameThreads);  // 128 words
+  uint32_t* lds_parent = sc + 128;                                          // 64 KiB
   float4* s_pts = reinterpret_cast<float4*>(lds_parent + kClusterLdsParents);  // 64 KiB (cell-list path)
   const uint32_t f = blockIdx.x;
   const uint32_t M = (uint32_t)c.res[f].n_roi;
@@ -521,10 +743,10 @@ __global__ __launch_bounds__(kFrameThreads) void k2_seeded_cluster(Ctx c) {
 }
 
 void launch_cluster(const Ctx& c, hipStream_t s) {
-  const size_t lds = sizeof(float4) * kFrameThreads + 64 * sizeof(uint32_t) +
-                     sizeof(uint32_t) * kClusterLdsParents + sizeof(float4) * kClusterGridMax;
+  const size_t lds = sizeof(float4) * kFrameThreads + 128 * sizeof(uint32_t) +
+                     sizeof(uint32_t) * kClusterLdsParents + sizeof(float4) * kClusterGridMax + sizeof(uint16_t) * kClusterGridMax;
   static bool attr_done = false;
-  if (!attr_done) {   // 144 KiB of dynamic LDS (> the 64 KiB default cap; one 1024-thread workgroup per CU either way)
+  if (!attr_done) {   // 152 KiB of dynamic LDS (> the 64 KiB default cap; one 1024-thread workgroup per CU either way)
     (void)hipFuncSetAttribute((const void*)k2_seeded_cluster, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
