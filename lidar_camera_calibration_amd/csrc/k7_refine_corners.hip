@@ -433,6 +433,15 @@ __device__ __forceinline__ bool dogleg_compute_step(Dog& s, double& s0, double& 
 }
 
 // TrustRegionMinimizer::Minimize for 3 parameters; every lane runs the same control flow.
+#ifdef ILCC_K7_TIMING
+__device__ unsigned long long g_k7_t[4];
+#define K7_T0 const unsigned long long k7t0 = __builtin_readcyclecounter()
+#define K7_ACC(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_k7_t[k] += __builtin_readcyclecounter() - k7t0; } while (0)
+#else
+#define K7_T0 do {} while (0)
+#define K7_ACC(k) do {} while (0)
+#endif
+
 __device__ int trust_region_minimize(const Problem& q, double x[3], double& final_cost, int max_iter) {
   if (q.n == 0) {
     final_cost = 0.0;
@@ -473,7 +482,12 @@ __device__ int trust_region_minimize(const Problem& q, double x[3], double& fina
     if (s.radius <= 1e-32) break;
     ++iter;
     double st0 = 0, st1 = 0, st2 = 0;
-    bool valid = dogleg_compute_step(s, st0, st1, st2);
+    bool valid;
+    {
+      K7_T0;
+      valid = dogleg_compute_step(s, st0, st1, st2);
+      K7_ACC(0);
+    }
     double mcc = 0;
     if (valid) {
       // model_cost_change = -(J step)'(r + J step/2) = -(g' step + step' JtJ step / 2)
@@ -490,7 +504,11 @@ __device__ int trust_region_minimize(const Problem& q, double x[3], double& fina
     invalid = 0;
     const double cand[3] = {x[0] + st0 * sc0, x[1] + st1 * sc1, x[2] + st2 * sc2};
     double cs[10];
-    evaluate<false>(q, cand, cs);
+    {
+      K7_T0;
+      evaluate<false>(q, cand, cs);
+      K7_ACC(1);
+    }
     const double cand_cost = cs[0];
     const double step_norm = nrm3(x[0] - cand[0], x[1] - cand[1], x[2] - cand[2]);
     if (step_norm <= 1e-8 * (x_norm + 1e-8)) break;            // ParameterToleranceReached
@@ -502,7 +520,11 @@ __device__ int trust_region_minimize(const Problem& q, double x[3], double& fina
       x[1] = cand[1];
       x[2] = cand[2];
       x_norm = nrm3(x[0], x[1], x[2]);
-      evaluate<true>(q, x, sums);
+      {
+        K7_T0;
+        evaluate<true>(q, x, sums);
+        K7_ACC(2);
+      }
       x_cost = sums[0];
       gr0 = sums[1];
       gr1 = sums[2];
@@ -638,6 +660,12 @@ __device__ void solve_body(const Ctx& c, SolveRec* rec, float2* s_yz, uint8_t* s
   const int ia = trust_region_minimize(q, x, ca, c.p.max_iterations);
   q.oob = false;   // pass B (:406-408)
   const int ib = trust_region_minimize(q, x, cb, c.p.max_iterations);
+#ifdef ILCC_K7_TIMING
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    printf("K7a f0 slot %d: iters %d + %d; cycles dogleg %llu, evaluate<false> %llu, evaluate<true> %llu\n", (int)blockIdx.y, ia, ib, g_k7_t[0], g_k7_t[1], g_k7_t[2]);
+    g_k7_t[0] = g_k7_t[1] = g_k7_t[2] = 0;
+  }
+#endif
   q.oob = true;
   double cs[10];
   evaluate<false>(q, x, cs);
