@@ -101,7 +101,7 @@ def main():
     est = LidarCornersBatch(F, lidar.n_points, params, device=local_rank)
     n_cand = params.n_th * params.n_ty * params.n_tz * 2
 
-    depth = max(1, min(args.in_flight, 4))
+    depth = max(1, min(args.in_flight, int(os.environ.get("ILCC_BENCH_MAX_DEPTH", "4"))))
 
     pending = []   # the previous step's gather, still in flight (one RCCL gather per step)
 

@@ -70,6 +70,7 @@ struct ilcc_handle {
   int32_t n_th2 = 0, n_ty2 = 0, n_tz2 = 0, seed_stride_th = 12, seed_stride_t = 2;
   bool seed_stride_env = false, seed_stride_t_env = false;
   bool refine_pass = true;   // (experiment hook: ILCC_K6_REFINE=0 skips the refinement pass)
+  bool chain_full_passes = true;   // (experiment hook: ILCC_K6_CHAIN=0 lets full passes of different batches overlap)
   // (experiment hooks: ILCC_SEED_STRIDE_TH / ILCC_SEED_STRIDE_T override the seed decimation)
   double* d_solve = nullptr;   // 3 theta_t + 2 (cost, iterations) for the test entry
   uint32_t grid_lds_points = 2048;
@@ -379,7 +380,7 @@ int32_t enqueue(ilcc_handle* h, int si, const float4* d_xyzi, const uint64_t* of
     // durations stay clean and they do not fight for LDS); the seed and refinement passes above are small,
     // latency-bound launches and are left free to overlap with another batch's full pass, like K2/K3/K7.
     HIP_TRY(h, hipEventRecord(sl.ev[7], s));
-    if (h->k6_last >= 0 && h->k6_last != si && h->slots[h->k6_last].busy)
+    if (h->chain_full_passes && h->k6_last >= 0 && h->k6_last != si && h->slots[h->k6_last].busy)
       HIP_TRY(h, hipStreamWaitEvent(s, h->slots[h->k6_last].k6_done, 0));
     HIP_TRY(h, hipEventRecord(sl.ev[8], s));
     full.tie_count = sl.d_tie_count;
@@ -593,6 +594,7 @@ ilcc_handle* ilcc_create(int32_t device, const ilcc_params* p, uint32_t max_fram
     h->seed_stride_env = true;
   }
   if (const char* e3 = std::getenv("ILCC_K6_REFINE")) h->refine_pass = std::atoi(e3) != 0;
+  if (const char* e4 = std::getenv("ILCC_K6_CHAIN")) h->chain_full_passes = std::atoi(e4) != 0;
   if (const char* e2 = std::getenv("ILCC_SEED_STRIDE_T")) {
     h->seed_stride_t = std::max(1, std::atoi(e2));
     h->seed_stride_t_env = true;
