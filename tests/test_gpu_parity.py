@@ -488,3 +488,35 @@ def test_near_tie_is_ordered_like_the_fp64_oracle(ob):
         assert r.status == 0 and ref.status == 0
         assert r.grid_index == ref.grid_index == 34756
         assert np.abs(r.corners_array() - ob.result_corners(ref)).max() < 1e-6
+
+
+def test_sparse_wide_roi_takes_the_hashed_lds_cell_lists(ob):
+    """K2's fourth neighbour search: <= 4096 ROI points whose bounding box needs more than 16 384 cells (a wide
+    ROI over a thinned cloud) -- the hashed-bucket LDS cell lists instead of the direct cell grid.  Stage counts and
+    the cluster cloud must equal the oracle's."""
+    board = synth.Board()
+    pose = synth.pose_from_fixture(1)
+    cloud = synth.make_frame(synth.vlp16(), board, pose, 11)
+    click = synth.make_click(pose, 11)
+    # keep the neighbourhood of the board dense (so that the click still lands in a >= 100-point cluster) and every
+    # 12th point elsewhere: ~3 k points spread over a 12 x 12 x 6 m box
+    near = np.linalg.norm(cloud[:, :3] - click[None, :], axis=1) < 0.9
+    keep = near | (np.arange(len(cloud)) % 12 == 0)
+    thin = np.ascontiguousarray(cloud[keep])
+    p = N.default_params()
+    p.roi_half[0], p.roi_half[1], p.roi_half[2] = 6.0, 6.0, 3.0
+    e = LidarCornersBatch(1, len(thin), p)
+    r = e.extract(thin[None], click[None])[0]
+    got = e.fetch_cloud(0, N.CLOUD_CLUSTER)
+    e.close()
+    op = ob.default_params()
+    op.solver = ob.SOLVER_GRID
+    op.roi_half[0], op.roi_half[1], op.roi_half[2] = 6.0, 6.0, 3.0
+    o, chess, pca = ob.extract(thin, click, op, want_clouds=True)
+    assert 256 < r.n_roi <= 4096, r.n_roi
+    ext = thin[:, :3].max(0) - thin[:, :3].min(0)
+    assert np.prod(np.floor(np.minimum(ext, [12, 12, 6]) / 0.12) + 1) > 16384      # the direct grid does not fit
+    assert (r.status, r.n_roi, r.n_cluster, r.n_plane) == (o.status, o.n_roi, o.n_cluster, o.n_plane)
+    assert r.n_cluster >= 100 and len(got) == r.n_cluster
+    if r.status == 0 and o.status == 0:
+        assert np.abs(r.corners_array() - ob.result_corners(o)).max() < 1e-5
