@@ -14,12 +14,17 @@ from oracle import binding as ob
 
 F = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 seed = int(sys.argv[2], 0) if len(sys.argv) > 2 else 0xBEEF
+mode = sys.argv[3] if len(sys.argv) > 3 else "grid"   # "grid" or "local" (the reference trajectory)
 board, lidar = synth.Board(), synth.vlp16()
 clouds, clicks, gts, _ = synth.make_batch(F, lidar, board, seed=seed)
-est = LidarCornersBatch(F, lidar.n_points, N.default_params(), device=0)
+gp = N.default_params()
+if mode == "local":
+    gp.solver = N.SOLVER_REFERENCE_LOCAL
+est = LidarCornersBatch(F, lidar.n_points, gp, device=0)
 res = est.extract(clouds, clicks)
 p = ob.default_params()
-p.solver = ob.SOLVER_GRID
+p.solver = ob.SOLVER_GRID if mode == "grid" else ob.SOLVER_REFERENCE_LOCAL
+p.phase_mode = 2
 p.accum_float = 0
 t0 = time.perf_counter()
 with cf.ThreadPoolExecutor(min(64, os.cpu_count() or 1)) as ex:
@@ -30,6 +35,7 @@ both = [f for f in range(F) if res[f].status == 0 and ref[f].status == 0]
 same_idx = sum(int(res[f].grid_index == ref[f].grid_index) for f in both)
 dev = [float(np.abs(res[f].corners_array() - ob.result_corners(ref[f])).max()) for f in both]
 it = sum(int(res[f].iters_a == ref[f].iters_a and res[f].iters_b == ref[f].iters_b) for f in both)
+print("mode", mode)
 print("frames %d  status agree %d  both ok %d  grid argmin identical %d  iteration counts identical %d  "
       "max corner deviation %.3g m  frames above 1e-6 m: %d" % (F, same_status, len(both), same_idx, it, max(dev) if dev else 0.0,
                                                              sum(d > 1e-6 for d in dev)))
