@@ -114,21 +114,34 @@ __global__ __launch_bounds__(kCropThreads) void k1_roi_scatter(Ctx c) {
   float4* __restrict__ dst = c.roi + beg;
   const unsigned long long* masks = c.crop_masks + ((uint64_t)f * c.crop_chunks + s) * (kCropChunk / ILCC_WAVE);
   constexpr int kWaves = kCropThreads / ILCC_WAVE, kMasks = kCropChunk / ILCC_WAVE;
+  static_assert(kMasks == ILCC_WAVE, "one keep-mask per lane of the first wavefront");
   const int lane = lane_id(), w = wave_id();
-  // this wavefront's loads are masks w, w + 4, ...; the rank of a survivor = survivors in all earlier masks
-  // (input order = mask order) + survivors below it in its own mask
-  uint32_t before = base;
-  int m = 0;
+  // rank of a survivor = survivors in all earlier masks (input order = mask order) + survivors below it in
+  // its own mask: the first wavefront turns the 64 mask popcounts into an exclusive prefix in LDS
+  __shared__ unsigned long long s_mask[kMasks];
+  __shared__ uint32_t s_before[kMasks];
+  if (w == 0) {
+    const unsigned long long mk = masks[lane];
+    uint32_t incl = (uint32_t)__popcll(mk);
+    const uint32_t own = incl;
+#pragma unroll
+    for (int o = 1; o < ILCC_WAVE; o <<= 1) {
+      const uint32_t t = __shfl_up(incl, o, ILCC_WAVE);
+      if (lane >= o) incl += t;
+    }
+    s_mask[lane] = mk;
+    s_before[lane] = base + incl - own;
+  }
+  __syncthreads();
+#pragma unroll
   for (int k = 0; k < kCropChunk / kCropThreads; ++k) {
     const int mine = k * kWaves + w;
-    for (; m < mine; ++m) before += (uint32_t)__popcll(masks[m]);
-    const unsigned long long mk = masks[mine];
+    const unsigned long long mk = s_mask[mine];
     if ((mk >> lane) & 1ull) {
       const uint64_t i = cbeg + (uint64_t)k * kCropThreads + threadIdx.x;
-      dst[before + (uint32_t)__popcll(mk & ((1ull << lane) - 1ull))] = src[i];
+      dst[s_before[mine] + (uint32_t)__popcll(mk & ((1ull << lane) - 1ull))] = src[i];
     }
   }
-  (void)kMasks;
 }
 
 void launch_roi_crop(const Ctx& c, hipStream_t s) {
