@@ -260,6 +260,7 @@ Ctx make_ctx(ilcc_handle* h, Slot& sl, const float4* d_xyzi, const float* d_clic
   c.grid_lds_points = h->grid_lds_points;
   c.grid_bound = sl.d_bound;
   c.tie_count = nullptr;   // only the full pass of K6 collects; K7a gets the pointers below
+  c.tie_count_all = sl.d_tie_count;
   c.tie_list = sl.d_tie_list;
   c.grid_iters = sl.d_iters;
   c.seed_partial = nullptr;
@@ -321,8 +322,7 @@ int32_t enqueue(ilcc_handle* h, int si, const float4* d_xyzi, const uint64_t* of
   sl.n_frames = n_frames;
   hipStream_t s = sl.stream;
   HIP_TRY(h, hipMemcpyAsync(sl.d_off, sl.off.data(), sizeof(uint64_t) * (n_frames + 1), hipMemcpyHostToDevice, s));
-  HIP_TRY(h, hipMemsetAsync(sl.d_count, 0, sizeof(uint32_t) * offsets[n_frames], s));
-  HIP_TRY(h, hipMemsetAsync(sl.d_res, 0, sizeof(ilcc_result) * n_frames, s));   // no stale fields in failed frames
+  // (result records, component counters, K6 counters and near-tie counters are reset inside K1 / K2)
   Ctx c = make_ctx(h, sl, d_xyzi, d_clicks, n_frames, chunks);
   if (no_crop)   // get_chessboard_by_point clusters the whole cloud: an unbounded box only drops non-finite points
     c.p.roi_half[0] = c.p.roi_half[1] = c.p.roi_half[2] = (double)INFINITY;
@@ -337,8 +337,6 @@ int32_t enqueue(ilcc_handle* h, int si, const float4* d_xyzi, const uint64_t* of
   launch_plane_frame_hist(c, s);
   sl.grid = !front_only && h->p.solver == ILCC_SOLVER_GRID;
   if (sl.grid) {
-    HIP_TRY(h, hipMemsetAsync(sl.d_iters, 0, sizeof(unsigned long long) * kIterSlots, s));
-    HIP_TRY(h, hipMemsetAsync(sl.d_tie_count, 0, sizeof(uint32_t) * n_frames, s));
   }
   HIP_TRY(h, hipEventRecord(sl.ev[4], s));
   if (sl.grid) {

@@ -83,6 +83,7 @@ struct Ctx {
   // near ties: candidates of the full pass whose fp32 cost is within kTieEps of the bound at the time they
   // complete; K7a recounts them in fp64 so that the argmin is the fp64 oracle's even when fp32 cannot order them
   uint32_t* tie_count;       // per frame (nullptr: this launch does not collect)
+  uint32_t* tie_count_all;   // the same array, always set: K1 resets it
   GridPartial* tie_list;     // n_frames x kTieCap: cost (fp32), d2, flat
   unsigned long long* grid_iters;  // executed K6 work in counts of grid_cost_evals_per_count() evaluations, for the VALU rate
   // seeding pass of the branch-and-bound (a decimated subset of the same grid, evaluated first)

@@ -96,7 +96,7 @@ __device__ void cluster_frame(const Ctx& c, uint32_t f, uint32_t* lds_parent, fl
   const float4* __restrict__ P = c.roi + beg;
   uint32_t* gparent = c.uf_parent + beg;
   uint32_t* parent = LDS_PARENT ? lds_parent : gparent;
-  uint32_t* count = c.uf_count + beg;   // zeroed by the host before the launch
+  uint32_t* count = c.uf_count + beg;   // zeroed below, together with the parents
   const float tol2 = (float)(c.p.cluster_tol * c.p.cluster_tol);
   const uint32_t tid = threadIdx.x;
 
@@ -104,7 +104,10 @@ __device__ void cluster_frame(const Ctx& c, uint32_t f, uint32_t* lds_parent, fl
   __shared__ unsigned long long tmark[12];
 #endif
   K2_MARK(0);
-  for (uint32_t i = tid; i < M; i += kFrameThreads) parent[i] = i;
+  for (uint32_t i = tid; i < M; i += kFrameThreads) {
+    parent[i] = i;
+    count[i] = 0u;   // component sizes, accumulated on the roots further down
+  }
   __syncthreads();
   K2_MARK(1);
 
