@@ -4,13 +4,17 @@
 // One 1024-thread workgroup per frame.  Single-linkage components of the radius graph
 // (squared float distance dx*dx+dy*dy+dz*dz < (float)(tol*tol), FLANN's strict test) are
 // built with a lock-free union-find whose parents live in LDS (<= 16384 ROI points, else a
-// global scratch array); neighbours are found by tiled all-pairs: 1024 "j" points staged in
-// LDS per tile, every lane holds its own "i" point in registers, LDS reads are wave-uniform
-// (broadcast).  Roots are always the smallest member index, so the labelling is
-// deterministic.  Neighbour search, three ways with identical results: all-pairs up to
-// ILCC_K2_ALLPAIRS_MAX points; cell lists held entirely in LDS (points, heads, links) up to 4096
-// points -- the ROI case; above that a spatial hash with chained buckets in global memory, which is
-// what un-cropped clouds (the online caller get_chessboard_by_point, LidarCornersEst.cpp:72-115) need.
+// global scratch array).  Roots are always the smallest member index, so the labelling is
+// deterministic.  Neighbour search, four ways with identical results:
+//   <= ILCC_K2_ALLPAIRS_MAX (256) points  tiled all-pairs (1024 "j" points per LDS tile, broadcast reads);
+//   <= 4096 points (the ROI case)          wave-cooperative search on a direct cell grid in LDS: points
+//                                          counting-sorted by cell, a wavefront per occupied cell, candidates in
+//                                          the lanes, own points through v_readlane, unions queued and executed
+//                                          64 at a time -- or, when the bounding box needs more than 16384 cells,
+//                                          per-point scans of counting-sorted hashed buckets in LDS;
+//   above                                  a spatial hash with chained buckets in global memory: what un-cropped
+//                                          clouds (the online caller get_chessboard_by_point,
+//                                          LidarCornersEst.cpp:72-115) need.
 // Cluster choice follows the reference: components with
 // cluster_min <= size <= cluster_max, sorted by size (largest = index 0); the one containing
 // the exact 1-NN of the click wins, otherwise index 0.  Members are emitted in index order.
