@@ -60,22 +60,53 @@ __device__ __forceinline__ float plane_dist(const float pl[4], const float4 q) {
   return fabsf(s);
 }
 
+// N block sums with ONE pair of barriers; the same combination order as block_sum (lane tree, then wavefronts in
+// index order), so every total is bit-identical to N separate block_sum calls
+template <int NV>
+__device__ __forceinline__ void block_sum_n(double (&v)[NV], double* scratch /* >= 16 * NV + NV */) {
+#pragma unroll
+  for (int k = 0; k < NV; ++k) v[k] = wave_sum(v[k]);
+  constexpr int kW = kFrameThreads / ILCC_WAVE;
+  __syncthreads();
+  if (lane_id() == 0) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) scratch[wave_id() * NV + k] = v[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    double t = scratch[k];
+    for (int w = 1; w < kW; ++w) t += scratch[w * NV + k];
+    v[k] = t;
+  }
+}
+
+constexpr int kRansacLdsPoints = 2048;   // cluster points staged in LDS (32 KiB); larger clusters are read through L2
+
 __global__ __launch_bounds__(kFrameThreads) void k3_ransac_plane(Ctx c) {
+  __shared__ float4 s_P[kRansacLdsPoints];
   __shared__ uint32_t sc[64];
-  __shared__ double scd[17];
+  __shared__ double scd[16 * 6 + 8];
   __shared__ float s_plane[4];
   const uint32_t f = blockIdx.x;
   ilcc_result* r = &c.res[f];
   if (r->status != ILCC_OK) return;
   const uint32_t M = (uint32_t)r->n_cluster;
   const uint64_t beg = c.off[f];
-  const float4* __restrict__ P = c.cluster + beg;
+  const float4* __restrict__ G = c.cluster + beg;
   const uint32_t tid = threadIdx.x;
   const int lane = lane_id(), wid = wave_id();
   const float thr = (float)c.p.ransac_thresh;
   if (M < 3) {
     if (tid == 0) r->status = ILCC_NO_PLANE;
     return;
+  }
+  // every hypothesis re-reads the whole cluster (128 x M points): from LDS, not from L2, when it fits
+  const float4* P = G;
+  if (M <= (uint32_t)kRansacLdsPoints) {
+    for (uint32_t i = tid; i < M; i += kFrameThreads) s_P[i] = G[i];
+    __syncthreads();
+    P = s_P;
   }
 
   // ---- score hypotheses, one per wavefront pass
@@ -138,9 +169,9 @@ __global__ __launch_bounds__(kFrameThreads) void k3_ransac_plane(Ctx c) {
         sz += q.z;
       }
     }
-    const double cx = block_sum<double>(sx, scd) / bc;
-    const double cy = block_sum<double>(sy, scd) / bc;
-    const double cz = block_sum<double>(sz, scd) / bc;
+    double sums3[3] = {sx, sy, sz};
+    block_sum_n<3>(sums3, scd);
+    const double cx = sums3[0] / bc, cy = sums3[1] / bc, cz = sums3[2] / bc;
     double cv[6] = {0, 0, 0, 0, 0, 0};
     for (uint32_t i = tid; i < M; i += kFrameThreads) {
       const float4 q = P[i];
@@ -154,8 +185,10 @@ __global__ __launch_bounds__(kFrameThreads) void k3_ransac_plane(Ctx c) {
         cv[5] += dz * dz;
       }
     }
+    __syncthreads();   // scd is reused
+    block_sum_n<6>(cv, scd);
     double cs[6];
-    for (int k = 0; k < 6; ++k) cs[k] = block_sum<double>(cv[k], scd) / bc;
+    for (int k = 0; k < 6; ++k) cs[k] = cv[k] / bc;
     if (tid == 0) {
       const double cov[9] = {cs[0], cs[1], cs[2], cs[1], cs[3], cs[4], cs[2], cs[4], cs[5]};
       double w[3], v[3][3];
