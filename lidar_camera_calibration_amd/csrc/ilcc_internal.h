@@ -133,6 +133,27 @@ __device__ __forceinline__ T block_sum(T v, T* scratch) {
   return scratch[16];
 }
 
+// N block sums with ONE pair of barriers; the same combination order as block_sum (lane tree, then wavefronts in
+// index order), so every total is bit-identical to N separate block_sum calls
+template <int NV>
+__device__ __forceinline__ void block_sum_n(double (&v)[NV], double* scratch /* >= 16 * NV + NV */) {
+#pragma unroll
+  for (int k = 0; k < NV; ++k) v[k] = wave_sum(v[k]);
+  const int kW = (blockDim.x + ILCC_WAVE - 1) / ILCC_WAVE;
+  __syncthreads();
+  if (lane_id() == 0) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) scratch[wave_id() * NV + k] = v[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    double t = scratch[k];
+    for (int w = 1; w < kW; ++w) t += scratch[w * NV + k];
+    v[k] = t;
+  }
+}
+
 // exclusive scan of 0/1 flags over the workgroup (thread order); returns rank, total via ref.
 // scratch: >= 17 uint32 in LDS.
 __device__ __forceinline__ uint32_t block_rank(bool flag, uint32_t* scratch, uint32_t& total) {

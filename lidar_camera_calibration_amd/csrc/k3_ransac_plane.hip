@@ -60,27 +60,6 @@ __device__ __forceinline__ float plane_dist(const float pl[4], const float4 q) {
   return fabsf(s);
 }
 
-// N block sums with ONE pair of barriers; the same combination order as block_sum (lane tree, then wavefronts in
-// index order), so every total is bit-identical to N separate block_sum calls
-template <int NV>
-__device__ __forceinline__ void block_sum_n(double (&v)[NV], double* scratch /* >= 16 * NV + NV */) {
-#pragma unroll
-  for (int k = 0; k < NV; ++k) v[k] = wave_sum(v[k]);
-  constexpr int kW = kFrameThreads / ILCC_WAVE;
-  __syncthreads();
-  if (lane_id() == 0) {
-#pragma unroll
-    for (int k = 0; k < NV; ++k) scratch[wave_id() * NV + k] = v[k];
-  }
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < NV; ++k) {
-    double t = scratch[k];
-    for (int w = 1; w < kW; ++w) t += scratch[w * NV + k];
-    v[k] = t;
-  }
-}
-
 constexpr int kRansacLdsPoints = 2048;   // cluster points staged in LDS (32 KiB); larger clusters are read through L2
 
 __global__ __launch_bounds__(kFrameThreads) void k3_ransac_plane(Ctx c) {

@@ -16,7 +16,7 @@ namespace ilcc {
 
 __global__ __launch_bounds__(kFrameThreads) void k45_plane_frame_hist(Ctx c) {
   __shared__ uint32_t sc[64];
-  __shared__ double scd[17];
+  __shared__ double scd[16 * 6 + 8];
   __shared__ float s_pca[16];
   __shared__ float s_mm[2 * (kFrameThreads / ILCC_WAVE) + 2];
   __shared__ double s_gz[2];
@@ -49,10 +49,12 @@ __global__ __launch_bounds__(kFrameThreads) void k45_plane_frame_hist(Ctx c) {
     vmax = fmaxf(vmax, q.w);
   }
   // centroid narrowed to float like pcl's Vector4f, then used in double
-  const double cx = (double)(float)(block_sum<double>(sx, scd) / M);
-  const double cy = (double)(float)(block_sum<double>(sy, scd) / M);
-  const double cz = (double)(float)(block_sum<double>(sz, scd) / M);
-  const double isum = block_sum<double>(si, scd);
+  double s4[4] = {sx, sy, sz, si};
+  block_sum_n<4>(s4, scd);   // one pair of barriers, totals bit-identical to four block_sum calls
+  const double cx = (double)(float)(s4[0] / M);
+  const double cy = (double)(float)(s4[1] / M);
+  const double cz = (double)(float)(s4[2] / M);
+  const double isum = s4[3];
   double cv[6] = {0, 0, 0, 0, 0, 0};
   for (uint32_t i = tid; i < M; i += kFrameThreads) {
     const float4 q = P[i];
@@ -64,8 +66,10 @@ __global__ __launch_bounds__(kFrameThreads) void k45_plane_frame_hist(Ctx c) {
     cv[4] += dy * dz;
     cv[5] += dz * dz;
   }
+  __syncthreads();   // scd is reused
+  block_sum_n<6>(cv, scd);
   double cs[6];
-  for (int k = 0; k < 6; ++k) cs[k] = block_sum<double>(cv[k], scd) / M;
+  for (int k = 0; k < 6; ++k) cs[k] = cv[k] / M;
   // min / max intensity
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -155,45 +159,41 @@ __global__ __launch_bounds__(kFrameThreads) void k45_plane_frame_hist(Ctx c) {
   }
   __syncthreads();
 
+  // std::map<count, first bin with that count>, walked from the largest count down until one edge above and one
+  // below the mean have been seen (:261-282).  Equivalent, and parallel over the bins: among the bins that are
+  // the FIRST with their count, `high` is the edge of the one with the largest count on the upper side of the
+  // mean, `low` the same on the lower side (representatives have distinct counts, so there are no ties; an edge
+  // equal to the mean is on neither side).  The serial walk by one thread was ~50 us of this kernel.
+  __shared__ unsigned long long s_top[2];   // per side of the mean: (count + 1) << 32 | bin, 0 = none
+  if (tid == 0) s_top[0] = s_top[1] = 0ull;
+  __syncthreads();
+  const bool hist_ok = !(flat || HL <= 0);
+  const double mean = isum / M;              // :245-248
+  const double bin_width = (mx - mn) / HL;   // :258
+  if (hist_ok) {
+    for (int bb = (int)tid; bb < HL; bb += kFrameThreads) {
+      const int cb = s_hist[bb];
+      bool first = true;
+      for (int b2 = 0; b2 < bb; ++b2) first = first && (s_hist[b2] != cb);
+      if (!first) continue;
+      const double edge = bin_width * (double)bb + mn;   // :269
+      const int side = edge > mean ? 1 : (edge < mean ? 0 : -1);
+      if (side >= 0) atomicMax(&s_top[side], ((unsigned long long)(uint32_t)(cb + 1) << 32) | (unsigned long long)(uint32_t)bb);
+    }
+  }
+  __syncthreads();
   if (tid == 0) {
     int status = ILCC_OK;
-    if (flat || HL <= 0) {
+    if (!hist_ok || s_top[0] == 0ull || s_top[1] == 0ull) {
       status = ILCC_DEGENERATE_HIST;
     } else {
-      const double mean = isum / M;              // :245-248
-      const double bin_width = (mx - mn) / HL;   // :258
-      // std::map<count, first bin with that count>, walked from the largest count down (:261-282)
-      bool low_found = false, high_found = false;
-      double low = -1, high = -1;
-      int prev = 0x7fffffff;
-      for (;;) {
-        int bestc = -1;
-        for (int b = 0; b < HL; ++b)
-          if (s_hist[b] < prev && s_hist[b] > bestc) bestc = s_hist[b];
-        if (bestc < 0) break;
-        int index = 0;
-        while (s_hist[index] != bestc) ++index;
-        const double edge = bin_width * (double)index + mn;   // :269
-        if (edge > mean && !high_found) {
-          high_found = true;
-          high = edge;
-        }
-        if (edge < mean && !low_found) {
-          low_found = true;
-          low = edge;
-        }
-        if (low_found && high_found) break;
-        prev = bestc;
-      }
-      if (!low_found || !high_found) {
-        status = ILCC_DEGENERATE_HIST;
-      } else {
-        const double rate = c.p.gray_rate;
-        s_gz[0] = ((rate - 1) * low + high) / rate;   // :322
-        s_gz[1] = (low + (rate - 1) * high) / rate;   // :323
-        r->gray_zone[0] = s_gz[0];
-        r->gray_zone[1] = s_gz[1];
-      }
+      const double low = bin_width * (double)(uint32_t)(s_top[0] & 0xFFFFFFFFull) + mn;
+      const double high = bin_width * (double)(uint32_t)(s_top[1] & 0xFFFFFFFFull) + mn;
+      const double rate = c.p.gray_rate;
+      s_gz[0] = ((rate - 1) * low + high) / rate;   // :322
+      s_gz[1] = (low + (rate - 1) * high) / rate;   // :323
+      r->gray_zone[0] = s_gz[0];
+      r->gray_zone[1] = s_gz[1];
     }
     s_status = status;
     if (status != ILCC_OK) r->status = status;
