@@ -10,7 +10,7 @@
 // 4 x 4 (ty, tz) candidates; lane = candidate * 4 + slice: the four lanes of a quad evaluate the SAME
 // candidate on four interleaved quarters of the point walk and keep private running sums (both
 // colour phases).  The branch-and-bound test therefore needs only a quad reduction -- four DPP adds --
-// and runs every 16 points: a tile stops the moment each of its candidates is provably beaten.
+// and runs every 12 points: a tile stops the moment each of its candidates is provably beaten.
 // History of this mapping, measured on the 128-frame batch:
 //  * lanes = points, 4 x 4 candidates in registers (round-1 first design): 14.5 VALU per evaluation
 //    thanks to separable i/j terms, but every test needed a ~130-instruction transposed reduction over
@@ -40,7 +40,10 @@ namespace ilcc {
 #endif
 constexpr int kTile = 4;          // 4 x 4 candidates per wavefront; lane = ((a << 2) | b) << 2 | slice
 constexpr int kSlices = 4;        // lanes (one quad) sharing a candidate, each on every 4th point of the walk
-constexpr int kUnroll = 4;        // points per lane between bound tests (16 points of the walk)
+#ifndef ILCC_K6_UNROLL
+#define ILCC_K6_UNROLL 3
+#endif
+constexpr int kUnroll = ILCC_K6_UNROLL;        // points per lane between bound tests (3 -> every 12 points of the walk; measured 2: 179 k, 3: 181 k, 4: 178 k, 6: 167 k frames/s)
 constexpr int kStep = kSlices * kUnroll;
 constexpr int kBoundRefresh = ILCC_K6_BOUND_REFRESH; // points between reloads of the frame's shared bound
 
@@ -282,7 +285,7 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
     }
     if (!(PRUNE && pruned)) {
       if (!LDS_POINTS) idx = (uint32_t)(((uint64_t)(pos + my_s) * S) % M);
-      for (; pos < M; pos += kSlices) {   // tail (< 16 points): one point per lane and trip, lanes past the end idle
+      for (; pos < M; pos += kSlices) {   // tail (< 12 points): one point per lane and trip, lanes past the end idle
         const uint32_t at = pos + my_s;
         if (at < M) {
           const PointTerms p1 = fetch(at);
