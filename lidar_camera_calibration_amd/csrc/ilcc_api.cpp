@@ -70,6 +70,7 @@ struct ilcc_handle {
   int32_t n_th2 = 0, n_ty2 = 0, n_tz2 = 0, seed_stride_th = 12, seed_stride_t = 2;
   bool seed_stride_env = false, seed_stride_t_env = false;
   bool refine_pass = true;   // (experiment hook: ILCC_K6_REFINE=0 skips the refinement pass)
+  int refine_radius_env = 0;        // (experiment hook: ILCC_K6_REFINE_RADIUS)
   bool chain_full_passes = true;   // (experiment hook: ILCC_K6_CHAIN=0 lets full passes of different batches overlap)
   // (experiment hooks: ILCC_SEED_STRIDE_TH / ILCC_SEED_STRIDE_T override the seed decimation)
   double* d_solve = nullptr;   // 3 theta_t + 2 (cost, iterations) for the test entry
@@ -368,7 +369,7 @@ int32_t enqueue(ilcc_handle* h, int si, const float4* d_xyzi, const uint64_t* of
       if (h->refine_pass) {
         // refinement pass: all candidates around the seed argmin (theta +- half a seed stride, 16 x 16 translations)
         Ctx refine = full;
-        refine.refine_radius_th = std::max(1, h->seed_stride_th / 2);
+        refine.refine_radius_th = h->refine_radius_env > 0 ? h->refine_radius_env : std::max(1, h->seed_stride_th / 2);
         refine.grid_blocks = std::min((uint32_t)(2 * refine.refine_radius_th + 1), h->max_theta);
         refine.partial = sl.d_partial3;
         launch_grid_cost(refine, s, /*use_oob=*/1, nullptr, true);
@@ -593,6 +594,7 @@ ilcc_handle* ilcc_create(int32_t device, const ilcc_params* p, uint32_t max_fram
   }
   if (const char* e3 = std::getenv("ILCC_K6_REFINE")) h->refine_pass = std::atoi(e3) != 0;
   if (const char* e4 = std::getenv("ILCC_K6_CHAIN")) h->chain_full_passes = std::atoi(e4) != 0;
+  if (const char* e6 = std::getenv("ILCC_K6_REFINE_RADIUS")) h->refine_radius_env = std::atoi(e6);
   if (const char* e2 = std::getenv("ILCC_SEED_STRIDE_T")) {
     h->seed_stride_t = std::max(1, std::atoi(e2));
     h->seed_stride_t_env = true;

@@ -15,7 +15,10 @@ namespace ilcc {
 constexpr int kCropThreads = 256;      // K1
 constexpr int kCropChunk = 4096;       // points per K1 block
 constexpr int kFrameThreads = 1024;    // K2..K5, K7: one workgroup per frame
-constexpr int kGridThreads = 256;      // K6: 4 wavefronts per workgroup
+#ifndef ILCC_K6_THREADS
+#define ILCC_K6_THREADS 256
+#endif
+constexpr int kGridThreads = ILCC_K6_THREADS;      // K6: wavefronts x 64 per workgroup (measured: see DESIGN.md)
 constexpr int kTileA = 4;              // K6 candidate tile: ty values per wavefront pass
 #ifndef ILCC_TILE_B
 #define ILCC_TILE_B 4
