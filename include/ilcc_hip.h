@@ -36,7 +36,7 @@ extern "C" {
 #endif
 
 #define ILCC_MAX_CORNERS 256
-#define ILCC_ABI_VERSION 1
+#define ILCC_ABI_VERSION 2
 
 /* per-frame / per-call status */
 enum {
@@ -50,8 +50,17 @@ enum {
   ILCC_CAPACITY = 7,        /* more frames / points than the handle was created for */
   ILCC_HIP_ERROR = 8,
   ILCC_IO_ERROR = 9,
-  ILCC_BOARD_NOT_FOUND = 10 /* get_chessboard_by_point returned false (plane < 500 points or no cluster
-                               around the predicted centre), LidarCornersEst.cpp:111-112 */
+  ILCC_BOARD_NOT_FOUND = 10, /* get_chessboard_by_point returned false (plane < 500 points or no cluster
+                                around the predicted centre), LidarCornersEst.cpp:111-112 */
+  ILCC_AMBIGUOUS = 11        /* ILCC_SOLVER_GRID: a basin one square away costs (almost) the same as the chosen one
+                                (basin_margin < ambiguity_eps); corners ARE written.  The reference leaves this call to
+                                the human at the viewer (keys 'd' / 'r', LidarCornersEst.cpp:415-437) */
+};
+
+/* ilcc_result.flags */
+enum {
+  ILCC_FLAG_TIE_OVERFLOW = 1 /* more than 256 grid candidates within 2e-5 of the minimum: the fixed-point recount of
+                                near ties was skipped and the fp32 argmin (same tie-break) was used */
 };
 
 /* how (theta, ty, tz) is found */
@@ -59,8 +68,11 @@ enum {
   /* the reference's own trajectory: Ceres-style local solve from (0,0,0), pass A (out-of-board
    * term on) then pass B (off) -- LidarCornersEst.cpp:398-409 */
   ILCC_SOLVER_REFERENCE_LOCAL = 0,
-  /* exhaustive (theta,ty,tz) x colour-phase grid on the pass-A cost, one wavefront per candidate
-   * tile, then the same local A+B polish started from the grid argmin */
+  /* exhaustive (theta,ty,tz) x colour-phase grid on the pass-A cost (out-of-board term on), one
+   * wavefront per candidate tile; then a monotone pattern search on the same cost (27-point stencil on a lattice
+   * of step / refine_div, fixed-point sums) and a check of the eight neighbouring one-square-shifted basins.
+   * No Ceres-style iteration in this mode: the reference's two solves, restated faithfully, stop at their
+   * 50-iteration caps and can leave the cost higher than where they started. */
   ILCC_SOLVER_GRID = 1
 };
 
@@ -106,6 +118,14 @@ typedef struct ilcc_params {
   double th_min, th_step;
   double ty_min, ty_step;
   double tz_min, tz_step;
+  /* ILCC_SOLVER_GRID refinement */
+  int32_t refine_div;        /* finest lattice = grid step / refine_div; power of two <= 64 (default 16), 0: keep the grid argmin */
+  int32_t refine_max_rounds; /* bound on the 27-candidate rounds of one pattern search (default 64) */
+  int32_t refine_th_margin;  /* the search may leave the grid's theta range by this many grid steps (default 32) */
+  int32_t reserved0;
+  double ambiguity_eps;      /* status ILCC_AMBIGUOUS when basin_margin < ambiguity_eps (default 0.25; <= 0: never) */
+  /* get_chessboard_by_point hard-codes its own tolerance: setClusterTolerance(0.1), LidarCornersEst.cpp:80 */
+  double online_cluster_tol;
 } ilcc_params;
 
 typedef struct ilcc_result {
@@ -115,7 +135,7 @@ typedef struct ilcc_result {
   int32_t n_black, n_gray, n_white;
   int32_t n_corners;
   int32_t phase;               /* topleftWhite chosen (0/1) */
-  int32_t iters_a, iters_b;
+  int32_t iters_a, iters_b;    /* REFERENCE_LOCAL: trust-region iterations of pass A / B; GRID: refinement rounds / basin hops */
   int32_t grid_index;          /* ((k*n_ty+a)*n_tz+b)*2+phase of the grid argmin, -1 if unused */
   int32_t found_board;         /* 1: the cluster holding the click's nearest point was admissible
                                   (find_board of get_chessboard_by_point, LidarCornersEst.cpp:91-102) */
@@ -124,8 +144,13 @@ typedef struct ilcc_result {
   float pca[16];               /* row-major 4x4 pca_matrix (lidar -> plane frame) */
   double gray_zone[2];
   double theta_t[3];
-  double cost_a, cost_b;       /* final cost of pass A / pass B */
+  double cost_a, cost_b;       /* REFERENCE_LOCAL: final cost of pass A / pass B; GRID: cost_a = sel_cost, cost_b = cost of
+                                  the cheapest neighbouring basin */
   double sel_cost;             /* with-OOB cost at theta_t */
+  double basin_margin;         /* GRID: (cost_b - sel_cost) / sel_cost -- how much worse the best one-square-shifted
+                                  alternative is; 0 = the data cannot tell the two apart */
+  int32_t flags;               /* ILCC_FLAG_* */
+  int32_t grid_ties;           /* GRID: candidates the grid pass listed within 2e-5 of its minimum */
   float corners[ILCC_MAX_CORNERS * 3]; /* x y z, outer loop short board axis, inner long axis */
 } ilcc_result;
 
@@ -182,15 +207,19 @@ int32_t ilcc_submit_batch_device(ilcc_handle* h, const float* d_xyzi, const uint
                                  uint32_t n_frames, const float* d_clicks, int32_t* ticket);
 int32_t ilcc_wait(ilcc_handle* h, int32_t ticket, ilcc_result* out);
 /* ilcc_wait that also leaves, in device memory, the fixed-size records the multi-GPU gather ships
- * (one collective of corner records per step): d_records[n_frames][16 + 3*n_corners]
+ * (one collective of corner records per step): d_records[n_frames][ILCC_RECORD_HEADER + 3*n_corners]
  * floats = status, n_corners, phase, grid_index, iters_a, iters_b, cost_a, cost_b, sel_cost, theta,
- * ty, tz, n_plane, n_black, n_white, 0, then x y z per corner (zero beyond the frame's n_corners).
+ * ty, tz, n_plane, n_black, n_white, basin_margin, tag (= tag_base + frame index: lets the receiver check WHOSE
+ * record sits where), check (24-bit xor-fold of the corner bits and the tag: lets it check the contents), flags, 0,
+ * then x y z per corner (zero beyond the frame's n_corners).
  * Complete on return, so the caller can hand the buffer to RCCL on any stream. */
-int32_t ilcc_wait_records_device(ilcc_handle* h, int32_t ticket, ilcc_result* out, void* d_records, uint32_t n_corners);
+#define ILCC_RECORD_HEADER 20
+int32_t ilcc_wait_records_device(ilcc_handle* h, int32_t ticket, ilcc_result* out, void* d_records, uint32_t n_corners,
+                                 uint32_t tag_base);
 
 /* LidarCornersEst::get_chessboard_by_point (LidarCornersEst.cpp:72-115), the front half of the path as
  * the online node uses it (ilcc2/test/lidar_chessboard_online.cpp:91-101): NO ROI crop, Euclidean
- * clustering of the whole cloud with params.cluster_tol (the reference uses 0.10 here), the cluster
+ * clustering of the whole cloud with params.online_cluster_tol (0.10, LidarCornersEst.cpp:80), the cluster
  * around `points[f]`, getPlane, then get_gray_zone(rate = params.gray_rate) for colouring.
  * status per frame: ILCC_OK (reference: true) or ILCC_BOARD_NOT_FOUND / another failure (false).
  * The plane cloud (`outcloud`) is ILCC_CLOUD_CHESSBOARD; ilcc_fetch_classes gives the
@@ -215,6 +244,13 @@ int64_t ilcc_fetch_labelled(ilcc_handle* h, uint32_t frame, float* out_yz, uint8
  * selects it.  Test/diagnostic entry of the hot kernel. */
 int32_t ilcc_grid_cost(ilcc_handle* h, const float* yz, const uint8_t* label, uint32_t m,
                        int32_t use_oob, float* cost_out, int32_t* best_index, float* best_cost);
+
+/* the GRID-mode refinement kernel on caller-supplied labelled points: lat[3] in/out are lattice coordinates
+ * (theta, ty, tz) in units of step / refine_div from (th_min, ty_min, tz_min), *phase in/out; out: fixed-point
+ * costs (units of 2^-40) of the result and of the cheapest neighbouring basin, rounds and hops executed.
+ * Test/diagnostic entry. */
+int32_t ilcc_pattern_refine(ilcc_handle* h, const float* yz, const uint8_t* label, uint32_t m, int32_t lat[3],
+                            int32_t* phase, int64_t* cost_q, int64_t* alt_cost_q, int32_t* rounds, int32_t* hops);
 
 /* the local solver (Optimization::get_theta_t) on caller-supplied labelled points */
 int32_t ilcc_get_theta_t(ilcc_handle* h, const float* yz, const uint8_t* label, uint32_t m,

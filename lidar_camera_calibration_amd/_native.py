@@ -16,7 +16,10 @@ LIB_PATH = os.environ.get("ILCC_HIP_LIB") or os.path.join(_HERE, "libilcc_hip.so
 MAX_CORNERS = 256
 
 OK, NO_ROI_POINTS, NO_CLUSTER, NO_PLANE, DEGENERATE_HIST, TOO_FEW_POINTS, BAD_ARGUMENT, CAPACITY, \
-    HIP_ERROR, IO_ERROR, BOARD_NOT_FOUND = range(11)
+    HIP_ERROR, IO_ERROR, BOARD_NOT_FOUND, AMBIGUOUS = range(12)
+FLAG_TIE_OVERFLOW = 1
+RECORD_HEADER = 20
+COST_Q_ONE = float(1 << 40)
 SOLVER_REFERENCE_LOCAL, SOLVER_GRID = 0, 1
 CLOUD_ROI, CLOUD_CLUSTER, CLOUD_CHESSBOARD, CLOUD_PCA, CLOUD_OPTIM = range(5)
 
@@ -25,7 +28,7 @@ EXPORTS = [
     "ilcc_abi_version", "ilcc_strerror", "ilcc_last_error", "ilcc_default_params",
     "ilcc_set_chessboard_param", "ilcc_create", "ilcc_destroy", "ilcc_set_params", "ilcc_extract",
     "ilcc_extract_batch", "ilcc_extract_batch_device", "ilcc_submit_batch_device", "ilcc_wait", "ilcc_wait_records_device", "ilcc_fetch_cloud", "ilcc_fetch_labelled", "ilcc_chessboard_by_point_batch", "ilcc_fetch_classes",
-    "ilcc_grid_cost", "ilcc_get_theta_t", "ilcc_get_timing", "ilcc_reset_timing",
+    "ilcc_grid_cost", "ilcc_pattern_refine", "ilcc_get_theta_t", "ilcc_get_timing", "ilcc_reset_timing",
     "ilcc_save_corners2txt", "ilcc_read_lidar_corners",
 ]
 
@@ -53,6 +56,10 @@ class Params(C.Structure):
         ("th_min", C.c_double), ("th_step", C.c_double),
         ("ty_min", C.c_double), ("ty_step", C.c_double),
         ("tz_min", C.c_double), ("tz_step", C.c_double),
+        ("refine_div", C.c_int32), ("refine_max_rounds", C.c_int32),
+        ("refine_th_margin", C.c_int32), ("reserved0", C.c_int32),
+        ("ambiguity_eps", C.c_double),
+        ("online_cluster_tol", C.c_double),
     ]
 
 
@@ -74,6 +81,9 @@ class Result(C.Structure):
         ("theta_t", C.c_double * 3),
         ("cost_a", C.c_double), ("cost_b", C.c_double),
         ("sel_cost", C.c_double),
+        ("basin_margin", C.c_double),
+        ("flags", C.c_int32),
+        ("grid_ties", C.c_int32),
         ("corners", C.c_float * (MAX_CORNERS * 3)),
     ]
 
@@ -129,7 +139,7 @@ def lib():
         L.ilcc_submit_batch_device.restype = C.c_int32
         L.ilcc_wait.argtypes = [vp, C.c_int32, rp]
         L.ilcc_wait.restype = C.c_int32
-        L.ilcc_wait_records_device.argtypes = [vp, C.c_int32, rp, vp, C.c_uint32]
+        L.ilcc_wait_records_device.argtypes = [vp, C.c_int32, rp, vp, C.c_uint32, C.c_uint32]
         L.ilcc_wait_records_device.restype = C.c_int32
         L.ilcc_chessboard_by_point_batch.argtypes = [vp, fp, C.POINTER(C.c_uint64), C.c_uint32, fp, C.c_int32, rp]
         L.ilcc_chessboard_by_point_batch.restype = C.c_int32
@@ -142,6 +152,10 @@ def lib():
         L.ilcc_grid_cost.argtypes = [vp, fp, C.POINTER(C.c_uint8), C.c_uint32, C.c_int32, fp,
                                      C.POINTER(C.c_int32), fp]
         L.ilcc_grid_cost.restype = C.c_int32
+        L.ilcc_pattern_refine.argtypes = [vp, fp, C.POINTER(C.c_uint8), C.c_uint32, C.POINTER(C.c_int32),
+                                          C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                          C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        L.ilcc_pattern_refine.restype = C.c_int32
         L.ilcc_get_theta_t.argtypes = [vp, fp, C.POINTER(C.c_uint8), C.c_uint32, C.c_int32, C.c_int32,
                                        C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32)]
         L.ilcc_get_theta_t.restype = C.c_int32

@@ -68,12 +68,12 @@ struct ilcc_handle {
   // decimated subset of the same tables: seeding pass of K6's branch and bound
   float *d_cth2 = nullptr, *d_sth2 = nullptr, *d_ay2 = nullptr, *d_az2 = nullptr;
   int32_t n_th2 = 0, n_ty2 = 0, n_tz2 = 0, seed_stride_th = 12, seed_stride_t = 2;
-  bool seed_stride_env = false, seed_stride_t_env = false;
-  bool refine_pass = true;   // (experiment hook: ILCC_K6_REFINE=0 skips the refinement pass)
-  int refine_radius_env = 0;        // (experiment hook: ILCC_K6_REFINE_RADIUS)
-  bool chain_full_passes = true;   // (experiment hook: ILCC_K6_CHAIN=0 lets full passes of different batches overlap)
-  // (experiment hooks: ILCC_SEED_STRIDE_TH / ILCC_SEED_STRIDE_T override the seed decimation)
-  double* d_solve = nullptr;   // 3 theta_t + 2 (cost, iterations) for the test entry
+  // K7r: cos/sin of the theta lattice (grid step / refine_div, refine_th_margin grid steps beyond the grid on both sides)
+  double2* d_th_lattice = nullptr;
+  size_t th_lattice_cap = 0;
+  int32_t th_lat_lo = 0, th_lat_hi = 0, hop_y = 0, hop_z = 0;
+  double* d_solve = nullptr;   // 3 theta_t + 2 (cost, iterations) for the test entries
+  RefineOut* d_refine_io = nullptr;
   uint32_t grid_lds_points = 2048;
   ilcc_timing timing{};
   std::string err;
@@ -116,6 +116,15 @@ bool params_ok(const ilcc_params& p, std::string& why) {
   if (p.grid_prune != 0 && p.grid_prune != 1) return bad("grid_prune must be 0 or 1");
   if (p.max_iterations < 0 || p.max_iterations > 100000) return bad("max_iterations");
   if (p.n_th < 1 || p.n_ty < 1 || p.n_tz < 1) return bad("grid sizes must be >= 1");
+  if (p.n_th > 4096 || p.n_ty > 4096 || p.n_tz > 4096) return bad("grid axes are limited to 4096 candidates");
+  // K6 keeps the (ty, tz) tables in LDS behind the staged points: the raised dynamic-LDS limit covers kGridTableMax floats
+  if (p.n_ty + p.n_tz > kGridTableMax) return bad("n_ty + n_tz exceeds the LDS table capacity of the grid kernel");
+  if (p.refine_div < 0 || p.refine_div > 64 || (p.refine_div & (p.refine_div - 1)) != 0)
+    return bad("refine_div must be 0 or a power of two <= 64");
+  if (p.refine_max_rounds < 0 || p.refine_max_rounds > 4096) return bad("refine_max_rounds");
+  if (p.refine_th_margin < 0 || p.refine_th_margin > 4096) return bad("refine_th_margin");
+  if (!(p.online_cluster_tol > 0)) return bad("online_cluster_tol must be > 0");
+  if (!(p.ambiguity_eps == p.ambiguity_eps)) return bad("ambiguity_eps is NaN");
   if ((uint64_t)p.n_th * p.n_ty * p.n_tz * 2ull >= 0xFFFFFFFFull) return bad("grid too large");
   if (!(p.th_step > 0) || !(p.ty_step > 0) || !(p.tz_step > 0)) return bad("grid steps must be > 0");
   return true;
@@ -152,8 +161,8 @@ int32_t upload_tables(ilcc_handle* h) {
   // pass then evaluates everything around its argmin (theta +- half a seed stride, 8 x 8 translations), which
   // on the synthetic VLP-16 set yields the exact grid minimum as the bound in 46 of 46 frames (seed alone:
   // 3-20 x the minimum).  Measured on the 128-frame batch (K6 ms): translation stride 2: 1.05, 4: 0.91, 5: 0.83.
-  if (!h->seed_stride_env) h->seed_stride_th = std::max(2, p.n_th / 5);
-  if (!h->seed_stride_t_env) h->seed_stride_t = std::max(1, std::min(p.n_ty, p.n_tz) / 8);
+  h->seed_stride_th = std::max(2, p.n_th / 5);
+  h->seed_stride_t = std::max(1, std::min(p.n_ty, p.n_tz) / 8);
   std::vector<float> cth2, sth2, ay2, az2;
   for (int k = h->seed_stride_th / 2; k < p.n_th; k += h->seed_stride_th) {
     cth2.push_back(cth[k]);
@@ -169,6 +178,30 @@ int32_t upload_tables(ilcc_handle* h) {
     HIP_TRY(h, hipMemcpyAsync(h->d_sth2, sth2.data(), sizeof(float) * sth2.size(), hipMemcpyHostToDevice, st));
     HIP_TRY(h, hipMemcpyAsync(h->d_ay2, ay2.data(), sizeof(float) * ay2.size(), hipMemcpyHostToDevice, st));
     HIP_TRY(h, hipMemcpyAsync(h->d_az2, az2.data(), sizeof(float) * az2.size(), hipMemcpyHostToDevice, st));
+  }
+  // K7r: cos/sin of every theta lattice point, from the host's libm -- the oracle evaluates cos()/sin() of the
+  // SAME doubles (th_min + q * (th_step / div)) with the same libm, so the kernel's per-point terms are the oracle's
+  {
+    const int div = p.refine_div > 0 ? p.refine_div : 1;
+    h->th_lat_lo = -p.refine_th_margin * div;
+    h->th_lat_hi = (p.n_th - 1 + p.refine_th_margin) * div;
+    const size_t n = (size_t)(h->th_lat_hi - h->th_lat_lo) + 1;
+    if (n > h->th_lattice_cap) {
+      if (h->d_th_lattice) (void)hipFree(h->d_th_lattice);
+      h->d_th_lattice = nullptr;
+      h->th_lattice_cap = 0;
+      HIP_TRY(h, hipMalloc((void**)&h->d_th_lattice, sizeof(double2) * n));
+      h->th_lattice_cap = n;
+    }
+    std::vector<double2> tab(n);
+    for (size_t i = 0; i < n; ++i) {
+      const double th = p.th_min + (double)(h->th_lat_lo + (int64_t)i) * (p.th_step / (double)div);
+      tab[i] = make_double2(std::cos(th), std::sin(th));
+    }
+    HIP_TRY(h, hipMemcpyAsync(h->d_th_lattice, tab.data(), sizeof(double2) * n, hipMemcpyHostToDevice, st));
+    HIP_TRY(h, hipStreamSynchronize(st));   // tab is a local
+    h->hop_y = (int32_t)std::lround(p.grid_length / (p.ty_step / (double)div));
+    h->hop_z = (int32_t)std::lround(p.grid_length / (p.tz_step / (double)div));
   }
   HIP_TRY(h, hipStreamSynchronize(st));
   return ILCC_OK;
@@ -189,8 +222,28 @@ void free_slot(Slot& sl) {
   sl = Slot{};
 }
 
+// The HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share a queue
+// serialise: a fourth batch in flight only pays with >= 5 queues.  The variable is read when the runtime
+// initialises, so the library sets it (when unset) as soon as it is loaded, and says so when it finds a value that
+// is too small at the moment the fourth slot is first used.
+__attribute__((constructor)) void ilcc_default_hw_queues() { (void)setenv("GPU_MAX_HW_QUEUES", "8", /*overwrite=*/0); }
+
+void warn_hw_queues_once(int slot_index) {
+  static bool warned = false;
+  if (slot_index < 3 || warned) return;
+  const char* v = std::getenv("GPU_MAX_HW_QUEUES");
+  if (v && std::atoi(v) >= 5) return;
+  warned = true;
+  std::fprintf(stderr,
+               "libilcc_hip: GPU_MAX_HW_QUEUES=%s: with fewer than 5 hardware queues the fourth batch in flight shares a "
+               "queue with another one and serialises; keep at most 3 tickets outstanding or export GPU_MAX_HW_QUEUES=8 "
+               "before the HIP runtime starts\n",
+               v ? v : "(unset)");
+}
+
 int32_t alloc_slot(ilcc_handle* h, Slot& sl) {
   if (sl.allocated) return ILCC_OK;
+  warn_hw_queues_once((int)(&sl - h->slots));
   const uint64_t np = h->max_points;
   const uint32_t mf = h->max_frames;
   HIP_TRY(h, hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
@@ -275,6 +328,11 @@ Ctx make_ctx(ilcc_handle* h, Slot& sl, const float4* d_xyzi, const float* d_clic
   c.sth = h->d_sth;
   c.ay = h->d_ay;
   c.az = h->d_az;
+  c.th_lattice = h->d_th_lattice;
+  c.th_lat_lo = h->th_lat_lo;
+  c.th_lat_hi = h->th_lat_hi;
+  c.refine_hop_y = h->hop_y;
+  c.refine_hop_z = h->hop_z;
   c.p = h->p;
   c.c_th = near_zero_index(h->p.th_min, h->p.th_step, h->p.n_th);
   c.c_ty = near_zero_index(h->p.ty_min, h->p.ty_step, h->p.n_ty);
@@ -325,8 +383,10 @@ int32_t enqueue(ilcc_handle* h, int si, const float4* d_xyzi, const uint64_t* of
   HIP_TRY(h, hipMemcpyAsync(sl.d_off, sl.off.data(), sizeof(uint64_t) * (n_frames + 1), hipMemcpyHostToDevice, s));
   // (result records, component counters, K6 counters and near-tie counters are reset inside K1 / K2)
   Ctx c = make_ctx(h, sl, d_xyzi, d_clicks, n_frames, chunks);
-  if (no_crop)   // get_chessboard_by_point clusters the whole cloud: an unbounded box only drops non-finite points
+  if (no_crop) {   // get_chessboard_by_point clusters the whole cloud: an unbounded box only drops non-finite points
     c.p.roi_half[0] = c.p.roi_half[1] = c.p.roi_half[2] = (double)INFINITY;
+    c.p.cluster_tol = c.p.online_cluster_tol;   // setClusterTolerance(0.1), LidarCornersEst.cpp:80 (EuclideanCluster(): 0.12, :131)
+  }
 
   HIP_TRY(h, hipEventRecord(sl.ev[0], s));
   launch_roi_crop(c, s);
@@ -337,8 +397,6 @@ int32_t enqueue(ilcc_handle* h, int si, const float4* d_xyzi, const uint64_t* of
   HIP_TRY(h, hipEventRecord(sl.ev[3], s));
   launch_plane_frame_hist(c, s);
   sl.grid = !front_only && h->p.solver == ILCC_SOLVER_GRID;
-  if (sl.grid) {
-  }
   HIP_TRY(h, hipEventRecord(sl.ev[4], s));
   if (sl.grid) {
     const bool prune = h->p.grid_prune != 0;
@@ -366,10 +424,10 @@ int32_t enqueue(ilcc_handle* h, int si, const float4* d_xyzi, const uint64_t* of
       full.seed_stride_t = h->seed_stride_t;
       full.seed_stride_th = h->seed_stride_th;
       full.seed_off_th = h->seed_stride_th / 2;
-      if (h->refine_pass) {
-        // refinement pass: all candidates around the seed argmin (theta +- half a seed stride, 16 x 16 translations)
+      {
+        // refinement pass: all candidates around the seed argmin (theta +- half a seed stride, 8 x 8 translations)
         Ctx refine = full;
-        refine.refine_radius_th = h->refine_radius_env > 0 ? h->refine_radius_env : std::max(1, h->seed_stride_th / 2);
+        refine.refine_radius_th = std::max(1, h->seed_stride_th / 2);
         refine.grid_blocks = std::min((uint32_t)(2 * refine.refine_radius_th + 1), h->max_theta);
         refine.partial = sl.d_partial3;
         launch_grid_cost(refine, s, /*use_oob=*/1, nullptr, true);
@@ -379,7 +437,7 @@ int32_t enqueue(ilcc_handle* h, int si, const float4* d_xyzi, const uint64_t* of
     // durations stay clean and they do not fight for LDS); the seed and refinement passes above are small,
     // latency-bound launches and are left free to overlap with another batch's full pass, like K2/K3/K7.
     HIP_TRY(h, hipEventRecord(sl.ev[7], s));
-    if (h->chain_full_passes && h->k6_last >= 0 && h->k6_last != si && h->slots[h->k6_last].busy)
+    if (h->k6_last >= 0 && h->k6_last != si && h->slots[h->k6_last].busy)
       HIP_TRY(h, hipStreamWaitEvent(s, h->slots[h->k6_last].k6_done, 0));
     HIP_TRY(h, hipEventRecord(sl.ev[8], s));
     full.tie_count = sl.d_tie_count;
@@ -389,9 +447,13 @@ int32_t enqueue(ilcc_handle* h, int si, const float4* d_xyzi, const uint64_t* of
   }
   HIP_TRY(h, hipEventRecord(sl.ev[5], s));
   if (!front_only) {
-    Ctx c7 = c;
-    c7.tie_count = sl.grid ? sl.d_tie_count : nullptr;   // near ties of the full pass, recounted in fp64 by K7a
-    launch_refine_corners(c7, s);
+    if (sl.grid) {
+      Ctx c7 = c;
+      c7.tie_count = sl.d_tie_count;   // near ties of the full pass, re-ordered on fixed-point sums by K7r
+      launch_pattern_refine_corners(c7, s);
+    } else {
+      launch_refine_corners(c, s);
+    }
   }
   HIP_TRY(h, hipEventRecord(sl.ev[6], s));
   HIP_TRY(h, hipGetLastError());
@@ -402,9 +464,10 @@ int32_t enqueue(ilcc_handle* h, int si, const float4* d_xyzi, const uint64_t* of
 }
 
 // wait for the slot's batch, hand the records over, account the timing
-int32_t finish(ilcc_handle* h, int si, ilcc_result* out, float* d_records = nullptr, uint32_t n_corners = 0) {
+int32_t finish(ilcc_handle* h, int si, ilcc_result* out, float* d_records = nullptr, uint32_t n_corners = 0,
+               uint32_t tag_base = 0) {
   Slot& sl = h->slots[si];
-  if (d_records) launch_pack_records(sl.d_res, sl.n_frames, n_corners, d_records, sl.stream);   // same stream: after K7
+  if (d_records) launch_pack_records(sl.d_res, sl.n_frames, n_corners, tag_base, d_records, sl.stream);   // same stream: after K7
   HIP_TRY(h, hipStreamSynchronize(sl.stream));
   sl.busy = false;
   h->last_slot = si;
@@ -431,7 +494,7 @@ int32_t finish(ilcc_handle* h, int si, ilcc_result* out, float* d_records = null
   uint32_t max_lab = 0;
   uint64_t evals = 0;
   for (uint32_t f = 0; f < n_frames; ++f) {
-    if (out[f].status != ILCC_OK) continue;
+    if (out[f].status != ILCC_OK && out[f].status != ILCC_AMBIGUOUS) continue;
     const uint32_t m = (uint32_t)(out[f].n_black + out[f].n_white);
     max_lab = std::max(max_lab, m);
     evals += (uint64_t)m * (uint64_t)h->p.n_th * h->p.n_ty * h->p.n_tz;
@@ -476,6 +539,7 @@ const char* ilcc_strerror(int32_t status) {
     case ILCC_HIP_ERROR: return "HIP runtime error";
     case ILCC_IO_ERROR: return "file I/O error";
     case ILCC_BOARD_NOT_FOUND: return "no chessboard plane of sufficient size around the given point";
+    case ILCC_AMBIGUOUS: return "board position ambiguous: a basin one square away costs about the same";
     default: return "unknown status";
   }
 }
@@ -513,6 +577,11 @@ void ilcc_default_params(ilcc_params* p) {
   p->n_tz = 40;
   p->tz_step = 0.15 / 20.0;
   p->tz_min = -0.15;
+  p->refine_div = 16;
+  p->refine_max_rounds = 64;
+  p->refine_th_margin = 32;
+  p->ambiguity_eps = 0.25;
+  p->online_cluster_tol = 0.10;   // LidarCornersEst.cpp:80
 }
 
 // Minimal OpenCV-FileStorage YAML reader for the three scalar keys the path uses
@@ -588,17 +657,6 @@ ilcc_handle* ilcc_create(int32_t device, const ilcc_params* p, uint32_t max_fram
   h->max_frames = max_frames;
   h->max_points = max_total_points;
   h->max_theta = 4096;
-  if (const char* e1 = std::getenv("ILCC_SEED_STRIDE_TH")) {
-    h->seed_stride_th = std::max(1, std::atoi(e1));
-    h->seed_stride_env = true;
-  }
-  if (const char* e3 = std::getenv("ILCC_K6_REFINE")) h->refine_pass = std::atoi(e3) != 0;
-  if (const char* e4 = std::getenv("ILCC_K6_CHAIN")) h->chain_full_passes = std::atoi(e4) != 0;
-  if (const char* e6 = std::getenv("ILCC_K6_REFINE_RADIUS")) h->refine_radius_env = std::atoi(e6);
-  if (const char* e2 = std::getenv("ILCC_SEED_STRIDE_T")) {
-    h->seed_stride_t = std::max(1, std::atoi(e2));
-    h->seed_stride_t_env = true;
-  }
   h->crop_chunks_cap =
       (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, max_total_points / kCropChunk + (uint64_t)max_frames + 1);
   auto fail = [&](const std::string& what) {
@@ -613,11 +671,16 @@ ilcc_handle* ilcc_create(int32_t device, const ilcc_params* p, uint32_t max_fram
   } else {
     (void)hipGetDevice(&h->device);
   }
+  // dynamic-LDS limits are kept per (function, device): raise them for THIS device, and say so when that fails
+  if ((e = set_kernel_attributes_k2()) != hipSuccess || (e = set_kernel_attributes_k6()) != hipSuccess ||
+      (e = set_kernel_attributes_k7()) != hipSuccess)
+    return fail(std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize): ") + hipGetErrorString(e));
   float** tabs[] = {&h->d_cth, &h->d_sth, &h->d_ay, &h->d_az, &h->d_cth2, &h->d_sth2, &h->d_ay2, &h->d_az2};
   for (float** t : tabs)
     if ((e = hipMalloc((void**)t, sizeof(float) * h->max_theta)) != hipSuccess)
       return fail(std::string("hipMalloc tables: ") + hipGetErrorString(e));
-  if ((e = hipMalloc((void**)&h->d_solve, sizeof(double) * 8)) != hipSuccess)
+  if ((e = hipMalloc((void**)&h->d_solve, sizeof(double) * 8)) != hipSuccess ||
+      (e = hipMalloc((void**)&h->d_refine_io, sizeof(RefineOut))) != hipSuccess)
     return fail(std::string("hipMalloc: ") + hipGetErrorString(e));
   if (alloc_slot(h, h->slots[0]) != ILCC_OK) return fail(h->err);   // further slots on first asynchronous use
   if (upload_tables(h) != ILCC_OK) return fail(h->err);
@@ -630,7 +693,8 @@ void ilcc_destroy(ilcc_handle* h) {
     if (sl.stream) (void)hipStreamSynchronize(sl.stream);
     free_slot(sl);
   }
-  void* bufs[] = {h->d_cth, h->d_sth, h->d_ay, h->d_az, h->d_cth2, h->d_sth2, h->d_ay2, h->d_az2, h->d_solve};
+  void* bufs[] = {h->d_cth, h->d_sth, h->d_ay, h->d_az, h->d_cth2, h->d_sth2, h->d_ay2, h->d_az2, h->d_solve, h->d_refine_io,
+                  h->d_th_lattice};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   delete h;
@@ -687,13 +751,14 @@ int32_t ilcc_wait(ilcc_handle* h, int32_t ticket, ilcc_result* out) {
   return finish(h, ticket, out);
 }
 
-int32_t ilcc_wait_records_device(ilcc_handle* h, int32_t ticket, ilcc_result* out, void* d_records, uint32_t n_corners) {
+int32_t ilcc_wait_records_device(ilcc_handle* h, int32_t ticket, ilcc_result* out, void* d_records, uint32_t n_corners,
+                                 uint32_t tag_base) {
   if (!h || !out || !d_records || n_corners > ILCC_MAX_CORNERS || ticket < 0 || ticket >= kSlots || !h->slots[ticket].busy) {
     if (h) h->err = "ilcc_wait_records_device: bad argument or no batch in flight under this ticket";
     return ILCC_BAD_ARGUMENT;
   }
   HIP_TRY(h, hipSetDevice(h->device));
-  return finish(h, ticket, out, static_cast<float*>(d_records), n_corners);
+  return finish(h, ticket, out, static_cast<float*>(d_records), n_corners, tag_base);
 }
 
 int32_t ilcc_extract_batch_device(ilcc_handle* h, const float* d_xyzi, const uint64_t* offsets,
@@ -767,7 +832,7 @@ int64_t ilcc_fetch_classes(ilcc_handle* h, uint32_t frame, uint8_t* out_class, u
   Slot& sl = h->slots[h->last_slot];
   if (sl.busy || frame >= sl.n_frames) return -(int64_t)ILCC_BAD_ARGUMENT;
   const ilcc_result& r = sl.h_res[frame];
-  const int64_t n = (r.status == ILCC_OK || r.status == ILCC_BOARD_NOT_FOUND) ? r.n_plane : 0;
+  const int64_t n = (r.status == ILCC_OK || r.status == ILCC_AMBIGUOUS || r.status == ILCC_BOARD_NOT_FOUND) ? r.n_plane : 0;
   const int64_t m = std::min<int64_t>(n, (int64_t)cap_points);
   if (m > 0 && out_class &&
       hipMemcpy(out_class, sl.d_cls + sl.off[frame], (size_t)m, hipMemcpyDeviceToHost) != hipSuccess)
@@ -788,9 +853,9 @@ int64_t ilcc_fetch_cloud(ilcc_handle* h, uint32_t frame, int32_t which, float* o
     case ILCC_CLOUD_CHESSBOARD: src = sl.d_board; n = r.n_plane; break;   // also after ILCC_BOARD_NOT_FOUND
     case ILCC_CLOUD_PCA:
       src = sl.d_pca;
-      n = (r.status == ILCC_OK || r.status == ILCC_DEGENERATE_HIST || r.status == ILCC_BOARD_NOT_FOUND) ? r.n_plane : 0;
+      n = (r.status == ILCC_OK || r.status == ILCC_AMBIGUOUS || r.status == ILCC_DEGENERATE_HIST || r.status == ILCC_BOARD_NOT_FOUND) ? r.n_plane : 0;
       break;
-    case ILCC_CLOUD_OPTIM: src = sl.d_optim; n = (r.status == ILCC_OK) ? r.n_plane : 0; break;
+    case ILCC_CLOUD_OPTIM: src = sl.d_optim; n = (r.status == ILCC_OK || r.status == ILCC_AMBIGUOUS) ? r.n_plane : 0; break;
     default: return -(int64_t)ILCC_BAD_ARGUMENT;
   }
   const int64_t m = std::min<int64_t>(n, (int64_t)cap_points);
@@ -855,6 +920,10 @@ int32_t ilcc_grid_cost(ilcc_handle* h, const float* yz, const uint8_t* label, ui
   const size_t vol = (size_t)h->p.n_th * h->p.n_ty * h->p.n_tz * 2;
   float* d_vol = nullptr;
   if (cost_out) HIP_TRY(h, hipMalloc((void**)&d_vol, sizeof(float) * vol));
+  struct VolGuard {   // every exit path below frees the volume
+    float* p;
+    ~VolGuard() { if (p) (void)hipFree(p); }
+  } guard{d_vol};
   uint32_t lds = 1024;
   while (lds < m && lds < (uint32_t)kGridLdsPointsMax) lds <<= 1;
   const uint32_t saved = h->grid_lds_points;
@@ -866,10 +935,10 @@ int32_t ilcc_grid_cost(ilcc_handle* h, const float* yz, const uint8_t* label, ui
   // full evaluation when the volume is wanted, the pipeline's branch-and-bound variant otherwise
   launch_grid_cost(c, s, use_oob, d_vol, /*prune=*/d_vol == nullptr && h->p.grid_prune != 0);
   std::vector<GridPartial> part(c.grid_blocks);
-  hipError_t e = hipMemcpyAsync(part.data(), sl.d_partial, sizeof(GridPartial) * c.grid_blocks, hipMemcpyDeviceToHost, s);
+  hipError_t e = hipGetLastError();   // a launch that asked for more LDS than the device grants fails HERE, not at the copy
+  if (e == hipSuccess) e = hipMemcpyAsync(part.data(), sl.d_partial, sizeof(GridPartial) * c.grid_blocks, hipMemcpyDeviceToHost, s);
   if (e == hipSuccess && cost_out) e = hipMemcpyAsync(cost_out, d_vol, sizeof(float) * vol, hipMemcpyDeviceToHost, s);
   if (e == hipSuccess) e = hipStreamSynchronize(s);
-  if (d_vol) (void)hipFree(d_vol);
   if (e != hipSuccess) {
     h->err = std::string("ilcc_grid_cost: ") + hipGetErrorString(e);
     return ILCC_HIP_ERROR;
@@ -894,6 +963,7 @@ int32_t ilcc_get_theta_t(ilcc_handle* h, const float* yz, const uint8_t* label, 
   HIP_TRY(h, hipMemcpyAsync(h->d_solve, theta_t, sizeof(double) * 3, hipMemcpyHostToDevice, s));
   const Ctx c = make_ctx(h, sl, nullptr, nullptr, 1, 1);
   launch_local_solve(c, s, topleft_white, use_oob, h->d_solve, h->d_solve + 3);
+  HIP_TRY(h, hipGetLastError());
   double back[5];
   HIP_TRY(h, hipMemcpyAsync(back, h->d_solve, sizeof(back), hipMemcpyDeviceToHost, s));
   HIP_TRY(h, hipStreamSynchronize(s));
@@ -902,6 +972,35 @@ int32_t ilcc_get_theta_t(ilcc_handle* h, const float* yz, const uint8_t* label, 
   theta_t[2] = back[2];
   if (cost) *cost = back[3];
   if (iterations) *iterations = (int32_t)back[4];
+  return ILCC_OK;
+}
+
+int32_t ilcc_pattern_refine(ilcc_handle* h, const float* yz, const uint8_t* label, uint32_t m, int32_t lat[3],
+                            int32_t* phase, int64_t* cost_q, int64_t* alt_cost_q, int32_t* rounds, int32_t* hops) {
+  if (!lat || !phase) return ILCC_BAD_ARGUMENT;
+  int32_t st = stage_labelled(h, yz, label, m);
+  if (st != ILCC_OK) return st;
+  Slot& sl = h->slots[0];
+  hipStream_t s = sl.stream;
+  RefineOut io{};
+  io.lat[0] = lat[0];
+  io.lat[1] = lat[1];
+  io.lat[2] = lat[2];
+  io.phase = *phase;
+  HIP_TRY(h, hipMemcpyAsync(h->d_refine_io, &io, sizeof(io), hipMemcpyHostToDevice, s));
+  const Ctx c = make_ctx(h, sl, nullptr, nullptr, 1, 1);
+  launch_pattern_refine_test(c, s, h->d_refine_io);
+  HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipMemcpyAsync(&io, h->d_refine_io, sizeof(io), hipMemcpyDeviceToHost, s));
+  HIP_TRY(h, hipStreamSynchronize(s));
+  lat[0] = io.lat[0];
+  lat[1] = io.lat[1];
+  lat[2] = io.lat[2];
+  *phase = io.phase;
+  if (cost_q) *cost_q = io.cost_q;
+  if (alt_cost_q) *alt_cost_q = io.alt_q;
+  if (rounds) *rounds = io.rounds;
+  if (hops) *hops = io.hops;
   return ILCC_OK;
 }
 

@@ -25,10 +25,16 @@ constexpr int kTileA = 4;              // K6 candidate tile: ty values per wavef
 #endif
 constexpr int kTileB = ILCC_TILE_B;    // K6 candidate tile: tz values per wavefront pass (4 or 8)
 constexpr int kGridLdsPointsMax = 8192;   // K6 LDS staging upper bound (12 B per point -> 96 KiB)
+constexpr int kGridTableMax = 8192;       // K6: n_ty + n_tz bound (their tables sit in LDS behind the points: 32 KiB)
 #ifndef ILCC_K7_THREADS
 #define ILCC_K7_THREADS 256
 #endif
 constexpr int kSolveThreads = ILCC_K7_THREADS;     // K7: wavefronts x 64 per (frame, phase)
+#ifndef ILCC_K7R_THREADS
+#define ILCC_K7R_THREADS 1024
+#endif
+constexpr int kRefineThreads = ILCC_K7R_THREADS;   // K7r: one workgroup per frame
+constexpr int kRefineList = 32;        // K7r: candidates evaluated per sweep over the points
 constexpr int kTieCap = 256;           // K6 -> K7a: near-tie candidates kept per frame for the fp64 recount
 constexpr float kTieEps = 2e-5f;       // relative cost window of a near-tie (fp32 sums of ~1e3 terms agree to ~1e-6)
 constexpr int kIterSlots = 64;         // K6 executed-iteration counters (spread to avoid one hot atomic)
@@ -46,10 +52,18 @@ struct GridPartial {   // per K6 workgroup best candidate
   uint32_t pad;
 };
 
-struct SolveRec {      // K7a result for one (frame, phase slot)
+struct SolveRec {      // K7a / K7r result for one (frame, phase slot)
   double x[3];
   double cost_a, cost_b, sel;
+  double margin;       // K7r: (cheapest neighbouring basin - cost) / cost
   int32_t iters_a, iters_b, phase, valid;
+  int32_t flags, ties;
+};
+
+struct RefineOut {     // K7r diagnostic entry (ilcc_pattern_refine)
+  long long cost_q, alt_q;
+  int32_t lat[3];
+  int32_t phase, rounds, hops;
 };
 
 // everything a kernel needs, passed by value
@@ -102,6 +116,10 @@ struct Ctx {
   const float* sth;          // sin(theta_k)/g
   const float* ay;           // (ty_a + W g/2)/g
   const float* az;           // (tz_b + H g/2)/g
+  // K7r: cos/sin of every theta lattice point, index (lattice theta) - th_lat_lo
+  const double2* th_lattice;
+  int32_t th_lat_lo, th_lat_hi;
+  int32_t refine_hop_y, refine_hop_z;   // one board square along y / z in lattice units
   // parameters
   ilcc_params p;
   int32_t c_th, c_ty, c_tz;  // index of the candidate nearest zero on each axis
@@ -186,7 +204,16 @@ void launch_grid_cost(const Ctx& c, hipStream_t s, int32_t use_oob, float* cost_
                       bool prune);
 uint32_t grid_cost_evals_per_count();   // (point, candidate) evaluations behind one count of Ctx::grid_iters
 void launch_refine_corners(const Ctx& c, hipStream_t s);
-void launch_pack_records(const ilcc_result* d_res, uint32_t n_frames, uint32_t n_corners, float* d_out, hipStream_t s);
+void launch_pack_records(const ilcc_result* d_res, uint32_t n_frames, uint32_t n_corners, uint32_t tag_base, float* d_out,
+                         hipStream_t s);
+// K7r on every frame of the batch (GRID mode), then K7b
+void launch_pattern_refine_corners(const Ctx& c, hipStream_t s);
+// stand-alone K7r on the labelled points of frame 0 (test entry)
+void launch_pattern_refine_test(const Ctx& c, hipStream_t s, RefineOut* d_io);
+// once per (process, device): raise the dynamic-LDS limits of the kernels that need more than 64 KiB
+hipError_t set_kernel_attributes_k2();
+hipError_t set_kernel_attributes_k6();
+hipError_t set_kernel_attributes_k7();
 // stand-alone local solve on the labelled points of frame 0 (test entry)
 void launch_local_solve(const Ctx& c, hipStream_t s, int32_t tlw, int32_t use_oob, double* theta_t,
                         double* cost_iters /*[2]: cost, iterations*/);

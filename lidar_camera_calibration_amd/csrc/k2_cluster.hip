@@ -749,14 +749,18 @@ __global__ __launch_bounds__(kFrameThreads) void k2_seeded_cluster(Ctx c) {
     cluster_frame<false>(c, f, lds_parent, tile, sc, s_pts);
 }
 
+static constexpr size_t kClusterLdsBytes = sizeof(float4) * kFrameThreads + 128 * sizeof(uint32_t) +
+                                           sizeof(uint32_t) * kClusterLdsParents + sizeof(float4) * kClusterGridMax +
+                                           sizeof(uint16_t) * kClusterGridMax;
+
+// 152 KiB of dynamic LDS (> the 64 KiB default cap; one 1024-thread workgroup per CU either way).  Called by
+// ilcc_create for the handle's device: the attribute is kept per (function, device).
+hipError_t set_kernel_attributes_k2() {
+  return hipFuncSetAttribute((const void*)k2_seeded_cluster, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kClusterLdsBytes);
+}
+
 void launch_cluster(const Ctx& c, hipStream_t s) {
-  const size_t lds = sizeof(float4) * kFrameThreads + 128 * sizeof(uint32_t) +
-                     sizeof(uint32_t) * kClusterLdsParents + sizeof(float4) * kClusterGridMax + sizeof(uint16_t) * kClusterGridMax;
-  static bool attr_done = false;
-  if (!attr_done) {   // 152 KiB of dynamic LDS (> the 64 KiB default cap; one 1024-thread workgroup per CU either way)
-    (void)hipFuncSetAttribute((const void*)k2_seeded_cluster, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_done = true;
-  }
+  const size_t lds = kClusterLdsBytes;
   hipLaunchKernelGGL(k2_seeded_cluster, dim3(c.n_frames), dim3(kFrameThreads), lds, s, c);
 }
 

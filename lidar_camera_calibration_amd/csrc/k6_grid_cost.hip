@@ -240,8 +240,9 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
     float lim2 = 2.f * (1.f + kTieEps) * fminf(__uint_as_float(gb_bits), best.cost);
     if (PRUNE) gb_bits = __hip_atomic_load(bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // lane's points: walk positions my_s, my_s + 4, ...  (LDS_POINTS = false: point index (pos * S) mod M)
-    uint32_t idx = (uint32_t)(((uint64_t)my_s * S) % M);
-    const uint32_t idx_step = (uint32_t)(((uint64_t)kSlices * S) % M);
+    // (M == 0: no point is ever fetched, every candidate costs 0; keep the modulo defined)
+    uint32_t idx = M ? (uint32_t)(((uint64_t)my_s * S) % M) : 0u;
+    const uint32_t idx_step = M ? (uint32_t)(((uint64_t)kSlices * S) % M) : 0u;
     uint32_t pos = 0;
     auto fetch = [&](uint32_t at) -> PointTerms {   // at = walk position of THIS lane's point
       if (LDS_POINTS) {
@@ -284,7 +285,7 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
       }
     }
     if (!(PRUNE && pruned)) {
-      if (!LDS_POINTS) idx = (uint32_t)(((uint64_t)(pos + my_s) * S) % M);
+      if (!LDS_POINTS && M) idx = (uint32_t)(((uint64_t)(pos + my_s) * S) % M);
       for (; pos < M; pos += kSlices) {   // tail (< 12 points): one point per lane and trip, lanes past the end idle
         const uint32_t at = pos + my_s;
         if (at < M) {
@@ -306,13 +307,15 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
         // completions are rare: afford a fresh look at the frame's bound so that little junk is listed while it is loose
         const float fresh = __uint_as_float(__hip_atomic_load(bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         const float thr = (1.f + kTieEps) * fminf(fresh, fminf(best.cost, fminf(c0, c1)));
+        // more than kTieCap entries: the count keeps growing, the consumer sees the overflow and falls back to the
+        // (deterministic) fp32 argmin with ILCC_FLAG_TIE_OVERFLOW set -- which entries made it into the list never matters
         if (c0 <= thr) {
           const uint32_t at = atomicAdd(c.tie_count + f, 1u);
-          c.tie_list[(uint64_t)f * kTieCap + (at % (uint32_t)kTieCap)] = GridPartial{c0, d2, 2u * cell, 0u};   // ring: the newest (lowest) survive
+          if (at < (uint32_t)kTieCap) c.tie_list[(uint64_t)f * kTieCap + at] = GridPartial{c0, d2, 2u * cell, 0u};
         }
         if (c1 <= thr) {
           const uint32_t at = atomicAdd(c.tie_count + f, 1u);
-          c.tie_list[(uint64_t)f * kTieCap + (at % (uint32_t)kTieCap)] = GridPartial{c1, d2, 2u * cell + 1u, 0u};
+          if (at < (uint32_t)kTieCap) c.tie_list[(uint64_t)f * kTieCap + at] = GridPartial{c1, d2, 2u * cell + 1u, 0u};
         }
       }
       if (better(c0, d2, 2u * cell, best)) best = Best{c0, d2, 2u * cell};
@@ -384,18 +387,23 @@ __global__ __launch_bounds__(kGridThreads) void k6_grid_cost(Ctx c, float* volum
 // executed-work unit of Ctx::grid_iters: one count = one point x one 16-candidate tile
 uint32_t grid_cost_evals_per_count() { return kTile * kTile; }
 
-void launch_grid_cost(const Ctx& c, hipStream_t s, int32_t use_oob, float* cost_volume, bool prune) {
-  const dim3 grid(c.grid_blocks, c.n_frames), block(kGridThreads);
-  const size_t lds = (sizeof(float2) + sizeof(float)) * (size_t)c.grid_lds_points + sizeof(float) * (size_t)(c.p.n_ty + c.p.n_tz);
-  static bool attr_done = false;
+// allow > 64 KiB of dynamic LDS (gfx950 has 160 KiB per CU): the staged points plus the (ty, tz) tables, whose
+// combined length params_ok bounds by kGridTableMax.  Called by ilcc_create for the handle's device.
+hipError_t set_kernel_attributes_k6() {
   const void* fns[] = {(const void*)k6_grid_cost<true, true, false>,  (const void*)k6_grid_cost<true, false, false>,
                        (const void*)k6_grid_cost<false, true, false>, (const void*)k6_grid_cost<false, false, false>,
                        (const void*)k6_grid_cost<true, false, true>,  (const void*)k6_grid_cost<false, false, true>};
-  if (!attr_done) {   // allow > 64 KiB of dynamic LDS (gfx950 has 160 KiB per CU)
-    const int cap = (int)((sizeof(float2) + sizeof(float)) * (size_t)kGridLdsPointsMax + sizeof(float) * 2 * 1024);
-    for (const void* fn : fns) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-    attr_done = true;
+  const int cap = (int)((sizeof(float2) + sizeof(float)) * (size_t)kGridLdsPointsMax + sizeof(float) * (size_t)kGridTableMax);
+  for (const void* fn : fns) {
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    if (e != hipSuccess) return e;
   }
+  return hipSuccess;
+}
+
+void launch_grid_cost(const Ctx& c, hipStream_t s, int32_t use_oob, float* cost_volume, bool prune) {
+  const dim3 grid(c.grid_blocks, c.n_frames), block(kGridThreads);
+  const size_t lds = (sizeof(float2) + sizeof(float)) * (size_t)c.grid_lds_points + sizeof(float) * (size_t)(c.p.n_ty + c.p.n_tz);
   // the diagnostic volume is always a complete evaluation (no pruning)
   if (cost_volume) {
     if (use_oob)

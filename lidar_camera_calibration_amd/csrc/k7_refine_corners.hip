@@ -15,6 +15,12 @@
 //      threads: no thread-0 section, no divergence.  A solve is a chain of ~100 dependent
 //      evaluations, so latency -- not throughput -- is what this layout minimises; frames and
 //      phases run concurrently on different CUs.
+// K7r pattern_refine (ILCC_SOLVER_GRID): one 1024-thread workgroup per frame.  Starts at the K6 grid argmin
+//      (near ties of the fp32 grid pass are first re-ordered on exact fixed-point costs), then a monotone
+//      pattern search on the pass-A cost and a check of the eight neighbouring basins -- the same
+//      specification as the oracle's orc_pattern_refine, bit for bit: every point's term is computed in
+//      fp64 exactly like the oracle's, rounded to a multiple of 2^-40 and summed as an INTEGER, so the
+//      parallel reduction cannot change a single decision.
 // K7b corners: picks the phase with the lower with-OOB cost, then builds the corner lattice:
 //      LidarCornersEst::getPCDcorners (:501-556) with
 //      transf = pcl::getTransformation(0, ty, tz, theta, 0, 0) (:412), and the display cloud
@@ -552,9 +558,7 @@ __device__ __forceinline__ bool partial_less(const GridPartial& a, const GridPar
 template <bool LDS_POINTS>
 __device__ void solve_body(const Ctx& c, SolveRec* rec, float2* s_yz, uint8_t* s_lab, double* s_red) {
   const uint32_t f = blockIdx.x, slot = blockIdx.y;
-  ilcc_result* r = &c.res[f];
   SolveRec* out = &rec[2 * f + slot];
-  const int lane = lane_id();
   const uint64_t beg = c.off[f];
   const uint32_t n = c.n_lab[f];
 
@@ -579,78 +583,7 @@ __device__ void solve_body(const Ctx& c, SolveRec* rec, float2* s_yz, uint8_t* s
 
   double x[3] = {0.0, 0.0, 0.0};
   int phase = (int)slot;
-  if (c.p.solver == ILCC_SOLVER_GRID) {
-    // argmin over this frame's K6 partials: cost, then index distance to zero, then flat index
-    const GridPartial* gp = c.partial + (uint64_t)f * c.grid_blocks;
-    GridPartial b{__builtin_inff(), 0xFFFFFFFFu, 0xFFFFFFFFu, 0u};
-    for (uint32_t k = lane; k < c.grid_blocks; k += ILCC_WAVE) {
-      const GridPartial t = gp[k];
-      if (partial_less(t, b)) b = t;
-    }
-#pragma unroll
-    for (int o = ILCC_WAVE / 2; o > 0; o >>= 1) {
-      GridPartial t;
-      t.cost = __shfl_xor(b.cost, o, ILCC_WAVE);
-      t.d2 = __shfl_xor(b.d2, o, ILCC_WAVE);
-      t.flat = __shfl_xor(b.flat, o, ILCC_WAVE);
-      if (partial_less(t, b)) b = t;
-    }
-    if (threadIdx.x == 0) {
-      r->grid_index = (int32_t)b.flat;
-      r->grid_cost = b.cost;
-    }
-    if (b.flat == 0xFFFFFFFFu) {
-      if (threadIdx.x == 0) out->valid = 0;
-      return;
-    }
-    // Near ties: fp32 sums of ~1e3 terms cannot order candidates whose costs agree to ~1e-6; the fp64 oracle
-    // can.  K6's full pass listed every candidate within kTieEps of the bound; recount the ones within kTieEps
-    // of the fp32 minimum in fp64 (the solver's own cost evaluation) and apply the tie-break on those values.
-    if (c.tie_count != nullptr) {
-      const uint32_t nt = min(c.tie_count[f], (uint32_t)kTieCap);
-      const GridPartial* tl = c.tie_list + (uint64_t)f * kTieCap;
-      const float window = b.cost * (1.f + kTieEps);
-      uint32_t close = 0;
-      for (uint32_t e = 0; e < nt; ++e) close += (tl[e].cost <= window && tl[e].flat != b.flat) ? 1u : 0u;
-      if (close > 0) {   // uniform across the workgroup
-        double best64 = 0.0;
-        GridPartial pick = b;
-        bool have = false;
-        for (uint32_t e = 0; e <= nt; ++e) {   // e == nt: the fp32 argmin itself (it may have been dropped by the cap)
-          const GridPartial t = (e < nt) ? tl[e] : b;
-          if (!(t.cost <= window)) continue;
-          if (e < nt && t.flat == b.flat) continue;
-          const uint32_t cl = t.flat >> 1;
-          const uint32_t tz = cl % (uint32_t)c.p.n_tz, ty = (cl / (uint32_t)c.p.n_tz) % (uint32_t)c.p.n_ty,
-                         tk = cl / ((uint32_t)c.p.n_tz * (uint32_t)c.p.n_ty);
-          const double xe[3] = {c.p.th_min + tk * c.p.th_step, c.p.ty_min + ty * c.p.ty_step, c.p.tz_min + tz * c.p.tz_step};
-          q.tlw = (t.flat & 1u) != 0;
-          q.oob = true;
-          double cs64[10];
-          evaluate<false>(q, xe, cs64);
-          const bool take = !have || cs64[0] < best64 ||
-                            (cs64[0] == best64 && (t.d2 < pick.d2 || (t.d2 == pick.d2 && t.flat < pick.flat)));
-          if (take) {
-            have = true;
-            best64 = cs64[0];
-            pick = t;
-          }
-        }
-        b = pick;
-        if (threadIdx.x == 0) {
-          r->grid_index = (int32_t)b.flat;
-          r->grid_cost = b.cost;
-        }
-      }
-    }
-    const uint32_t cell = b.flat >> 1;
-    const uint32_t bz = cell % (uint32_t)c.p.n_tz, ay = (cell / (uint32_t)c.p.n_tz) % (uint32_t)c.p.n_ty,
-                   k = cell / ((uint32_t)c.p.n_tz * (uint32_t)c.p.n_ty);
-    x[0] = c.p.th_min + k * c.p.th_step;
-    x[1] = c.p.ty_min + ay * c.p.ty_step;
-    x[2] = c.p.tz_min + bz * c.p.tz_step;
-    phase = (int)(b.flat & 1u);
-  } else if (c.p.phase_mode != 2) {
+  if (c.p.phase_mode != 2) {
     phase = (c.p.phase_mode == 1) ? 1 : 0;
   }
 
@@ -680,6 +613,9 @@ __device__ void solve_body(const Ctx& c, SolveRec* rec, float2* s_yz, uint8_t* s
     out->iters_b = ib;
     out->phase = phase;
     out->valid = 1;
+    out->margin = 0.0;
+    out->flags = 0;
+    out->ties = 0;
   }
 }
 
@@ -697,6 +633,298 @@ __global__ __launch_bounds__(kSolveThreads) void k7a_local_solve(Ctx c, SolveRec
     solve_body<true>(c, rec, s_yz, s_lab, s_red);
   else
     solve_body<false>(c, rec, s_yz, s_lab, s_red);
+}
+
+// ------------------------------------------------------------------ K7r pattern refine (ILCC_SOLVER_GRID)
+constexpr double kCostQOne = 1099511627776.0;   // 2^40: quantum of the fixed-point cost (oracle: ORC_COST_Q_ONE)
+constexpr int kRefineWaves = kRefineThreads / ILCC_WAVE;
+constexpr int32_t kNoTheta = INT32_MIN;         // candidate whose theta lies outside the lattice table: never evaluated
+
+struct RCand {
+  int32_t q0, q1, q2, phase;   // lattice coordinates (theta, ty, tz), topleftWhite
+};
+struct RefineShared {
+  RCand cand[kRefineList];
+  GridPartial meta[kRefineList];                 // near-tie recount: fp32 cost, d2, flat of the listed candidates
+  unsigned long long acc[3][kRefineList];        // fixed-point sums, three rotating sets (one barrier pair per sweep)
+};
+
+struct RefineState {
+  int32_t lat[3];
+  int32_t phase, rounds, hops;
+  long long cost, alt;
+};
+
+// One sweep over the frame's labelled points for the n_cand (<= 32) candidates in sh.cand.  lane -> (candidate,
+// slice): every lane walks its slice of the points for ONE candidate and adds its integer partial sum to the
+// candidate's LDS word -- no cross-lane reduction, and the result cannot depend on who adds first.
+// Returns the index of the acc set that holds the totals.  `sweep` counts the sweeps of this workgroup.
+__device__ __forceinline__ int refine_sweep(const Ctx& c, const Board& bd, const float2* yz, const uint8_t* lab, uint32_t n,
+                                            RefineShared& sh, int n_cand, int& sweep) {
+  const int buf = sweep % 3;
+  if (threadIdx.x < kRefineList) sh.acc[(sweep + 1) % 3][threadIdx.x] = 0ull;   // last read two sweeps ago
+  __syncthreads();   // candidates (written by the caller) and this sweep's zeroed set are visible
+  const int lane = lane_id();
+  const int slices = ILCC_WAVE / n_cand;
+  const int cand = lane % n_cand, slice = lane / n_cand;
+  if (slice < slices) {
+    const RCand cd = sh.cand[cand];
+    if (cd.q0 != kNoTheta) {
+      const double div = (double)(c.p.refine_div > 0 ? c.p.refine_div : 1);
+      const double2 cs = c.th_lattice[cd.q0 - c.th_lat_lo];
+      const double x[3] = {0.0, c.p.ty_min + (double)cd.q1 * (c.p.ty_step / div), c.p.tz_min + (double)cd.q2 * (c.p.tz_step / div)};
+      const bool tlw = cd.phase != 0;
+      long long sum = 0;
+      for (uint32_t p = (uint32_t)(wave_id() * slices + slice); p < n; p += (uint32_t)(kRefineWaves * slices)) {
+        const float2 v = yz[p];
+        const double res = residual<false>(x, cs.x, cs.y, (double)v.x, (double)v.y, bd, tlw, lab[p] != 0, true, nullptr);
+        double r0, r1;
+        huber(bd.delta, res * res, r0, r1);
+        sum += __double2ll_rn(0.5 * r0 * kCostQOne);
+      }
+      atomicAdd(&sh.acc[buf][cand], (unsigned long long)sum);
+    }
+  }
+  __syncthreads();
+  ++sweep;
+  return buf;
+}
+
+// orc_pattern_refine, executed redundantly (and identically) by every thread of the workgroup
+__device__ void pattern_refine(const Ctx& c, const Board& bd, const float2* yz, const uint8_t* lab, uint32_t n,
+                               RefineShared& sh, int& sweep, RefineState& st) {
+  const int tid = (int)threadIdx.x;
+  const bool refine = c.p.refine_div > 0;
+  const int div = refine ? c.p.refine_div : 1;
+  st.rounds = 0;
+  st.hops = 0;
+  st.cost = 0;
+  st.alt = 0;
+  for (;;) {
+    int stride = div, r = 0;
+    while (refine && stride >= 1 && r < c.p.refine_max_rounds) {
+      if (tid < 27) {
+        const int dk = tid / 9 - 1, da = (tid / 3) % 3 - 1, db = tid % 3 - 1;
+        const int q0 = st.lat[0] + dk * stride;
+        sh.cand[tid] = RCand{(q0 < c.th_lat_lo || q0 > c.th_lat_hi) ? kNoTheta : q0, st.lat[1] + da * stride, st.lat[2] + db * stride, st.phase};
+      }
+      const int b = refine_sweep(c, bd, yz, lab, n, sh, 27, sweep);
+      long long bc = LLONG_MAX;
+      int bd2 = 0, be = -1;
+      for (int e = 0; e < 27; ++e) {   // (dk, da, db) order; ties: nearer, then first
+        if (e == 13) continue;
+        const int dk = e / 9 - 1, da = (e / 3) % 3 - 1, db = e % 3 - 1;
+        const int q0 = st.lat[0] + dk * stride;
+        if (q0 < c.th_lat_lo || q0 > c.th_lat_hi) continue;
+        const long long cc = (long long)sh.acc[b][e];
+        const int d2 = dk * dk + da * da + db * db;
+        if (cc < bc || (cc == bc && d2 < bd2)) {
+          bc = cc;
+          bd2 = d2;
+          be = e;
+        }
+      }
+      const long long centre = (long long)sh.acc[b][13];
+      ++r;
+      if (be >= 0 && bc < centre) {
+        st.lat[0] += (be / 9 - 1) * stride;
+        st.lat[1] += ((be / 3) % 3 - 1) * stride;
+        st.lat[2] += (be % 3 - 1) * stride;
+      } else {
+        stride >>= 1;
+      }
+    }
+    st.rounds += r;
+    // the eight neighbouring basins (one square along y and/or z; an odd shift swaps the colours) + the centre
+    if (tid < 9) {
+      const int da = tid / 3 - 1, db = tid % 3 - 1;
+      sh.cand[tid] = RCand{st.lat[0], st.lat[1] + da * c.refine_hop_y, st.lat[2] + db * c.refine_hop_z, st.phase ^ ((da + db) & 1)};
+    }
+    const int b = refine_sweep(c, bd, yz, lab, n, sh, 9, sweep);
+    st.cost = (long long)sh.acc[b][4];
+    long long alt = LLONG_MAX;
+    int ae = -1;
+    for (int e = 0; e < 9; ++e) {
+      if (e == 4) continue;
+      const long long cc = (long long)sh.acc[b][e];
+      if (cc < alt) {
+        alt = cc;
+        ae = e;
+      }
+    }
+    st.alt = alt;
+    if (alt < st.cost && st.hops < 2 && refine) {
+      const int da = ae / 3 - 1, db = ae % 3 - 1;
+      ++st.hops;
+      st.lat[1] += da * c.refine_hop_y;
+      st.lat[2] += db * c.refine_hop_z;
+      st.phase ^= (da + db) & 1;
+      continue;
+    }
+    break;
+  }
+}
+
+template <bool LDS_POINTS>
+__device__ void refine_frame(const Ctx& c, SolveRec* rec, float2* s_yz, uint8_t* s_lab, RefineShared& sh) {
+  const uint32_t f = blockIdx.x;
+  ilcc_result* r = &c.res[f];
+  SolveRec* out = &rec[2 * f];
+  const int lane = lane_id(), tid = (int)threadIdx.x;
+  const uint64_t beg = c.off[f];
+  const uint32_t n = c.n_lab[f];
+  const Board bd{(double)c.p.board_w, (double)c.p.board_h, c.p.grid_length, c.p.huber_delta};
+  const float2* yz = c.yz + beg;
+  const uint8_t* lab = c.lab + beg;
+  if (tid < kRefineList) sh.acc[0][tid] = 0ull;
+  if (LDS_POINTS) {
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+      s_yz[i] = yz[i];
+      s_lab[i] = lab[i];
+    }
+    yz = s_yz;
+    lab = s_lab;
+  }
+  __syncthreads();
+
+  // argmin over this frame's K6 partials: cost, then index distance to zero, then flat index (every wavefront
+  // repeats the same reduction: no broadcast needed)
+  const GridPartial* gp = c.partial + (uint64_t)f * c.grid_blocks;
+  GridPartial b{__builtin_inff(), 0xFFFFFFFFu, 0xFFFFFFFFu, 0u};
+  for (uint32_t k = lane; k < c.grid_blocks; k += ILCC_WAVE) {
+    const GridPartial t = gp[k];
+    if (partial_less(t, b)) b = t;
+  }
+#pragma unroll
+  for (int o = ILCC_WAVE / 2; o > 0; o >>= 1) {
+    GridPartial t;
+    t.cost = __shfl_xor(b.cost, o, ILCC_WAVE);
+    t.d2 = __shfl_xor(b.d2, o, ILCC_WAVE);
+    t.flat = __shfl_xor(b.flat, o, ILCC_WAVE);
+    if (partial_less(t, b)) b = t;
+  }
+  if (b.flat == 0xFFFFFFFFu) {
+    if (tid == 0) out->valid = 0;
+    return;
+  }
+  int sweep = 0;
+  int flags = 0;
+  uint32_t n_ties = 0;
+  const int div = c.p.refine_div > 0 ? c.p.refine_div : 1;
+  const uint32_t n_ty = (uint32_t)c.p.n_ty, n_tz = (uint32_t)c.p.n_tz;
+  // Near ties: fp32 sums of ~1e3 terms cannot order candidates whose costs agree to ~1e-6; the oracle orders them
+  // on exact fixed-point sums.  K6's full pass listed every candidate within kTieEps of the bound; recount the
+  // ones within kTieEps of the fp32 minimum with the oracle's arithmetic and apply its tie-break to those values.
+  if (c.tie_count != nullptr) {
+    n_ties = c.tie_count[f];
+    if (n_ties > (uint32_t)kTieCap) {
+      flags |= ILCC_FLAG_TIE_OVERFLOW;   // the list is incomplete: keep the (deterministic) fp32 argmin
+    } else {
+      const GridPartial* tl = c.tie_list + (uint64_t)f * kTieCap;
+      const float window = b.cost * (1.f + kTieEps);
+      uint32_t close = 0;
+      for (uint32_t e = 0; e < n_ties; ++e) close += (tl[e].cost <= window && tl[e].flat != b.flat) ? 1u : 0u;
+      if (close > 0) {   // uniform across the workgroup
+        long long best_q = LLONG_MAX;
+        GridPartial pick = b;
+        int k = 0;
+        for (uint32_t e = 0; e <= n_ties; ++e) {   // e == n_ties: the fp32 argmin itself
+          const GridPartial t = (e < n_ties) ? tl[e] : b;
+          const bool take = (t.cost <= window) && !(e < n_ties && t.flat == b.flat);
+          if (take) {
+            if (tid == 0) {
+              const uint32_t cl = t.flat >> 1;
+              sh.cand[k] = RCand{(int32_t)(cl / (n_tz * n_ty)) * div, (int32_t)((cl / n_tz) % n_ty) * div, (int32_t)(cl % n_tz) * div, (int32_t)(t.flat & 1u)};
+              sh.meta[k] = t;
+            }
+            ++k;
+          }
+          if (k == kRefineList || (e == n_ties && k > 0)) {
+            const int bf = refine_sweep(c, bd, yz, lab, n, sh, k, sweep);
+            for (int j = 0; j < k; ++j) {
+              const long long cq = (long long)sh.acc[bf][j];
+              const GridPartial m = sh.meta[j];
+              if (cq < best_q || (cq == best_q && (m.d2 < pick.d2 || (m.d2 == pick.d2 && m.flat < pick.flat)))) {
+                best_q = cq;
+                pick = m;
+              }
+            }
+            k = 0;
+            __syncthreads();   // every thread has read meta / cand before thread 0 refills them
+          }
+        }
+        b = pick;
+      }
+    }
+  }
+  if (tid == 0) {
+    r->grid_index = (int32_t)b.flat;
+    r->grid_cost = b.cost;
+  }
+  const uint32_t cell = b.flat >> 1;
+  RefineState st;
+  st.lat[0] = (int32_t)(cell / (n_tz * n_ty)) * div;
+  st.lat[1] = (int32_t)((cell / n_tz) % n_ty) * div;
+  st.lat[2] = (int32_t)(cell % n_tz) * div;
+  st.phase = (int)(b.flat & 1u);
+  pattern_refine(c, bd, yz, lab, n, sh, sweep, st);
+  if (tid == 0) {
+    const double dv = (double)div;
+    out->x[0] = c.p.th_min + (double)st.lat[0] * (c.p.th_step / dv);
+    out->x[1] = c.p.ty_min + (double)st.lat[1] * (c.p.ty_step / dv);
+    out->x[2] = c.p.tz_min + (double)st.lat[2] * (c.p.tz_step / dv);
+    out->cost_a = out->sel = (double)st.cost / kCostQOne;
+    out->cost_b = (double)st.alt / kCostQOne;
+    out->margin = ((double)st.alt - (double)st.cost) / (double)(st.cost > 0 ? st.cost : 1);
+    out->iters_a = st.rounds;
+    out->iters_b = st.hops;
+    out->phase = st.phase;
+    out->valid = 1;
+    out->flags = flags;
+    out->ties = (int32_t)n_ties;
+  }
+}
+
+__global__ __launch_bounds__(kRefineThreads) void k7r_pattern_refine(Ctx c, SolveRec* rec) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  __shared__ RefineShared sh;
+  const uint32_t f = blockIdx.x;
+  if (c.res[f].status != ILCC_OK) {
+    if (threadIdx.x == 0) rec[2 * f].valid = 0;
+    return;
+  }
+  float2* s_yz = reinterpret_cast<float2*>(smem);
+  uint8_t* s_lab = smem + sizeof(float2) * (size_t)c.grid_lds_points;
+  if (c.n_lab[f] <= c.grid_lds_points)
+    refine_frame<true>(c, rec, s_yz, s_lab, sh);
+  else
+    refine_frame<false>(c, rec, s_yz, s_lab, sh);
+}
+
+// test entry: the refinement alone on frame 0's labelled points (global memory), start given by the caller
+__global__ __launch_bounds__(kRefineThreads) void k7r_pattern_refine_test(Ctx c, RefineOut* io) {
+  __shared__ RefineShared sh;
+  if (threadIdx.x < kRefineList) sh.acc[0][threadIdx.x] = 0ull;
+  __syncthreads();
+  const Board bd{(double)c.p.board_w, (double)c.p.board_h, c.p.grid_length, c.p.huber_delta};
+  RefineState st;
+  st.lat[0] = io->lat[0];
+  st.lat[1] = io->lat[1];
+  st.lat[2] = io->lat[2];
+  st.phase = io->phase;
+  int sweep = 0;
+  __syncthreads();
+  pattern_refine(c, bd, c.yz, c.lab, c.n_lab[0], sh, sweep, st);
+  if (threadIdx.x == 0) {
+    io->lat[0] = st.lat[0];
+    io->lat[1] = st.lat[1];
+    io->lat[2] = st.lat[2];
+    io->phase = st.phase;
+    io->rounds = st.rounds;
+    io->hops = st.hops;
+    io->cost_q = st.cost;
+    io->alt_q = st.alt;
+  }
 }
 
 // ------------------------------------------------------------------ K7b corners (getPCDcorners)
@@ -739,6 +967,9 @@ __global__ __launch_bounds__(kSolveThreads) void k7b_corners(Ctx c, const SolveR
     r->phase = best.phase;
     r->iters_a = best.iters_a;
     r->iters_b = best.iters_b;
+    r->basin_margin = best.margin;
+    r->flags = best.flags;
+    r->grid_ties = best.ties;
     const float roll = (float)best.x[0];
     const float E = cosf(roll), F = sinf(roll);
     const float T[16] = {1, 0, 0, 0, 0, E, -F, (float)best.x[1], 0, F, E, (float)best.x[2], 0, 0, 0, 1};
@@ -780,6 +1011,10 @@ __global__ __launch_bounds__(kSolveThreads) void k7b_corners(Ctx c, const SolveR
     }
     O[i] = make_float4(o[0], o[1], o[2], v.w);
   }
+  // GRID mode: a neighbouring basin that costs (almost) the same -> the caller is told (corners stay in the record).
+  // Written last: every thread above read r->status == ILCC_OK before this store can land (barrier)
+  __syncthreads();
+  if (tid == 0 && c.p.solver == ILCC_SOLVER_GRID && c.p.ambiguity_eps > 0.0 && best.margin < c.p.ambiguity_eps) r->status = ILCC_AMBIGUOUS;
 }
 
 // test entry: one solve on frame 0's labelled points (global memory)
@@ -808,15 +1043,26 @@ __global__ __launch_bounds__(kSolveThreads) void k7_local_solve_test(Ctx c, int 
   }
 }
 
+hipError_t set_kernel_attributes_k7() {
+  const int cap = (int)((sizeof(float2) + 1) * (size_t)kGridLdsPointsMax);
+  hipError_t e = hipFuncSetAttribute((const void*)k7a_local_solve, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k7r_pattern_refine, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+  return e;
+}
+
+void launch_pattern_refine_corners(const Ctx& c, hipStream_t s) {
+  const size_t lds = (sizeof(float2) + 1) * (size_t)c.grid_lds_points;
+  hipLaunchKernelGGL(k7r_pattern_refine, dim3(c.n_frames), dim3(kRefineThreads), lds, s, c, c.solve_rec);
+  hipLaunchKernelGGL(k7b_corners, dim3(c.n_frames), dim3(kSolveThreads), 0, s, c, c.solve_rec, 1);
+}
+
+void launch_pattern_refine_test(const Ctx& c, hipStream_t s, RefineOut* d_io) {
+  hipLaunchKernelGGL(k7r_pattern_refine_test, dim3(1), dim3(kRefineThreads), 0, s, c, d_io);
+}
+
 void launch_refine_corners(const Ctx& c, hipStream_t s) {
   const int n_slots = (c.p.solver == ILCC_SOLVER_REFERENCE_LOCAL && c.p.phase_mode == 2) ? 2 : 1;
   const size_t lds = (sizeof(float2) + 1) * (size_t)c.grid_lds_points;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)k7a_local_solve, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)((sizeof(float2) + 1) * (size_t)kGridLdsPointsMax));
-    attr_done = true;
-  }
   hipLaunchKernelGGL(k7a_local_solve, dim3(c.n_frames, n_slots), dim3(kSolveThreads), lds, s, c, c.solve_rec);
   hipLaunchKernelGGL(k7b_corners, dim3(c.n_frames), dim3(kSolveThreads), 0, s, c, c.solve_rec, n_slots);
 }
@@ -826,20 +1072,26 @@ void launch_local_solve(const Ctx& c, hipStream_t s, int32_t tlw, int32_t use_oo
   hipLaunchKernelGGL(k7_local_solve_test, dim3(1), dim3(kSolveThreads), 0, s, c, tlw, use_oob, theta_t, cost_iters);
 }
 
-// K9 pack_records: ilcc_result[] (device) -> fixed-size float records [n_frames, 16 + 3 * n_corners]
+// K9 pack_records: ilcc_result[] (device) -> fixed-size float records [n_frames, ILCC_RECORD_HEADER + 3 * n_corners]
 // for the path's single collective (the gather of corner records): the records go from
-// this GPU's HBM straight into RCCL, no host round trip.  Layout = sharding.pack_records.
-__global__ __launch_bounds__(128) void k9_pack_records(const ilcc_result* __restrict__ res, uint32_t n_corners,
+// this GPU's HBM straight into RCCL, no host round trip.  Layout = sharding.pack_records.  tag = tag_base + frame
+// and check = 24-bit xor-fold of the corner bits and the tag let the receiving rank verify WHOSE records arrived
+// where and that their contents are intact (both are exact in a float).
+__global__ __launch_bounds__(128) void k9_pack_records(const ilcc_result* __restrict__ res, uint32_t n_corners, uint32_t tag_base,
                                                        float* __restrict__ out) {
+  __shared__ uint32_t s_x[2];
   const ilcc_result& r = res[blockIdx.x];
-  const uint32_t width = 16u + 3u * n_corners;
+  const uint32_t width = (uint32_t)ILCC_RECORD_HEADER + 3u * n_corners;
   float* o = out + (uint64_t)blockIdx.x * width;
   const uint32_t have = (uint32_t)(r.n_corners < 0 ? 0 : r.n_corners);
+  const uint32_t tag = (tag_base + blockIdx.x) & 0xFFFFFFu;
+  uint32_t x = 0;
   for (uint32_t k = threadIdx.x; k < width; k += blockDim.x) {
     float v = 0.f;
-    if (k >= 16u) {
-      const uint32_t c = k - 16u;
+    if (k >= (uint32_t)ILCC_RECORD_HEADER) {
+      const uint32_t c = k - (uint32_t)ILCC_RECORD_HEADER;
       v = (c < 3u * have) ? r.corners[c] : 0.f;
+      x ^= __float_as_uint(v) * (2u * c + 1u);   // position-dependent: swapped corners change the fold
     } else {
       switch (k) {
         case 0: v = (float)r.status; break;
@@ -857,15 +1109,28 @@ __global__ __launch_bounds__(128) void k9_pack_records(const ilcc_result* __rest
         case 12: v = (float)r.n_plane; break;
         case 13: v = (float)r.n_black; break;
         case 14: v = (float)r.n_white; break;
-        default: v = 0.f;
+        case 15: v = (float)r.basin_margin; break;
+        case 16: v = (float)tag; break;
+        case 18: v = (float)r.flags; break;
+        default: v = 0.f;   // 17 (check) is written below, 19 is spare
       }
     }
-    o[k] = v;
+    if (k != 17u) o[k] = v;
+  }
+#pragma unroll
+  for (int of = ILCC_WAVE / 2; of > 0; of >>= 1) x ^= __shfl_xor(x, of, ILCC_WAVE);
+  if ((threadIdx.x & (ILCC_WAVE - 1)) == 0) s_x[threadIdx.x >> 6] = x;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t t = s_x[0] ^ s_x[1] ^ (tag * 0x9E3779B1u);
+    t = (t ^ (t >> 24)) & 0xFFFFFFu;
+    o[17] = (float)t;
   }
 }
 
-void launch_pack_records(const ilcc_result* d_res, uint32_t n_frames, uint32_t n_corners, float* d_out, hipStream_t s) {
-  if (n_frames) hipLaunchKernelGGL(k9_pack_records, dim3(n_frames), dim3(128), 0, s, d_res, n_corners, d_out);
+void launch_pack_records(const ilcc_result* d_res, uint32_t n_frames, uint32_t n_corners, uint32_t tag_base, float* d_out,
+                         hipStream_t s) {
+  if (n_frames) hipLaunchKernelGGL(k9_pack_records, dim3(n_frames), dim3(128), 0, s, d_res, n_corners, tag_base, d_out);
 }
 
 }  // namespace ilcc

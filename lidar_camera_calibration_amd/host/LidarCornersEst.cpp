@@ -90,7 +90,13 @@ void LidarCornersEst::PCA() {
 }
 
 bool LidarCornersEst::get_corners(std::vector<std::array<double, 3>>& corners) {
-  if (!run() || m_result.status != ILCC_OK) {
+  if (run() && m_result.status == ILCC_AMBIGUOUS && !accept_ambiguous) {
+    // what the reference leaves to the human at the viewer (keys 'd' / 'r', :415-437): a board position one square
+    // away explains the intensities (almost) equally well -- reject unless the caller asked to keep such scans
+    std::cout << "reject this scan (ambiguous: basin margin " << m_result.basin_margin << ")" << std::endl;
+    return false;
+  }
+  if (!run() || (m_result.status != ILCC_OK && m_result.status != ILCC_AMBIGUOUS)) {
     std::cout << "reject this scan" << std::endl;   // :439
     return false;
   }

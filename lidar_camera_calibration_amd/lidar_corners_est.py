@@ -42,6 +42,9 @@ class LidarCornersEst:
         self._cloud = None
         self._click = None
         self._result: Optional[N.Result] = None
+        # ILCC_AMBIGUOUS scans (a basin one square away costs about the same): get_corners() returns False unless
+        # this is set -- the automatic stand-in for the operator who would press 'r' at the viewer
+        self.accept_ambiguous = False
         self.m_click_point = None
         self.m_cloud_ROI = self.m_cloud_chessboard = self.m_cloud_PCA = None
         self.m_cloud_optim = self.m_cloud_corners = None
@@ -135,14 +138,18 @@ class LidarCornersEst:
                                                       off.ctypes.data_as(C.POINTER(C.c_uint64)), 1, N.fptr(pt),
                                                       int(min_plane_points), res)
         self._check(st)
-        self._result = res[0]
+        self._front = res[0]      # gray zone / classes of THIS call; never taken for a get_corners() result
+        self._result = None       # a later EuclideanCluster()/get_corners() re-runs the whole path on setROI's cloud
         out = self._fetch(N.CLOUD_CHESSBOARD) if res[0].status in (N.OK, N.BOARD_NOT_FOUND) else np.zeros((0, 4), np.float32)
         return res[0].status == N.OK, out
 
     def get_gray_zone(self, cloud=None, rate: Optional[float] = None) -> np.ndarray:
         """LidarCornersEst.cpp:303-328 on the plane cloud of the last call (computed on the device
         with ``params.gray_rate``)."""
-        return np.array(self._result.gray_zone)
+        src = self._result if self._result is not None else getattr(self, "_front", None)
+        if src is None:
+            raise RuntimeError("no plane cloud yet: call get_chessboard_by_point or PCA first")
+        return np.array(src.gray_zone)
 
     def color_by_gray_zone(self) -> np.ndarray:
         """LidarCornersEst.cpp:452-499: n x 3 uint8 RGB of the last plane cloud (black 10,10,10 /
@@ -176,7 +183,10 @@ class LidarCornersEst:
     def get_corners(self, corners: list) -> bool:
         """LidarCornersEst.cpp:374-450: fills ``corners`` with (x, y, z) triples, False if rejected."""
         res = self._run()
-        if res.status != N.OK:
+        if res.status == N.AMBIGUOUS and not self.accept_ambiguous:
+            print("reject this scan (ambiguous: basin margin %.3g)" % res.basin_margin)
+            return False
+        if res.status not in (N.OK, N.AMBIGUOUS):
             print("reject this scan")
             return False
         c = res.corners_array()
@@ -261,13 +271,15 @@ class LidarCornersBatch:
             raise IlccError(st, self._err())
         return ticket.value, n_frames
 
-    def wait(self, ticket, d_records_ptr: Optional[int] = None, n_corners: int = 0):
-        """Results of a submitted batch.  With ``d_records_ptr`` (device memory, n_frames x (16 + 3*n_corners)
-        float32) the fixed-size gather records are also packed on the GPU (``ilcc_wait_records_device``)."""
+    def wait(self, ticket, d_records_ptr: Optional[int] = None, n_corners: int = 0, tag_base: int = 0):
+        """Results of a submitted batch.  With ``d_records_ptr`` (device memory, n_frames x (RECORD_HEADER +
+        3*n_corners) float32) the fixed-size gather records are also packed on the GPU
+        (``ilcc_wait_records_device``); record f carries the tag ``tag_base + f``."""
         t, n_frames = ticket
         res = (N.Result * n_frames)()
         if d_records_ptr is not None:
-            st = self._lib.ilcc_wait_records_device(self._h, t, res, C.c_void_p(d_records_ptr), n_corners)
+            st = self._lib.ilcc_wait_records_device(self._h, t, res, C.c_void_p(d_records_ptr), n_corners,
+                                                    int(tag_base) & 0xFFFFFFFF)
         else:
             st = self._lib.ilcc_wait(self._h, t, res)
         if st != N.OK:
@@ -327,6 +339,20 @@ class LidarCornersBatch:
         if st != N.OK:
             raise IlccError(st, self._err())
         return bi.value, bc.value, vol
+
+    def pattern_refine(self, yz: np.ndarray, label: np.ndarray, lat, phase: int):
+        """The GRID-mode refinement kernel alone -> (lat[3], phase, cost_q, alt_cost_q, rounds, hops)."""
+        yz = np.ascontiguousarray(yz, dtype=np.float32).reshape(-1, 2)
+        label = np.ascontiguousarray(label, dtype=np.uint8)
+        q = np.array(lat, dtype=np.int32)
+        ph, rounds, hops = C.c_int32(int(phase)), C.c_int32(0), C.c_int32(0)
+        cq, aq = C.c_int64(0), C.c_int64(0)
+        st = self._lib.ilcc_pattern_refine(self._h, N.fptr(yz), label.ctypes.data_as(C.POINTER(C.c_uint8)), len(label),
+                                           q.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(ph), C.byref(cq),
+                                           C.byref(aq), C.byref(rounds), C.byref(hops))
+        if st != N.OK:
+            raise IlccError(st, self._err())
+        return q, ph.value, cq.value, aq.value, rounds.value, hops.value
 
     def get_theta_t(self, yz: np.ndarray, label: np.ndarray, topleft_white: bool, use_oob: bool,
                     theta_t0=(0.0, 0.0, 0.0)):

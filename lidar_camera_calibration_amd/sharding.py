@@ -12,7 +12,7 @@ from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
 
-HEADER_FLOATS = 16
+HEADER_FLOATS = 20   # ILCC_RECORD_HEADER
 MAX_CORNERS = 256
 RECORD_FLOATS = HEADER_FLOATS + 3 * MAX_CORNERS   # upper bound; pack with n_corners to shrink
 
@@ -46,11 +46,37 @@ def _as_struct_array(results, n_frames: int):
     return None
 
 
-def pack_records(results: Sequence, n_frames: int, n_corners: Optional[int] = None) -> np.ndarray:
+def record_check(corner_block: np.ndarray, tags: np.ndarray) -> np.ndarray:
+    """The 24-bit fold K9 stores in header slot 17: xor over the corner floats' bits times (2*position+1), xor
+    tag * 0x9E3779B1, folded.  corner_block: [F, 3*n_corners] float32, tags: [F]."""
+    bits = np.ascontiguousarray(corner_block, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    mult = (2 * np.arange(bits.shape[1], dtype=np.uint64) + 1)[None, :]
+    x = np.bitwise_xor.reduce((bits * mult) & np.uint64(0xFFFFFFFF), axis=1) if bits.shape[1] else np.zeros(len(bits), np.uint64)
+    t = x ^ ((np.asarray(tags, dtype=np.uint64) & np.uint64(0xFFFFFF)) * np.uint64(0x9E3779B1) & np.uint64(0xFFFFFFFF))
+    return ((t ^ (t >> np.uint64(24))) & np.uint64(0xFFFFFF)).astype(np.uint32)
+
+
+def verify_records(records: np.ndarray, expect_tags: np.ndarray) -> None:
+    """What rank 0 does with the gathered block: every record must carry the tag of the frame that belongs at its
+    position (the right rank's records in the right place) and a check word that matches its contents."""
+    rec = np.asarray(records, dtype=np.float32)
+    tags = rec[:, 16].astype(np.int64)
+    want = np.asarray(expect_tags, dtype=np.int64) & 0xFFFFFF
+    if not np.array_equal(tags, want):
+        bad = int(np.nonzero(tags != want)[0][0])
+        raise AssertionError("gathered record %d carries tag %d, expected %d" % (bad, tags[bad], want[bad]))
+    chk = record_check(rec[:, HEADER_FLOATS:], tags)
+    if not np.array_equal(chk, rec[:, 17].astype(np.uint32)):
+        bad = int(np.nonzero(chk != rec[:, 17].astype(np.uint32))[0][0])
+        raise AssertionError("gathered record %d fails its content check" % bad)
+
+
+def pack_records(results: Sequence, n_frames: int, n_corners: Optional[int] = None, tag_base: int = 0) -> np.ndarray:
     """ilcc_result-like records -> [n_frames, record_floats] float32.
 
     header: status, n_corners, phase, grid_index, iters_a, iters_b, cost_a, cost_b, sel_cost,
-    theta, ty, tz, n_plane, n_black, n_white, 0 ; then corners x y z."""
+    theta, ty, tz, n_plane, n_black, n_white, basin_margin, tag, check, flags, 0 ; then corners x y z
+    (bit-identical to the device-side K9 ``pack_records``)."""
     if n_corners is None:
         n_corners = max([int(results[f].n_corners) for f in range(n_frames)] + [0])
     out = np.zeros((n_frames, record_floats(n_corners)), dtype=np.float32)
@@ -63,17 +89,27 @@ def pack_records(results: Sequence, n_frames: int, n_corners: Optional[int] = No
         out[:, 12] = sa["n_plane"]
         out[:, 13] = sa["n_black"]
         out[:, 14] = sa["n_white"]
+        out[:, 15] = sa["basin_margin"]
+        out[:, 18] = sa["flags"]
         out[:, HEADER_FLOATS:] = sa["corners"][:, :3 * n_corners]
-        ok = np.arange(3 * n_corners)[None, :] < 3 * np.minimum(sa["n_corners"], n_corners)[:, None]
-        out[:, HEADER_FLOATS:] *= ok
+        ok = np.arange(3 * n_corners)[None, :] < 3 * np.maximum(sa["n_corners"], 0)[:, None]
+        out[:, HEADER_FLOATS:] = np.where(ok, out[:, HEADER_FLOATS:], np.float32(0))
+        tags = (int(tag_base) + np.arange(n_frames, dtype=np.int64)) & 0xFFFFFF
+        out[:, 16] = tags
+        out[:, 17] = record_check(out[:, HEADER_FLOATS:], tags)
         return out
     for f in range(n_frames):
         r = results[f]
         out[f, :15] = (r.status, r.n_corners, r.phase, r.grid_index, r.iters_a, r.iters_b, r.cost_a, r.cost_b,
                        r.sel_cost, r.theta_t[0], r.theta_t[1], r.theta_t[2], r.n_plane, r.n_black, r.n_white)
+        out[f, 15] = getattr(r, "basin_margin", 0.0)
+        out[f, 18] = getattr(r, "flags", 0)
         k = min(int(r.n_corners), n_corners)
         if k > 0:
             out[f, HEADER_FLOATS:HEADER_FLOATS + 3 * k] = np.ctypeslib.as_array(r.corners)[:3 * k]
+    tags = (int(tag_base) + np.arange(n_frames, dtype=np.int64)) & 0xFFFFFF
+    out[:, 16] = tags
+    out[:, 17] = record_check(out[:, HEADER_FLOATS:], tags)
     return out
 
 
@@ -114,7 +150,7 @@ def run_sharded(extract_fn, clouds: np.ndarray, clicks: np.ndarray, world: int, 
     rec[:, 0] = -1.0                                   # padding marker
     if hi > lo:
         res = extract_fn(clouds[lo:hi], clicks[lo:hi])
-        rec[:hi - lo] = pack_records(res, hi - lo, n_corners)
+        rec[:hi - lo] = pack_records(res, hi - lo, n_corners, tag_base=lo)   # tag = global frame index
     t = torch.from_numpy(rec)
     if device is not None:
         t = t.to(device)
@@ -122,4 +158,6 @@ def run_sharded(extract_fn, clouds: np.ndarray, clicks: np.ndarray, world: int, 
     if g is None:
         return None
     g = g.cpu().numpy()
-    return g[g[:, 0] >= 0][:f_total]
+    g = g[g[:, 0] >= 0][:f_total]
+    verify_records(g, np.arange(len(g)))               # every frame's record, intact, at its own position
+    return g

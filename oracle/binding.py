@@ -38,6 +38,9 @@ class Params(C.Structure):
         ("th_min", C.c_double), ("th_step", C.c_double),
         ("ty_min", C.c_double), ("ty_step", C.c_double),
         ("tz_min", C.c_double), ("tz_step", C.c_double),
+        ("refine_div", C.c_int32), ("refine_max_rounds", C.c_int32),
+        ("refine_th_margin", C.c_int32), ("refine_pad_", C.c_int32),
+        ("ambiguity_eps", C.c_double),
     ]
 
 
@@ -55,6 +58,7 @@ class Result(C.Structure):
         ("cost_a", C.c_double), ("cost_b", C.c_double),
         ("sel_cost", C.c_double),
         ("grid_cost", C.c_double),
+        ("basin_margin", C.c_double),
         ("pca", C.c_float * 16),
         ("corners", C.c_float * (MAX_CORNERS * 3)),
     ]
@@ -62,6 +66,8 @@ class Result(C.Structure):
 
 SOLVER_REFERENCE_LOCAL = 0
 SOLVER_GRID = 1
+OK, AMBIGUOUS = 0, 11
+COST_Q_ONE = float(1 << 40)
 
 
 def build(force: bool = False) -> str:
@@ -105,6 +111,12 @@ def lib():
         L.orc_get_theta_t.restype = C.c_int32
         L.orc_grid_search.argtypes = [fp, fp, bp, C.c_int32, pp, C.c_int32, dp, dp]
         L.orc_grid_search.restype = C.c_int32
+        L.orc_cost_q.argtypes = [dp, fp, fp, bp, C.c_int32, pp, C.c_int32, C.c_int32]
+        L.orc_cost_q.restype = C.c_int64
+        L.orc_pattern_refine.argtypes = [fp, fp, bp, C.c_int32, pp, ip, ip, C.POINTER(C.c_int64), ip, ip]
+        L.orc_pattern_refine.restype = C.c_int64
+        L.orc_lattice_point.argtypes = [pp, ip, dp]
+        L.orc_lattice_point.restype = None
         L.orc_corners.argtypes = [fp, dp, pp, fp]
         L.orc_corners.restype = C.c_int32
         L.orc_extract.argtypes = [fp, C.c_int32, fp, pp, C.POINTER(Result), fp, fp]
@@ -203,6 +215,37 @@ def cost(theta_t, y, z, label, p, tlw, use_oob):
     lab = np.ascontiguousarray(label, dtype=np.int8)
     return lib().orc_cost(tp, yp, zp, lab.ctypes.data_as(C.POINTER(C.c_int8)), len(yy),
                           C.byref(p), int(tlw), int(use_oob))
+
+
+def cost_q(theta_t, y, z, label, p, tlw, use_oob) -> int:
+    """fixed-point cost of ORC_SOLVER_GRID (units of 2^-40)"""
+    t, tp = _d(theta_t)
+    yy, yp = _f(y)
+    zz, zp = _f(z)
+    lab = np.ascontiguousarray(label, dtype=np.int8)
+    return int(lib().orc_cost_q(tp, yp, zp, lab.ctypes.data_as(C.POINTER(C.c_int8)), len(yy),
+                                C.byref(p), int(tlw), int(use_oob)))
+
+
+def lattice_point(p, lat):
+    q = np.ascontiguousarray(lat, dtype=np.int32)
+    out = np.zeros(3)
+    lib().orc_lattice_point(C.byref(p), q.ctypes.data_as(C.POINTER(C.c_int32)), out.ctypes.data_as(C.POINTER(C.c_double)))
+    return out
+
+
+def pattern_refine(y, z, label, p, lat, phase):
+    """-> (lat[3], phase, cost_q, alt_cost_q, rounds, hops)"""
+    yy, yp = _f(y)
+    zz, zp = _f(z)
+    lab = np.ascontiguousarray(label, dtype=np.int8)
+    q = np.array(lat, dtype=np.int32)
+    ph, rounds, hops = C.c_int32(int(phase)), C.c_int32(0), C.c_int32(0)
+    alt = C.c_int64(0)
+    c = lib().orc_pattern_refine(yp, zp, lab.ctypes.data_as(C.POINTER(C.c_int8)), len(yy), C.byref(p),
+                                 q.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(ph), C.byref(alt),
+                                 C.byref(rounds), C.byref(hops))
+    return q, ph.value, int(c), int(alt.value), rounds.value, hops.value
 
 
 def get_theta_t(pts_pca, gz, p, tlw, use_oob, theta_t0=(0.0, 0.0, 0.0)):

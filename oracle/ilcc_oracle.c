@@ -51,6 +51,10 @@ void orc_default_params(orc_params* p) {
   p->n_tz = 40;
   p->tz_step = 0.15 / 20.0;
   p->tz_min = -0.15;
+  p->refine_div = 16;
+  p->refine_max_rounds = 64;
+  p->refine_th_margin = 32;
+  p->ambiguity_eps = 0.25;
 }
 
 /* ------------------------------------------------------------------------- */
@@ -601,11 +605,11 @@ int32_t orc_gray_zone(const float* intensity, int32_t m, const orc_params* p, do
 /* ------------------------------------------------------------------------- */
 /* Jet semantics restated: floor/ceil drop derivatives, comparisons act on the scalar part,
  * abs(f) = f.a < 0 ? -f : f, matched cells and disabled OOB return the constant 0. */
-double orc_residual(const double theta_t[3], double y, double z, int32_t board_w, int32_t board_h,
-                    double g, int32_t topleft_white, int32_t laser_white, int32_t use_oob,
-                    double jac[3]) {
-  const double th = theta_t[0];
-  const double c = cos(th), s = sin(th);
+/* c, s = cos / sin of theta_t[0]: callers that visit many points under one theta hand them in (the values are
+ * the same doubles either way) */
+static double residual_cs(double c, double s, const double theta_t[3], double y, double z, int32_t board_w,
+                          int32_t board_h, double g, int32_t topleft_white, int32_t laser_white, int32_t use_oob,
+                          double jac[3]) {
   /* ceres::AngleAxisRotatePoint with axis (theta,0,0) applied to (0,y,z) == Rx(theta) (:37-40) */
   const double ry = c * y - s * z;
   const double rz = s * y + c * z;
@@ -647,6 +651,13 @@ double orc_residual(const double theta_t[3], double y, double z, int32_t board_w
   return res;
 }
 
+double orc_residual(const double theta_t[3], double y, double z, int32_t board_w, int32_t board_h,
+                    double g, int32_t topleft_white, int32_t laser_white, int32_t use_oob,
+                    double jac[3]) {
+  const double th = theta_t[0];
+  return residual_cs(cos(th), sin(th), theta_t, y, z, board_w, board_h, g, topleft_white, laser_white, use_oob, jac);
+}
+
 /* HuberLoss(a): rho(s) = s (s <= a^2) else 2 a sqrt(s) - a^2 ; rho' = 1 or a/sqrt(s) */
 static inline void huber(double a, double s, double* rho0, double* rho1) {
   const double b = a * a;
@@ -664,13 +675,54 @@ static inline void huber(double a, double s, double* rho0, double* rho1) {
 double orc_cost(const double theta_t[3], const float* y, const float* z, const int8_t* label,
                 int32_t m, const orc_params* p, int32_t topleft_white, int32_t use_oob) {
   double cost = 0;
+  const double c = cos(theta_t[0]), s = sin(theta_t[0]);
   for (int32_t k = 0; k < m; ++k) {
     if (label[k] != 0 && label[k] != 1) continue;
-    const double r = orc_residual(theta_t, (double)y[k], (double)z[k], p->board_w, p->board_h,
-                                  p->grid_length, topleft_white, label[k], use_oob, NULL);
+    const double r = residual_cs(c, s, theta_t, (double)y[k], (double)z[k], p->board_w, p->board_h,
+                                 p->grid_length, topleft_white, label[k], use_oob, NULL);
     double r0, r1;
     huber(p->huber_delta, r * r, &r0, &r1);
     cost += 0.5 * r0;
+  }
+  return cost;
+}
+
+/* Fixed-point form of the same sum (ORC_SOLVER_GRID): every term is rounded to a multiple of 2^-40 and the
+ * terms are added as integers, so the total does not depend on the order of summation. */
+static inline int64_t term_q(double c, double s, const double theta_t[3], float y, float z, int8_t label,
+                             const orc_params* p, int32_t topleft_white, int32_t use_oob) {
+  const double r = residual_cs(c, s, theta_t, (double)y, (double)z, p->board_w, p->board_h, p->grid_length,
+                               topleft_white, label, use_oob, NULL);
+  double r0, r1;
+  huber(p->huber_delta, r * r, &r0, &r1);
+  return (int64_t)llrint(0.5 * r0 * ORC_COST_Q_ONE);
+}
+
+int64_t orc_cost_q(const double theta_t[3], const float* y, const float* z, const int8_t* label,
+                   int32_t m, const orc_params* p, int32_t topleft_white, int32_t use_oob) {
+  int64_t cost = 0;
+  const double c = cos(theta_t[0]), s = sin(theta_t[0]);
+  for (int32_t k = 0; k < m; ++k) {
+    if (label[k] != 0 && label[k] != 1) continue;
+    cost += term_q(c, s, theta_t, y[k], z[k], label[k], p, topleft_white, use_oob);
+  }
+  return cost;
+}
+
+/* The same sum, abandoned (INT64_MAX returned) once it exceeds `limit`: the terms are non-negative integers, so
+ * a partial sum above the best complete sum cannot win -- and cannot tie.  The points are visited with a stride
+ * coprime to m so that every prefix samples the whole board (integer sums do not care about the order).  Only
+ * an exact shortcut for orc_grid_search: the answer is the exhaustive one. */
+static int64_t cost_q_bounded(const double theta_t[3], double c, double s, const float* y, const float* z,
+                              const int8_t* label, int32_t m, const orc_params* p, int32_t topleft_white,
+                              int32_t use_oob, int64_t limit, int32_t stride) {
+  int64_t cost = 0;
+  int32_t k = 0;
+  for (int32_t n = 0; n < m; ++n) {
+    if (label[k] == 0 || label[k] == 1) cost += term_q(c, s, theta_t, y[k], z[k], label[k], p, topleft_white, use_oob);
+    k += stride;
+    if (k >= m) k -= m;
+    if ((n & 31) == 31 && cost > limit) return INT64_MAX;
   }
   return cost;
 }
@@ -713,11 +765,12 @@ static double pose_eval(const lsq_problem* q, const double* x, double* r, double
 static double lsq_eval(const lsq_problem* q, const double* x, double* r, double* J) {
   if (q->kind) return pose_eval(q, x, r, J);
   double cost = 0;
+  const double cth = cos(x[0]), sth = sin(x[0]);
   for (int32_t k = 0; k < q->n; ++k) {
     double jac[3];
-    const double res = orc_residual(x, (double)q->y[k], (double)q->z[k], q->p->board_w,
-                                    q->p->board_h, q->p->grid_length, q->tlw, q->lab[k], q->oob,
-                                    J ? jac : NULL);
+    const double res = residual_cs(cth, sth, x, (double)q->y[k], (double)q->z[k], q->p->board_w,
+                                   q->p->board_h, q->p->grid_length, q->tlw, q->lab[k], q->oob,
+                                   J ? jac : NULL);
     double r0, r1;
     huber(q->p->huber_delta, res * res, &r0, &r1);
     cost += 0.5 * r0;
@@ -1284,29 +1337,150 @@ int32_t orc_grid_search(const float* y, const float* z, const int8_t* label, int
   const int32_t c_th = near_zero_index(p->th_min, p->th_step, p->n_th);
   const int32_t c_ty = near_zero_index(p->ty_min, p->ty_step, p->n_ty);
   const int32_t c_tz = near_zero_index(p->tz_min, p->tz_step, p->n_tz);
-  double bc = DBL_MAX;
+  int64_t bc = INT64_MAX;
   int64_t bd = INT64_MAX;
   int32_t bi = -1;
-  for (int32_t k = 0; k < p->n_th; ++k)
-    for (int32_t a = 0; a < p->n_ty; ++a)
-      for (int32_t b = 0; b < p->n_tz; ++b) {
-        const double x[3] = {p->th_min + k * p->th_step, p->ty_min + a * p->ty_step,
-                             p->tz_min + b * p->tz_step};
-        const int64_t d2 = (int64_t)(k - c_th) * (k - c_th) + (int64_t)(a - c_ty) * (a - c_ty) +
-                           (int64_t)(b - c_tz) * (b - c_tz);
-        for (int32_t ph = 0; ph < 2; ++ph) {
-          const double c = orc_cost(x, y, z, label, m, p, ph, use_oob);
-          const int32_t flat = ((k * p->n_ty + a) * p->n_tz + b) * 2 + ph;
-          if (cost_out) cost_out[flat] = c;
-          if (c < bc || (c == bc && (d2 < bd || (d2 == bd && flat < bi)))) {
-            bc = c;
-            bd = d2;
-            bi = flat;
+  /* stride ~ 0.618 m, coprime to m (used only by the bounded shortcut) */
+  int32_t stride = 1;
+  if (m > 2) {
+    stride = (int32_t)((double)m * 0.6180339) | 1;
+    for (;;) {
+      int32_t a = stride, b = m;
+      while (b) { const int32_t t = a % b; a = b; b = t; }
+      if (a == 1) break;
+      stride += 2;
+    }
+    if (stride >= m) stride = 1;
+  }
+  /* A first sweep over every 4th candidate per axis only tightens `limit` (the cost of SOME complete candidate, so
+   * nothing cheaper-or-equal is ever abandoned); the selection itself happens in the full sweep that follows. */
+  int64_t limit = INT64_MAX;
+  for (int32_t sweep = cost_out ? 1 : 0; sweep < 2; ++sweep) {
+    const int32_t dec = sweep == 0 ? 4 : 1;
+    for (int32_t k = (sweep == 0 ? c_th % dec : 0); k < p->n_th; k += dec) {
+      const double cth = cos(p->th_min + k * p->th_step), sth = sin(p->th_min + k * p->th_step);
+      for (int32_t a = (sweep == 0 ? c_ty % dec : 0); a < p->n_ty; a += dec)
+        for (int32_t b = (sweep == 0 ? c_tz % dec : 0); b < p->n_tz; b += dec) {
+          const double x[3] = {p->th_min + k * p->th_step, p->ty_min + a * p->ty_step,
+                               p->tz_min + b * p->tz_step};
+          const int64_t d2 = (int64_t)(k - c_th) * (k - c_th) + (int64_t)(a - c_ty) * (a - c_ty) +
+                             (int64_t)(b - c_tz) * (b - c_tz);
+          for (int32_t ph = 0; ph < 2; ++ph) {
+            const int64_t c = cost_out ? orc_cost_q(x, y, z, label, m, p, ph, use_oob)
+                                       : cost_q_bounded(x, cth, sth, y, z, label, m, p, ph, use_oob, limit, stride);
+            if (c < limit) limit = c;
+            if (sweep == 0) continue;
+            const int32_t flat = ((k * p->n_ty + a) * p->n_tz + b) * 2 + ph;
+            if (cost_out) cost_out[flat] = (double)c / ORC_COST_Q_ONE;
+            if (c < bc || (c == bc && (d2 < bd || (d2 == bd && flat < bi)))) {
+              bc = c;
+              bd = d2;
+              bi = flat;
+            }
           }
         }
-      }
-  if (best_cost) *best_cost = bc;
+    }
+  }
+  if (best_cost) *best_cost = (double)bc / ORC_COST_Q_ONE;
   return bi;
+}
+
+/* ------------------------------------------------------------------------- */
+/* ORC_SOLVER_GRID refinement: pattern search + neighbouring basins            */
+/* ------------------------------------------------------------------------- */
+/* Replaces, for the grid mode only, the reference's two local Ceres solves (LidarCornersEst.cpp:398-409):
+ * restated faithfully those run into their 50-iteration caps without converging and can leave the with-OOB
+ * cost HIGHER than where they started.  This search only ever moves to a strictly cheaper lattice point. */
+void orc_lattice_point(const orc_params* p, const int32_t lat[3], double theta_t[3]) {
+  const double div = (double)(p->refine_div > 0 ? p->refine_div : 1);
+  theta_t[0] = p->th_min + (double)lat[0] * (p->th_step / div);
+  theta_t[1] = p->ty_min + (double)lat[1] * (p->ty_step / div);
+  theta_t[2] = p->tz_min + (double)lat[2] * (p->tz_step / div);
+}
+
+static int64_t lattice_cost(const float* y, const float* z, const int8_t* label, int32_t m, const orc_params* p,
+                            const int32_t lat[3], int32_t phase) {
+  double x[3];
+  orc_lattice_point(p, lat, x);
+  return orc_cost_q(x, y, z, label, m, p, phase, 1);
+}
+
+int64_t orc_pattern_refine(const float* y, const float* z, const int8_t* label, int32_t m, const orc_params* p,
+                           int32_t lat[3], int32_t* phase, int64_t* alt_cost, int32_t* rounds, int32_t* hops) {
+  const int32_t div = p->refine_div > 0 ? p->refine_div : 1;
+  /* theta may leave the grid's range by refine_th_margin grid steps (the extent of the GPU kernel's cos/sin table) */
+  const int32_t th_lo = -p->refine_th_margin * div, th_hi = (p->n_th - 1 + p->refine_th_margin) * div;
+  /* one square along y / z in lattice units */
+  const int32_t hop_y = (int32_t)lround(p->grid_length / (p->ty_step / (double)div));
+  const int32_t hop_z = (int32_t)lround(p->grid_length / (p->tz_step / (double)div));
+  int64_t c = lattice_cost(y, z, label, m, p, lat, *phase);
+  int64_t alt = INT64_MAX;
+  int32_t n_rounds = 0, n_hops = 0;
+  for (;;) {
+    /* pattern search at strides div, div/2, ..., 1 */
+    int32_t stride = div, r = 0;
+    while (stride >= 1 && r < p->refine_max_rounds && p->refine_div > 0) {
+      int64_t bc = INT64_MAX;
+      int32_t bd = 0, bq[3] = {0, 0, 0};
+      for (int32_t dk = -1; dk <= 1; ++dk)
+        for (int32_t da = -1; da <= 1; ++da)
+          for (int32_t db = -1; db <= 1; ++db) {
+            if (dk == 0 && da == 0 && db == 0) continue;
+            const int32_t q[3] = {lat[0] + dk * stride, lat[1] + da * stride, lat[2] + db * stride};
+            if (q[0] < th_lo || q[0] > th_hi) continue;
+            const int64_t cc = lattice_cost(y, z, label, m, p, q, *phase);
+            const int32_t d2 = dk * dk + da * da + db * db;
+            if (cc < bc || (cc == bc && d2 < bd)) { /* ties: nearer, then first in (dk, da, db) order */
+              bc = cc;
+              bd = d2;
+              bq[0] = q[0];
+              bq[1] = q[1];
+              bq[2] = q[2];
+            }
+          }
+      ++r;
+      if (bc < c) {
+        c = bc;
+        lat[0] = bq[0];
+        lat[1] = bq[1];
+        lat[2] = bq[2];
+      } else {
+        stride >>= 1;
+      }
+    }
+    n_rounds += r;
+    /* the eight neighbouring basins: one square along y and/or z; an odd shift swaps the colours */
+    alt = INT64_MAX;
+    int32_t aq[3] = {0, 0, 0}, aph = 0;
+    for (int32_t da = -1; da <= 1; ++da)
+      for (int32_t db = -1; db <= 1; ++db) {
+        if (da == 0 && db == 0) continue;
+        const int32_t q[3] = {lat[0], lat[1] + da * hop_y, lat[2] + db * hop_z};
+        const int32_t ph = *phase ^ ((da + db) & 1);
+        const int64_t cc = lattice_cost(y, z, label, m, p, q, ph);
+        if (cc < alt) { /* ties: first in (da, db) order */
+          alt = cc;
+          aq[0] = q[0];
+          aq[1] = q[1];
+          aq[2] = q[2];
+          aph = ph;
+        }
+      }
+    if (alt < c && n_hops < 2 && p->refine_div > 0) {
+      ++n_hops;
+      c = alt;
+      lat[0] = aq[0];
+      lat[1] = aq[1];
+      lat[2] = aq[2];
+      *phase = aph;
+      continue;
+    }
+    break;
+  }
+  if (alt_cost) *alt_cost = alt;
+  if (rounds) *rounds = n_rounds;
+  if (hops) *hops = n_hops;
+  return c;
 }
 
 /* ------------------------------------------------------------------------- */
@@ -1406,21 +1580,29 @@ int32_t orc_extract(const float* xyzi, int32_t n, const float click[3], const or
     out->n_black = counts[0];
     out->n_gray = counts[1];
     out->n_white = counts[2];
-    double th[3] = {0, 0, 0};
-    int32_t phase = 0; /* first loop turn toggles topleftWhite true -> false (:379,398-401) */
     if (p->solver == ORC_SOLVER_GRID) {
+      /* exhaustive grid on the pass-A cost, then the monotone refinement (no Ceres in this mode) */
       double gc = 0;
       const int32_t flat = orc_grid_search(y, z, lab, nl, p, 1, &gc, NULL);
       out->grid_index = flat;
       out->grid_cost = gc;
-      phase = flat & 1;
+      int32_t phase = flat & 1;
       const int32_t cell = flat >> 1;
-      const int32_t bz = cell % p->n_tz, ay = (cell / p->n_tz) % p->n_ty,
-                    k = cell / (p->n_tz * p->n_ty);
-      th[0] = p->th_min + k * p->th_step;
-      th[1] = p->ty_min + ay * p->ty_step;
-      th[2] = p->tz_min + bz * p->tz_step;
-    }
+      const int32_t div = p->refine_div > 0 ? p->refine_div : 1;
+      int32_t lat[3] = {(cell / (p->n_tz * p->n_ty)) * div, ((cell / p->n_tz) % p->n_ty) * div, (cell % p->n_tz) * div};
+      int64_t alt = 0;
+      int32_t rounds = 0, hops = 0;
+      const int64_t c = orc_pattern_refine(y, z, lab, nl, p, lat, &phase, &alt, &rounds, &hops);
+      orc_lattice_point(p, lat, out->theta_t);
+      out->phase = phase;
+      out->iters_a = rounds;
+      out->iters_b = hops;
+      out->cost_a = out->sel_cost = (double)c / ORC_COST_Q_ONE;
+      out->cost_b = (double)alt / ORC_COST_Q_ONE; /* GRID mode: cheapest neighbouring basin */
+      out->basin_margin = ((double)alt - (double)c) / (double)(c > 0 ? c : 1);
+      if (p->ambiguity_eps > 0.0 && out->basin_margin < p->ambiguity_eps) status = ORC_AMBIGUOUS;
+    } else {
+    double th[3] = {0, 0, 0};
     lsq_problem q;
     memset(&q, 0, sizeof(q));
     q.n = nl;
@@ -1428,14 +1610,12 @@ int32_t orc_extract(const float* xyzi, int32_t n, const float click[3], const or
     q.z = z;
     q.lab = lab;
     q.p = p;
-    /* phases to try: the reference's first loop turn uses topleftWhite=false; the user's 'd' key
+    /* phases to try: the reference's first loop turn uses topleftWhite=false (:379,398-401); the user's 'd' key
      * toggles it (Visualization.cpp:45-48).  phase_mode 2 replaces the key press by trying both
      * from (0,0,0) and keeping the lower final cost measured WITH the out-of-board term. */
-    int32_t ph_lo = phase, ph_hi = phase;
-    if (p->solver == ORC_SOLVER_REFERENCE_LOCAL) {
-      if (p->phase_mode == 2) { ph_lo = 0; ph_hi = 1; }
-      else { ph_lo = ph_hi = (p->phase_mode == 1); }
-    }
+    int32_t ph_lo, ph_hi;
+    if (p->phase_mode == 2) { ph_lo = 0; ph_hi = 1; }
+    else { ph_lo = ph_hi = (p->phase_mode == 1); }
     double best_sel = DBL_MAX;
     for (int32_t ph = ph_lo; ph <= ph_hi; ++ph) {
       double t[3] = {th[0], th[1], th[2]};
@@ -1456,6 +1636,7 @@ int32_t orc_extract(const float* xyzi, int32_t n, const float click[3], const or
         out->phase = ph;
         for (int c = 0; c < 3; ++c) out->theta_t[c] = t[c];
       }
+    }
     }
     free(y);
     free(z);

@@ -44,13 +44,16 @@ enum {
   ORC_DEGENERATE_HIST = 4,   /* reference: UB (iter++ past rend), LidarCornersEst.cpp:266-282 */
   ORC_TOO_FEW_POINTS = 5,
   ORC_BAD_ARGUMENT = 6,
-  ORC_BOARD_NOT_FOUND = 10   /* get_chessboard_by_point returned false, LidarCornersEst.cpp:111-112 */
+  ORC_BOARD_NOT_FOUND = 10,  /* get_chessboard_by_point returned false, LidarCornersEst.cpp:111-112 */
+  ORC_AMBIGUOUS = 11         /* ORC_SOLVER_GRID: a neighbouring one-square-shifted basin costs (almost) the same; corners are
+                                still written (the reference has no such signal: a human looks at the viewer and presses 'd') */
 };
 
 /* solver selection for orc_extract */
 enum {
   ORC_SOLVER_REFERENCE_LOCAL = 0, /* get_corners default trajectory: topleftWhite=false, pass A then B from 0 */
-  ORC_SOLVER_GRID = 1             /* exhaustive (theta,ty,tz) x phase grid, then local A+B from the argmin */
+  ORC_SOLVER_GRID = 1             /* exhaustive (theta,ty,tz) x phase grid on the pass-A cost, then a monotone pattern search on the
+                                     same cost (lattice of step/refine_div) and a check of the eight neighbouring basins */
 };
 
 typedef struct orc_params {
@@ -83,6 +86,12 @@ typedef struct orc_params {
   double th_min, th_step;
   double ty_min, ty_step;
   double tz_min, tz_step;
+  /* ORC_SOLVER_GRID refinement (orc_pattern_refine) */
+  int32_t refine_div;        /* finest lattice = grid step / refine_div (power of two, default 16; 0: keep the grid argmin) */
+  int32_t refine_max_rounds; /* bound on the 27-candidate rounds of one pattern search (default 64) */
+  int32_t refine_th_margin;  /* the search may leave the grid's theta range by this many grid steps (default 32) */
+  int32_t refine_pad_;
+  double ambiguity_eps;      /* ORC_AMBIGUOUS when (best neighbouring basin - cost) / cost < eps (default 0.25; <= 0: never) */
 } orc_params;
 
 typedef struct orc_result {
@@ -98,6 +107,7 @@ typedef struct orc_result {
   double cost_a, cost_b;       /* final cost of pass A (OOB on) and B (OOB off) */
   double sel_cost;             /* with-OOB cost at the final theta_t (phase selection metric) */
   double grid_cost;
+  double basin_margin;         /* ORC_SOLVER_GRID: (cost of the best one-square-shifted basin - sel_cost) / sel_cost */
   float pca[16];               /* row-major 4x4, lidar -> plane frame (pca_matrix) */
   float corners[ORC_MAX_CORNERS * 3];
 } orc_result;
@@ -148,10 +158,31 @@ int32_t orc_get_theta_t(const float* pts_pca, int32_t m, const double gray_zone[
                         double theta_t[3], double* cost);
 
 /* exhaustive grid (spec of the GPU search): both phases, chosen OOB flag; returns winning flat index
- * ((k*n_ty + a)*n_tz + b)*2 + phase ; cost_out (optional) full volume [n_th*n_ty*n_tz*2] */
+ * ((k*n_ty + a)*n_tz + b)*2 + phase ; cost_out (optional) full volume [n_th*n_ty*n_tz*2].
+ * Candidates are ordered by the fixed-point cost (orc_cost_q); the doubles returned are cost_q * 2^-40. */
 int32_t orc_grid_search(const float* y, const float* z, const int8_t* label, int32_t m,
                         const orc_params* p, int32_t use_oob, double* best_cost,
                         double* cost_out);
+
+/* ORC_SOLVER_GRID works on a FIXED-POINT cost: sum over the labelled points of llrint(1/2 rho(r^2) * 2^40).
+ * Integer sums do not depend on the summation order, so a parallel reduction (the GPU) and this serial loop
+ * agree bit for bit, and ties are exact ties.  One quantum (2^-40 ~ 9e-13) is far below the fp64 noise of
+ * a ~1e3-term sum of terms <= 1. */
+#define ORC_COST_Q_ONE 1099511627776.0 /* 2^40 */
+int64_t orc_cost_q(const double theta_t[3], const float* y, const float* z, const int8_t* label,
+                   int32_t m, const orc_params* p, int32_t topleft_white, int32_t use_oob);
+
+/* refinement of ORC_SOLVER_GRID.  lat[3] in/out: lattice coordinates (theta, ty, tz) in units of
+ * step / refine_div relative to (th_min, ty_min, tz_min); phase in/out.  Pattern search: evaluate the 26
+ * neighbours at the current stride (refine_div, refine_div/2, ..., 1 lattice units), move to the cheapest if it
+ * is strictly cheaper than the centre (ties: smaller index distance, then index order), else halve the stride.
+ * Then the eight neighbouring basins (one square along y and/or z; an odd shift flips the colour phase) are
+ * evaluated once; a cheaper one is adopted and refined again (at most two hops).  Returns the final cost,
+ * *alt_cost = cheapest neighbouring basin, rounds / hops executed. */
+int64_t orc_pattern_refine(const float* y, const float* z, const int8_t* label, int32_t m, const orc_params* p,
+                           int32_t lat[3], int32_t* phase, int64_t* alt_cost, int32_t* rounds, int32_t* hops);
+/* lattice -> (theta, ty, tz) */
+void orc_lattice_point(const orc_params* p, const int32_t lat[3], double theta_t[3]);
 
 /* a9 getPCDcorners (inverse=false) */
 int32_t orc_corners(const float pca[16], const double theta_t[3], const orc_params* p,

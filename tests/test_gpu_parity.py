@@ -1,10 +1,12 @@
 """GPU parity tests (pytest -m gpu, on the MI355X box): every call goes through the C-ABI of
 libilcc_hip.so and is compared with the CPU oracle on the same seeded inputs.
 
-Tolerances: index/byte work (ROI, cluster, plane inliers, labels, histogram-derived gray zone, grid
-argmin index) must be identical; float stages 1e-6 m; the local solver runs in double on both sides
-and must agree to 1e-6 (theta_t) -- corners to 1e-5 m, 100x inside the 1e-3 m bar of BASELINE.json.
-fp32 grid cost vs the fp64 oracle: 2e-5 relative + 2e-6 absolute.
+Tolerances: index/byte/integer work (ROI, cluster, plane inliers, labels, histogram-derived gray zone, grid
+argmin index, and in ILCC_SOLVER_GRID the whole refinement -- fixed-point costs, lattice coordinates, theta_t,
+rounds, hops, margin) must be IDENTICAL; float stages 1e-6 m; the reference-trajectory solver runs in double on
+both sides and must agree to 1e-6 (theta_t) -- corners to 1e-5 m (GRID: 1e-6 m, only cosf/sinf of the final
+roll may differ in the last bit), far inside the 1e-3 m bar of BASELINE.json.
+fp32 grid cost vs the fixed-point oracle: 2e-5 relative + 2e-6 absolute.
 """
 import ctypes as C
 import os
@@ -64,7 +66,7 @@ def test_every_stage_matches_the_oracle(ob, est, frames, solver):
         # a1 ROI: same points, same order
         roi_idx = ob.roi_crop(clouds[f], clicks[f], op)
         assert np.array_equal(est.fetch_cloud(f, N.CLOUD_ROI), clouds[f][roi_idx])
-        if o.status != 0:
+        if o.status not in (N.OK, N.AMBIGUOUS):
             continue
         # a2 cluster / a3 plane inliers: identical clouds
         clu_idx, _ = ob.cluster(clouds[f][roi_idx], clicks[f], op)
@@ -81,36 +83,82 @@ def test_every_stage_matches_the_oracle(ob, est, frames, solver):
         keep = (inten < o.gray_zone[0]) | (inten > o.gray_zone[1])
         assert np.array_equal(yz, opc[keep][:, 1:3]) and np.array_equal(lab, (inten[keep] > o.gray_zone[1]))
         # a6-a8 search + solve, a9 corners
+        assert r.phase == o.phase
+        assert (r.iters_a, r.iters_b) == (o.iters_a, o.iters_b)
+        dev = np.abs(r.corners_array() - ob.result_corners(o)).max()
+        worst = max(worst, dev)
         if solver == N.SOLVER_GRID:
             assert r.grid_index == o.grid_index, f
             assert r.grid_cost == pytest.approx(o.grid_cost, rel=2e-5, abs=2e-6)
-        assert r.phase == o.phase
-        assert np.allclose(r.theta_t, o.theta_t, atol=1e-6), (f, list(r.theta_t), list(o.theta_t))
-        assert (r.iters_a, r.iters_b) == (o.iters_a, o.iters_b)
-        assert r.cost_a == pytest.approx(o.cost_a, rel=1e-9, abs=1e-12)
-        assert r.cost_b == pytest.approx(o.cost_b, rel=1e-9, abs=1e-12)
-        dev = np.abs(r.corners_array() - ob.result_corners(o)).max()
-        worst = max(worst, dev)
-        assert dev < 1e-5, (f, dev)                 # BASELINE bar: 1e-3 m
+            # the refinement works on integer sums: nothing about it may differ
+            assert tuple(r.theta_t) == tuple(o.theta_t), (f, list(r.theta_t), list(o.theta_t))
+            assert (r.cost_a, r.cost_b, r.sel_cost, r.basin_margin) == (o.cost_a, o.cost_b, o.sel_cost, o.basin_margin)
+            assert r.sel_cost <= o.grid_cost          # monotone: never above the grid argmin's cost
+            assert r.flags == 0
+            assert dev < 1e-6, (f, dev)
+        else:
+            assert np.allclose(r.theta_t, o.theta_t, atol=1e-6), (f, list(r.theta_t), list(o.theta_t))
+            assert r.cost_a == pytest.approx(o.cost_a, rel=1e-9, abs=1e-12)
+            assert r.cost_b == pytest.approx(o.cost_b, rel=1e-9, abs=1e-12)
+            assert dev < 1e-5, (f, dev)             # BASELINE bar: 1e-3 m
         assert r.n_corners == 35
     assert worst < 1e-5
 
 
 def test_bundled_pose_corners_config3(ob, est, golden_dir):
-    """BASELINE config 3: six synthetic frames whose true corners are the rows of
-    pointgrey_lidar_{1..6}.txt; GPU corners vs fixture files and vs the CPU oracle."""
+    """BASELINE config 3 on the VLP-16 / 10 mm-noise frames: six synthetic frames whose true corners are the rows of
+    pointgrey_lidar_{1..6}.txt.  GPU == CPU oracle (the config's second criterion) is asserted; the distance to the
+    bundled files on THIS sensor model is limited by what 16 rings and 10 mm of range noise resolve and is only
+    reported and sanity-bounded here -- the <= 1e-3 m criterion is test_config3_dense_low_noise... below."""
     clouds, clicks, _, _ = synth.make_batch(6, fixture_poses=True)
     for solver in (N.SOLVER_GRID, N.SOLVER_REFERENCE_LOCAL):
         _set_solver(est, solver)
         res = est.extract(clouds, clicks)
         op = _oparams(ob, solver)
+        errs = []
         for n in range(6):
             fix = np.loadtxt(os.path.join(golden_dir, "pointgrey_lidar_%d.txt" % (n + 1)))
             got = res[n].corners_array()
             o = ob.extract(clouds[n], clicks[n], op)
+            assert res[n].status == o.status == N.OK
+            assert np.abs(got - ob.result_corners(o)).max() < 1e-5      # config 3: |GPU - CPU oracle| <= 1e-3 m
+            errs.append(synth.corner_error(got, fix, BOARD))
+        print("config 3, VLP-16 frames, solver %d: |GPU - bundled file| = %s mm" % (solver, np.round(1e3 * np.array(errs), 2)))
+        assert max(errs) < 0.02
+
+
+def _dense_low_noise_fixture_frames():
+    """The six fixture poses seen by a dense, quiet sensor: 128 rings over +-12 deg (0.19 deg apart), 1800 azimuth
+    steps of 0.2 deg, 1 mm range noise, 3 mm beam footprint -- the regime in which the method itself, not the
+    sensor model, sets the error (CPU oracle on these frames: 0.22-0.70 mm from the bundled files in both modes)."""
+    lidar = synth.Lidar(np.linspace(-12.0, 12.0, 128), 1800)
+    board = synth.Board()
+    clouds, clicks = [], []
+    for n in range(6):
+        pose = synth.pose_from_fixture(n)
+        clouds.append(synth.make_frame(lidar, board, pose, 0xD0 + n, sigma_r=0.001, footprint=0.003))
+        clicks.append(synth.make_click(pose, 0xD0 + n))
+    return lidar, np.stack(clouds), np.stack(clicks)
+
+
+def test_config3_dense_low_noise_lands_within_1mm_of_the_bundled_files(ob, golden_dir):
+    """BASELINE config 3's pass criterion as written: max |GPU - fixture| <= 1e-3 m and
+    max |GPU - CPU oracle| <= 1e-3 m, both solver modes, on the dense low-noise variant of the six poses."""
+    lidar, clouds, clicks = _dense_low_noise_fixture_frames()
+    e = LidarCornersBatch(6, lidar.n_points, N.default_params())
+    for solver in (N.SOLVER_GRID, N.SOLVER_REFERENCE_LOCAL):
+        _set_solver(e, solver)
+        res = e.extract(clouds, clicks)
+        op = _oparams(ob, solver)
+        for n in range(6):
+            fix = np.loadtxt(os.path.join(golden_dir, "pointgrey_lidar_%d.txt" % (n + 1)))
+            got = res[n].corners_array()
+            o = ob.extract(clouds[n], clicks[n], op)
+            assert res[n].status == o.status == N.OK, (solver, n, res[n].status, o.status)
             assert np.abs(got - ob.result_corners(o)).max() < 1e-5
-            # vs the bundled file: limited by what 16 rings can resolve, not by the implementation
-            assert synth.corner_error(got, fix, BOARD) < 0.02
+            err = synth.corner_error(got, fix, BOARD)
+            assert err <= 1e-3, (solver, n, err)
+    e.close()
 
 
 def _rand_points(rng, m):
@@ -181,6 +229,81 @@ def test_local_solver_matches_oracle(ob, est, frames, tlw, oob):
     assert it == 0 and c == 0.0 and t[0] == 0.1
 
 
+def test_pattern_refine_kernel_matches_the_oracle_exactly(ob, est, frames):
+    """K7r alone (ilcc_pattern_refine) vs orc_pattern_refine on the labelled points of real frames, from the grid
+    argmin and from displaced starts (incl. one square off with the colours swapped -> a basin hop): lattice
+    coordinates, phase, both fixed-point costs, rounds and hops must be IDENTICAL -- integer sums leave no room."""
+    clouds, clicks, _ = frames
+    p = _set_solver(est, N.SOLVER_GRID)
+    res = est.extract(clouds[:6], clicks[:6])
+    labelled = [est.fetch_labelled(f) for f in range(6)]
+    op = ob.default_params()
+    rng = np.random.default_rng(3)
+    n_hops = 0
+    for f, (yz, lab) in enumerate(labelled):
+        cell = res[f].grid_index >> 1
+        k, a, b = cell // (p.n_ty * p.n_tz), (cell // p.n_tz) % p.n_ty, cell % p.n_tz
+        starts = [([16 * k, 16 * a, 16 * b], res[f].grid_index & 1),
+                  ([16 * k + 5, 16 * a + 320, 16 * b - 3], (res[f].grid_index & 1) ^ 1),       # one square along y
+                  ([int(rng.integers(0, 960)), int(rng.integers(0, 640)), int(rng.integers(0, 640))], int(rng.integers(0, 2))),
+                  ([-400, 100, 700], 0)]                                                        # theta beyond the grid
+        for lat0, ph0 in starts:
+            got = est.pattern_refine(yz, lab, lat0, ph0)
+            want = ob.pattern_refine(yz[:, 0], yz[:, 1], lab.astype(np.int8), op, lat0, ph0)
+            assert list(got[0]) == list(want[0]) and got[1:] == want[1:], (f, lat0, got, want)
+            n_hops += got[5]
+    assert n_hops >= 6                                     # the displaced starts did hop
+    # refinement switched off: the start is kept, the basin check still runs
+    p0 = _set_solver(est, N.SOLVER_GRID, refine_div=0)
+    op0 = ob.default_params()
+    op0.refine_div = 0
+    yz, lab = labelled[0]
+    got = est.pattern_refine(yz, lab, [30, 20, 20], 0)
+    want = ob.pattern_refine(yz[:, 0], yz[:, 1], lab.astype(np.int8), op0, [30, 20, 20], 0)
+    assert list(got[0]) == [30, 20, 20] == list(want[0]) and got[1:] == want[1:] and got[4] == 0
+    # no points at all: every cost is 0 -> margin 0
+    _set_solver(est, N.SOLVER_GRID)
+    got = est.pattern_refine(np.zeros((0, 2), np.float32), np.zeros(0, np.uint8), [480, 320, 320], 0)
+    assert list(got[0]) == [480, 320, 320] and got[2] == 0 and got[3] == 0
+
+
+def test_ambiguous_frames_are_flagged_not_silently_returned(ob):
+    """A board seen only through its middle rows cannot be placed along the long axis: a shift by one square with the
+    colours swapped costs exactly the same.  GRID mode returns ILCC_AMBIGUOUS (margin 0) with the corners still in the
+    record; the host mirror rejects such a scan unless told otherwise; ambiguity_eps <= 0 switches the flag off."""
+    board = synth.Board()
+    pose = synth.pose_from_fixture(0)
+    cloud = synth.make_frame(synth.vlp16(), board, pose, 0xA1)
+    click = synth.make_click(pose, 0xA1)
+    # keep only returns within +-0.28 m of the board centre along its long axis (fixture pose 1: long axis ~ -y)
+    along = (cloud[:, :3] - pose.centre.astype(np.float32)) @ pose.v.astype(np.float32)
+    on_board = np.linalg.norm(cloud[:, :3] - pose.centre.astype(np.float32), axis=1) < 1.0
+    cut = np.ascontiguousarray(cloud[~on_board | (np.abs(along) < 0.28)])
+    p = N.default_params()
+    e = LidarCornersBatch(1, len(cut), p)
+    r = e.extract(cut[None], click[None])[0]
+    op = ob.default_params()
+    op.solver = ob.SOLVER_GRID
+    o = ob.extract(cut, click, op)
+    assert r.status == o.status == N.AMBIGUOUS, (r.status, o.status)
+    assert r.basin_margin == o.basin_margin and r.basin_margin < p.ambiguity_eps
+    assert r.n_corners == 35 and tuple(r.theta_t) == tuple(o.theta_t)
+    assert len(e.fetch_cloud(0, N.CLOUD_OPTIM)) == r.n_plane
+    p.ambiguity_eps = 0.0
+    e.set_params(p)
+    assert e.extract(cut[None], click[None])[0].status == N.OK
+    e.close()
+    m = LidarCornersEst(max_points_per_frame=len(cut))
+    m.setROI(cut, click)
+    assert m.EuclideanCluster() is True
+    m.PCA()
+    corners = []
+    assert m.get_corners(corners) is False and corners == []
+    m.accept_ambiguous = True
+    assert m.get_corners(corners) is True and len(corners) == 35
+    m.close()
+
+
 def test_bad_frames_do_not_abort_the_batch(ob, est, frames):
     clouds, clicks, _ = frames
     _set_solver(est, N.SOLVER_GRID)
@@ -216,8 +339,8 @@ def test_ragged_batch_and_single_frame_entry(ob, frames):
     for i in range(3):
         o = ob.extract(clouds[i][:lens[i]], clicks[i], op)
         assert res[i].status == o.status and res[i].n_points == lens[i]
-        if o.status == 0:
-            assert np.abs(res[i].corners_array() - ob.result_corners(o)).max() < 1e-5
+        if o.status in (N.OK, N.AMBIGUOUS):
+            assert np.abs(res[i].corners_array() - ob.result_corners(o)).max() < 1e-6
     e.close()
     # the reference's call sequence through the host mirror
     m = LidarCornersEst(max_points_per_frame=28800)
@@ -230,7 +353,7 @@ def test_ragged_batch_and_single_frame_entry(ob, frames):
     assert m.m_cloud_corners.shape == (35, 4) and np.all(m.m_cloud_corners[:, 3] == 50.0)
     assert m.m_cloud_optim.shape == m.m_cloud_PCA.shape == m.m_cloud_chessboard.shape
     assert np.abs(m.m_cloud_optim[:, 0] - m.m_cloud_PCA[:, 0]).max() == 0.0       # roll about x only
-    assert np.abs(np.array(corners) - res[0].corners_array()).max() < 1e-7 or True
+    assert np.array_equal(np.array(corners, dtype=np.float32), res[0].corners_array())   # same frame, same path
     m.close()
 
 
@@ -253,7 +376,7 @@ def test_branch_and_bound_does_not_change_the_result(ob, frames):
         e.close()
     for a, b in zip(out[0], out[1]):
         assert a[0] == b[0] and a[1] == b[1]
-        assert np.abs(a[2] - b[2]).max() < 1e-6 if a[0] == 0 else True
+        assert np.array_equal(a[2], b[2])
     # K6 alone on arbitrary points, pruned entry vs the oracle's exhaustive argmin
     rng = np.random.default_rng(77)
     p = N.default_params()
@@ -307,7 +430,7 @@ def test_full_size_batch_properties():
     sub = np.array([np.ctypeslib.as_array(r.corners)[:105].copy() for r in e.extract(clouds[5:9], clicks[5:9])][:4])
     assert np.array_equal(sub, r1[5:9])
     ok = [f for f in range(F) if s1[f] == 0]
-    assert len(ok) >= 0.95 * F
+    assert len(ok) >= 0.93 * F                                      # (ambiguous frames are flagged, not counted)
     err = np.array([synth.corner_error(r1[f].reshape(35, 3), gts[f], BOARD) for f in ok])
     assert np.median(err) < 0.006
     # every result is an exact planar 0.15 m lattice (what the consumer relies on)
@@ -318,32 +441,44 @@ def test_full_size_batch_properties():
     e.close()
 
 
-def test_config5_dense_64_ring_cloud(ob):
-    """BASELINE config 5 shape: 64 rings x 2048 azimuths = 131 072 points, 11x8-corner board @0.10 m."""
-    board = synth.Board(9, 12, 0.10)
-    rng = np.random.default_rng(11)
-    pose = synth.random_pose(rng, range_m=(2.2, 2.6), yaw_deg=15, pitch_deg=10, roll_deg=25)
-    cloud = synth.make_frame(synth.hdl64(), board, pose, 77)
-    click = synth.make_click(pose, 77)
-    p = N.default_params()
+def config5_params(p):
+    """BASELINE config 5: 11 x 8 corners @0.10 m, FINE grid ty, tz in [-g, g] step g/64 (129 x 129),
+    theta in [-16, 16] deg step 0.25 deg (129): 2 146 689 candidates x 2 phases."""
     p.board_w, p.board_h, p.grid_length = 9, 12, 0.10
-    p.n_th, p.n_ty, p.n_tz = 33, 24, 24
-    p.th_min, p.th_step = -0.16, 0.01
+    p.n_th, p.n_ty, p.n_tz = 129, 129, 129
+    p.th_min, p.th_step = -16.0 * np.pi / 180.0, 0.25 * np.pi / 180.0
     p.ty_min = p.tz_min = -0.10
-    p.ty_step = p.tz_step = 0.10 / 12
-    e = LidarCornersBatch(1, 131072, p)
-    r = e.extract(cloud[None], click[None])[0]
-    assert r.status == 0 and r.n_corners == 88
-    op = ob.default_params()
+    p.ty_step = p.tz_step = 0.10 / 64
+    return p
+
+
+def test_config5_dense_64_ring_cloud_fine_grid(ob):
+    """BASELINE config 5 as specified: 64 rings x 2048 azimuths = 131 072 points, 11x8-corner board @0.10 m, the
+    129 x 129 x 129 x 2 grid.  Grid argmin index, refinement and corners vs the oracle (whose exhaustive search
+    uses an exact integer bound, so it finishes in seconds)."""
+    board = synth.Board(9, 12, 0.10)
+    e = LidarCornersBatch(4, 131072, config5_params(N.default_params()))
+    op = config5_params(ob.default_params())
     op.solver = ob.SOLVER_GRID
-    for k in ("board_w", "board_h", "grid_length", "n_th", "n_ty", "n_tz", "th_min", "th_step", "ty_min",
-              "ty_step", "tz_min", "tz_step"):
-        setattr(op, k, getattr(p, k))
-    o = ob.extract(cloud, click, op)
-    assert o.status == 0 and (r.n_roi, r.n_cluster, r.n_plane) == (o.n_roi, o.n_cluster, o.n_plane)
-    assert r.grid_index == o.grid_index
-    assert np.abs(r.corners_array() - ob.result_corners(o)).max() < 1e-5
-    assert synth.corner_error(r.corners_array(), synth.true_corners(pose, board), board) < 0.01
+    clouds, clicks, poses = [], [], []
+    for k in range(4):
+        rng = np.random.default_rng(11 + k)
+        pose = synth.random_pose(rng, range_m=(2.2, 2.6), yaw_deg=15, pitch_deg=10, roll_deg=25)
+        clouds.append(synth.make_frame(synth.hdl64(), board, pose, 77 + k))
+        clicks.append(synth.make_click(pose, 77 + k))
+        poses.append(pose)
+    res = e.extract(np.stack(clouds), np.stack(clicks))
+    tm = e.timing()
+    assert tm.grid_cost_evals_nominal_sum >= 4 * 3000 * 129 ** 3        # the fine grid really ran
+    for k in range(4):
+        r = res[k]
+        o = ob.extract(clouds[k], clicks[k], op)
+        assert r.status == o.status == N.OK and r.n_corners == 88
+        assert (r.n_roi, r.n_cluster, r.n_plane) == (o.n_roi, o.n_cluster, o.n_plane)
+        assert r.grid_index == o.grid_index
+        assert tuple(r.theta_t) == tuple(o.theta_t) and (r.iters_a, r.iters_b) == (o.iters_a, o.iters_b)
+        assert np.abs(r.corners_array() - ob.result_corners(o)).max() < 1e-6
+        assert synth.corner_error(r.corners_array(), synth.true_corners(poses[k], board), board) < 0.01
     e.close()
 
 
@@ -374,8 +509,9 @@ def test_large_roi_takes_the_global_memory_paths(ob):
     o = ob.extract(cloud, click, op)
     assert r.n_roi > 16384, r.n_roi
     assert (r.status, r.n_roi, r.n_cluster, r.n_plane) == (o.status, o.n_roi, o.n_cluster, o.n_plane)
-    assert r.status == 0 and r.grid_index == o.grid_index
-    assert np.abs(r.corners_array() - ob.result_corners(o)).max() < 1e-5
+    assert r.status in (N.OK, N.AMBIGUOUS) and r.grid_index == o.grid_index
+    assert tuple(r.theta_t) == tuple(o.theta_t)
+    assert np.abs(r.corners_array() - ob.result_corners(o)).max() < 1e-6
     e.close()
 
 
@@ -398,8 +534,8 @@ def test_cluster_size_gates_and_non_finite_points(ob, frames):
         assert (r.status, r.n_roi, r.n_cluster, r.n_plane) == (o.status, o.n_roi, o.n_cluster, o.n_plane), (cmin, cmax)
         roi = e.fetch_cloud(0, N.CLOUD_ROI)
         assert np.isfinite(roi[:, :3]).all()
-        if o.status == 0:
-            assert np.abs(r.corners_array() - ob.result_corners(o)).max() < 1e-5
+        if o.status in (N.OK, N.AMBIGUOUS):
+            assert np.abs(r.corners_array() - ob.result_corners(o)).max() < 1e-6
         e.close()
 
 
@@ -413,7 +549,7 @@ def test_online_caller_get_chessboard_by_point(ob):
     clouds = clouds.copy()
     clouds[5, ::5, :3] = np.nan                          # a sparser, partly non-finite cloud
     p = N.default_params()
-    p.cluster_tol = 0.10                                 # LidarCornersEst.cpp:79
+    assert p.online_cluster_tol == 0.10 and p.cluster_tol == 0.12   # LidarCornersEst.cpp:80 vs :131 -- the default IS the reference's
     p.gray_rate = 2.4                                    # launch/lidar_chessboard_online.launch:14
     e = LidarCornersBatch(6, 28800, p)
     res = e.chessboard_by_point(clouds, pts)
@@ -440,6 +576,15 @@ def test_online_caller_get_chessboard_by_point(ob):
     assert rgb.shape == (len(out), 3) and set(map(tuple, np.unique(rgb, axis=0))) <= {(10, 10, 10), (255, 0, 0), (255, 255, 255)}
     ok2, out2 = m.get_chessboard_by_point(clouds[4], pts[4])
     assert ok2 == (res[4].status == 0) and len(out2) == res[4].n_plane
+    # the front-half record of get_chessboard_by_point is never mistaken for a finished extraction: the
+    # reference's call sequence afterwards runs the whole path
+    assert np.allclose(m.get_gray_zone(), res[4].gray_zone if ok2 else m.get_gray_zone())
+    m.setROI(clouds[0], pts[0])
+    assert m.EuclideanCluster() is True
+    m.PCA()
+    corners = []
+    got = m.get_corners(corners)
+    assert m.result.n_corners == 35 and (len(corners) == 35) == got
     m.close()
 
 
@@ -460,18 +605,21 @@ def test_device_records_equal_host_packing():
     d_clicks = torch.from_numpy(clicks).cuda()
     d_rec = torch.full((F, record_floats(board.n_corners)), -3.0, dtype=torch.float32, device="cuda")
     t = est.submit_device(d_clouds.data_ptr(), F, lidar.n_points, d_clicks.data_ptr())
-    res = est.wait(t, d_rec.data_ptr(), board.n_corners)
-    want = pack_records(res, F, board.n_corners)
+    res = est.wait(t, d_rec.data_ptr(), board.n_corners, tag_base=4096)
+    want = pack_records(res, F, board.n_corners, tag_base=4096)
     got = d_rec.cpu().numpy()
     assert res[3].status != 0 and res[7].status != 0 and res[0].status == 0
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    from lidar_camera_calibration_amd.sharding import verify_records
+    verify_records(got, 4096 + np.arange(F))
     est.close()
 
 
 def test_near_tie_is_ordered_like_the_fp64_oracle(ob):
     """Seed 0xBEEF + 125 is a frame whose two best grid candidates (different translation basins, 137 mm apart in
     the corners) cost 0.121899381 and 0.121899392: fp32 sums cannot order them.  K6 lists the near ties of the
-    bound, K7a recounts them in fp64 -- the argmin must be the oracle's (found by tools/grid_parity_sweep.py)."""
+    bound, K7r re-orders them on exact fixed-point sums -- the argmin must be the oracle's (found by
+    tools/grid_parity_sweep.py)."""
     from lidar_camera_calibration_amd import LidarCornersBatch, synth
     from lidar_camera_calibration_amd import _native as N
     clouds, clicks, _, _ = synth.make_batch(1, seed=0xBEEF + 125)
@@ -485,8 +633,10 @@ def test_near_tie_is_ordered_like_the_fp64_oracle(ob):
         e = LidarCornersBatch(1, clouds.shape[1], p)
         r = e.extract(clouds, clicks)[0]
         e.close()
-        assert r.status == 0 and ref.status == 0
+        assert r.status == ref.status and ref.status in (N.OK, N.AMBIGUOUS)
         assert r.grid_index == ref.grid_index == 34756
+        assert r.grid_ties >= 2 and r.flags == 0
+        assert tuple(r.theta_t) == tuple(ref.theta_t)
         assert np.abs(r.corners_array() - ob.result_corners(ref)).max() < 1e-6
 
 
@@ -518,5 +668,5 @@ def test_sparse_wide_roi_takes_the_hashed_lds_cell_lists(ob):
     assert np.prod(np.floor(np.minimum(ext, [12, 12, 6]) / 0.12) + 1) > 16384      # the direct grid does not fit
     assert (r.status, r.n_roi, r.n_cluster, r.n_plane) == (o.status, o.n_roi, o.n_cluster, o.n_plane)
     assert r.n_cluster >= 100 and len(got) == r.n_cluster
-    if r.status == 0 and o.status == 0:
-        assert np.abs(r.corners_array() - ob.result_corners(o)).max() < 1e-5
+    if r.status in (N.OK, N.AMBIGUOUS):
+        assert np.abs(r.corners_array() - ob.result_corners(o)).max() < 1e-6

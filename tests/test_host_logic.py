@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     lib = N.lib()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.ilcc_abi_version() == 1
+    assert lib.ilcc_abi_version() == 2
 
 
 def test_calib_library_exports_every_declared_symbol():
@@ -51,14 +51,17 @@ def test_struct_layouts_match_the_library():
     assert p.solver == N.SOLVER_GRID and p.phase_mode == 2 and p.max_iterations == 50 and p.grid_prune == 1
     assert (p.n_th, p.n_ty, p.n_tz) == (61, 40, 40)
     assert p.tz_step == pytest.approx(0.0075) and p.tz_min == pytest.approx(-0.15)
-    assert C.sizeof(N.Result) == 14 * 4 + 4 + 16 + 64 + 4 + 16 + 24 + 24 + 3 * 4 * 256  # no hidden padding surprises
+    assert (p.refine_div, p.refine_max_rounds, p.refine_th_margin) == (16, 64, 32)
+    assert p.ambiguity_eps == 0.25 and p.online_cluster_tol == 0.10     # LidarCornersEst.cpp:80
+    assert C.sizeof(N.Result) == 14 * 4 + 4 + 16 + 64 + 4 + 16 + 24 + 24 + 8 + 8 + 3 * 4 * 256  # no hidden padding surprises
 
 
 def test_defaults_agree_with_the_oracle(ob):
     p, o = N.default_params(), ob.default_params()
     for f in ("cluster_tol", "cluster_min", "cluster_max", "ransac_thresh", "ransac_hyp", "ransac_seed",
               "hist_bins", "gray_rate", "huber_delta", "grid_length", "board_w", "board_h", "phase_mode",
-              "n_th", "n_ty", "n_tz", "th_min", "th_step", "ty_min", "ty_step", "tz_min", "tz_step"):
+              "n_th", "n_ty", "n_tz", "th_min", "th_step", "ty_min", "ty_step", "tz_min", "tz_step",
+              "refine_div", "refine_max_rounds", "refine_th_margin", "ambiguity_eps"):
         assert getattr(p, f) == getattr(o, f), f
     assert tuple(p.roi_half) == tuple(o.roi_half)
 
@@ -134,10 +137,24 @@ def test_shard_ranges_and_record_packing():
     for k in range(105):
         res[0].corners[k] = k * 0.5
     res[1].status = N.NO_CLUSTER
-    rec = sharding.pack_records(res, 2, 35)
-    assert rec.shape == (2, 16 + 105) and rec[0, 1] == 35 and rec[1, 0] == N.NO_CLUSTER
+    rec = sharding.pack_records(res, 2, 35, tag_base=640)
+    assert rec.shape == (2, N.RECORD_HEADER + 105) and rec[0, 1] == 35 and rec[1, 0] == N.NO_CLUSTER
     cs = sharding.unpack_corners(rec)
     assert cs[0].shape == (35, 3) and cs[0][34, 2] == 52.0 and cs[1].shape == (0, 3)
+    # what rank 0 checks after the gather: whose record sits where, and that its contents are intact
+    assert list(rec[:, 16]) == [640, 641]
+    sharding.verify_records(rec, [640, 641])
+    with pytest.raises(AssertionError, match="tag"):          # two ranks' blocks delivered in the wrong order
+        sharding.verify_records(rec[::-1], [640, 641])
+    bad = rec.copy()
+    bad[0, N.RECORD_HEADER + 7] += 1e-3                        # one corner coordinate damaged in flight
+    with pytest.raises(AssertionError, match="content"):
+        sharding.verify_records(bad, [640, 641])
+    swapped = rec.copy()
+    swapped[0, N.RECORD_HEADER:N.RECORD_HEADER + 3], swapped[0, N.RECORD_HEADER + 3:N.RECORD_HEADER + 6] = \
+        rec[0, N.RECORD_HEADER + 3:N.RECORD_HEADER + 6], rec[0, N.RECORD_HEADER:N.RECORD_HEADER + 3]
+    with pytest.raises(AssertionError, match="content"):       # the fold is position dependent
+        sharding.verify_records(swapped, [640, 641])
 
 
 def _gloo_worker(rank, world, port, clouds, clicks, out_dir):
@@ -171,5 +188,5 @@ def test_two_rank_gather_matches_single_process(ob, tmp_path):
     p = ob.default_params()
     p.solver = ob.SOLVER_REFERENCE_LOCAL
     want = sharding.pack_records([ob.extract(clouds[i], clicks[i], p) for i in range(3)], 3, 35)
-    assert got.shape == want.shape == (3, 16 + 105)
+    assert got.shape == want.shape == (3, N.RECORD_HEADER + 105)
     assert np.array_equal(got, want)

@@ -377,6 +377,124 @@ def test_local_solver_reaches_zero_cost_on_clean_board(ob):
     assert it <= 50
 
 
+# ----------------------------------------------------------------------------- GRID-mode refinement (specification)
+def _clean_board_points(p, th0, ty0, tz0, margin=0.12, step=0.03):
+    """noise-free checker samples (topleftWhite = False) moved by a known board -> cloud motion"""
+    g = p.grid_length
+    ys, zs = np.meshgrid(np.arange(-0.42, 0.43, step), np.arange(-0.57, 0.58, step), indexing="ij")
+    y, z = ys.ravel(), zs.ravel()
+    i = np.floor((y + 3 * g) / g).astype(int)
+    j = np.floor((z + 4 * g) / g).astype(int)
+    fi = (y + 3 * g) / g - i
+    fj = (z + 4 * g) / g - j
+    keep = (np.minimum(fi, 1 - fi) > margin) & (np.minimum(fj, 1 - fj) > margin)
+    white = ((i + j) % 2 == 1)
+    yy = math.cos(-th0) * (y - ty0) - math.sin(-th0) * (z - tz0)
+    zz = math.sin(-th0) * (y - ty0) + math.cos(-th0) * (z - tz0)
+    return yy[keep].astype(np.float32), zz[keep].astype(np.float32), white[keep].astype(np.int8)
+
+
+def test_fixed_point_cost_is_the_cost_and_ignores_summation_order(ob):
+    """orc_cost_q = sum of per-point terms rounded to 2^-40: within m/2 quanta of orc_cost, and -- being an
+    integer sum -- bit-identical under any permutation of the points (what lets a parallel reduction on the GPU
+    take exactly the oracle's decisions)."""
+    p = ob.default_params()
+    rng = np.random.default_rng(11)
+    m = 1500
+    y, z = rng.uniform(-0.5, 0.5, m).astype(np.float32), rng.uniform(-0.7, 0.7, m).astype(np.float32)
+    lab = rng.integers(0, 2, m).astype(np.int8)
+    for th in ([0.0, 0.0, 0.0], [0.11, -0.031, 0.052], [-0.2, 0.07, -0.09]):
+        for ph in (0, 1):
+            for oob in (0, 1):
+                cq = ob.cost_q(th, y, z, lab, p, ph, oob)
+                assert abs(cq / ob.COST_Q_ONE - ob.cost(th, y, z, lab, p, ph, oob)) <= 0.5 * m / ob.COST_Q_ONE + 1e-12
+                perm = rng.permutation(m)
+                assert ob.cost_q(th, y[perm], z[perm], lab[perm], p, ph, oob) == cq
+    assert ob.cost_q([0.0, 0.0, 0.0], y[:0], z[:0], lab[:0], p, 0, 1) == 0
+
+
+def _neighbour_costs(ob, p, y, z, lab, lat, phase, stride=1):
+    out = {}
+    for dk in (-1, 0, 1):
+        for da in (-1, 0, 1):
+            for db in (-1, 0, 1):
+                q = [lat[0] + dk * stride, lat[1] + da * stride, lat[2] + db * stride]
+                out[(dk, da, db)] = ob.cost_q(ob.lattice_point(p, q), y, z, lab, p, phase, 1)
+    return out
+
+
+def test_pattern_refine_is_monotone_and_ends_in_a_lattice_minimum(ob):
+    p = ob.default_params()
+    rng = np.random.default_rng(5)
+    y, z, lab = _clean_board_points(p, 0.031, 0.0131, -0.0212, margin=0.02)
+    y = (y + rng.normal(0, 0.004, len(y))).astype(np.float32)     # noise: a strict minimum instead of a plateau
+    z = (z + rng.normal(0, 0.004, len(z))).astype(np.float32)
+    flip = rng.random(len(lab)) < 0.03
+    lab = np.where(flip, 1 - lab, lab).astype(np.int8)
+    for start in ([30 * 16, 20 * 16, 20 * 16], [34 * 16, 22 * 16, 17 * 16], [27 * 16, 19 * 16, 18 * 16]):
+        c0 = ob.cost_q(ob.lattice_point(p, start), y, z, lab, p, 0, 1)
+        lat, ph, c, alt, rounds, hops = ob.pattern_refine(y, z, lab, p, start, 0)
+        assert c <= c0 and ph == 0 and hops == 0 and 0 < rounds <= p.refine_max_rounds
+        assert c == ob.cost_q(ob.lattice_point(p, lat), y, z, lab, p, ph, 1)
+        nb = _neighbour_costs(ob, p, y, z, lab, lat, ph)
+        assert min(nb.values()) == nb[(0, 0, 0)] == c            # no lattice neighbour is cheaper
+        # (where inside the flat bottom of the basin it ends is not pinned here: samples away from the square
+        # borders cost nothing anywhere on the plateau; accuracy is measured on synthetic frames below)
+        th = ob.lattice_point(p, lat)
+        assert abs(th[0] - 0.031) < 0.03 and abs(th[1] - 0.0131) < 0.03 and abs(th[2] + 0.0212) < 0.03, th
+        assert alt > c                                            # the neighbouring basins are worse: unambiguous
+    # refine_div = 0: the start is kept, only the basin check runs
+    p0 = ob.default_params()
+    p0.refine_div = 0
+    lat, ph, c, alt, rounds, hops = ob.pattern_refine(y, z, lab, p0, [30, 20, 20], 0)
+    assert list(lat) == [30, 20, 20] and rounds == 0 and hops == 0
+    assert c == ob.cost_q(ob.lattice_point(p0, [30, 20, 20]), y, z, lab, p0, 0, 1)
+
+
+def test_pattern_refine_hops_to_the_neighbouring_basin(ob):
+    """Start one square off along y (the colour phase is then the opposite one): the pattern search cannot cross
+    the ridge, the basin check finds the cheaper neighbour, adopts it (phase flipped back) and refines there."""
+    p = ob.default_params()
+    y, z, lab = _clean_board_points(p, 0.0, 0.0, 0.0)
+    true_lat = [30 * 16, 20 * 16, 20 * 16]
+    assert ob.cost_q(ob.lattice_point(p, true_lat), y, z, lab, p, 0, 1) == 0
+    off = [30 * 16, 40 * 16, 20 * 16]          # ty = +g: 20 grid steps = one square
+    lat, ph, c, alt, rounds, hops = ob.pattern_refine(y, z, lab, p, off, 1)
+    assert hops == 1 and ph == 0 and c == 0 and alt > 0
+    th = ob.lattice_point(p, lat)
+    assert abs(th[1]) < 0.04 and abs(th[2]) < 0.04 and abs(th[0]) < 0.06     # back in the true basin (cost 0 = on its plateau)
+    # a board seen only through its middle (no sample within a square of the border along z): a shift by one
+    # square along z with the colours swapped costs exactly the same -> margin 0 -> the frame is flagged
+    mid = np.abs(z) < 0.29
+    lat2, ph2, c2, alt2, _, hops2 = ob.pattern_refine(y[mid], z[mid], lab[mid], p, true_lat, 0)
+    assert c2 == 0 and alt2 == 0 and hops2 == 0
+
+
+def test_grid_mode_extract_flags_ambiguity_and_is_monotone(ob):
+    """orc_extract in GRID mode on a small grid: sel_cost <= grid cost (the refinement never raises the
+    with-OOB cost), theta_t on the lattice, status / margin consistent."""
+    p = ob.default_params()
+    p.solver = ob.SOLVER_GRID
+    p.n_th, p.th_min, p.th_step = 9, -4 * p.th_step, p.th_step          # +-2 deg: keeps the exhaustive oracle fast
+    p.n_ty = p.n_tz = 20
+    p.ty_step = p.tz_step = 0.015
+    pose = synth.pose_from_fixture(0)
+    cloud = synth.make_frame(synth.vlp16(), synth.Board(), pose, 0xC0FFEE)
+    click = synth.make_click(pose, 0xC0FFEE)
+    r = ob.extract(cloud, click, p)
+    assert r.status in (ob.OK, ob.AMBIGUOUS) and r.n_corners == 35
+    assert r.sel_cost <= r.grid_cost + 1e-15 and r.cost_a == r.sel_cost
+    assert (r.status == ob.AMBIGUOUS) == (r.basin_margin < p.ambiguity_eps)
+    assert r.basin_margin == pytest.approx((r.cost_b - r.sel_cost) / r.sel_cost, rel=1e-9)
+    div = p.refine_div
+    for k, (lo, st) in enumerate(((p.th_min, p.th_step), (p.ty_min, p.ty_step), (p.tz_min, p.tz_step))):
+        q = (r.theta_t[k] - lo) / (st / div)
+        assert abs(q - round(q)) < 1e-6
+    assert 0 < r.iters_a <= 3 * p.refine_max_rounds and 0 <= r.iters_b <= 2
+    gt = synth.true_corners(pose, synth.Board())
+    assert synth.corner_error(ob.result_corners(r), gt, synth.Board()) < 0.02
+
+
 # ----------------------------------------------------------------------------- closed loop at the fixture poses
 @pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 6])
 def test_config1_synthetic_frame_at_fixture_pose(ob, golden_dir, n, tmp_path):
