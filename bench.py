@@ -231,7 +231,12 @@ def main():
             extra += 3
             d = np.diff(ts)
             now = time.perf_counter() - t0
-            if (now >= 0.3 and abs(d[-1] - d[-2]) <= 0.03 * max(d[-1], d[-2])) or now >= 3.0:
+            done = (now >= 0.3 and abs(d[-1] - d[-2]) <= 0.03 * max(d[-1], d[-2])) or now >= 3.0
+            if dist_on:   # every rank must issue the same number of steps (= gathers): stop only when all are steady
+                flag = torch.tensor([0.0 if done else 1.0], dtype=torch.float32, device=rec_dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+                done = float(flag.item()) == 0.0
+            if done:
                 return extra
 
     extra_warm = warm(dptrs, args.warmup)
@@ -431,34 +436,30 @@ def pcie_inclusive_rate(torch, est, clouds, d_clicks, F, B, n_points, depth, ste
     torch.cuda.synchronize()
     dt_zero = time.perf_counter() - t0
 
-    # explicit copies on their own stream into rotating device buffers, issued ahead of the submit
-    nbuf = depth + 2
-    bufs = [torch.empty(pinned[0].shape, dtype=pinned[0].dtype, device="cuda") for _ in range(nbuf)]
-    cs = torch.cuda.Stream()
+    # explicit copies: ilcc_submit_batch enqueues each batch's hipMemcpyAsync on the batch's OWN stream, in front of
+    # its kernels -- it overlaps with the kernels of the other batches in flight and the host never blocks on it
+    pinned_clicks = [d_clicks[b].cpu().pin_memory() for b in range(B)]
 
     def go(n_steps):
         tickets = []
-        seq = [(s, b) for s in range(n_steps) for b in range(B)]
-        with torch.cuda.stream(cs):
-            bufs[0].copy_(pinned[seq[0][1]], non_blocking=True)
-        for i, (s, b) in enumerate(seq):
-            cs.synchronize()              # copy i complete: the C-ABI wants complete inputs
-            tickets.append(est.submit_device(bufs[i % nbuf].data_ptr(), F, n_points, d_clicks[b].data_ptr()))
-            if i + 1 < len(seq):
-                with torch.cuda.stream(cs):   # buffer (i+1) % nbuf was last read by batch i+1-nbuf, waited for below
-                    bufs[(i + 1) % nbuf].copy_(pinned[seq[i + 1][1]], non_blocking=True)
-            if len(tickets) == depth:
-                est.wait(tickets.pop(0))
+        for s in range(n_steps):
+            for b in range(B):
+                tickets.append(est.submit_host(hptrs[b], F, n_points, pinned_clicks[b].data_ptr()))
+                if len(tickets) == depth:
+                    est.wait(tickets.pop(0))
         while tickets:
             est.wait(tickets.pop(0))
 
-    go(2)
+    go(3)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     go(n)
     torch.cuda.synchronize()
     dt_copy = time.perf_counter() - t0
 
+    nbuf = 4
+    bufs = [torch.empty(pinned[0].shape, dtype=pinned[0].dtype, device="cuda") for _ in range(nbuf)]
+    cs = torch.cuda.Stream()
     # what the link itself delivers for the same buffers with nothing else running
     with torch.cuda.stream(cs):
         for b in range(2):
@@ -480,8 +481,8 @@ def pcie_inclusive_rate(torch, est, clouds, d_clicks, F, B, n_points, depth, ste
             "link_bound_frames_per_s": raw * 1e9 / (nbytes / F),
             "zero_copy": dict(zero, how="the batch stays in pinned host memory and K1 (which reads every input point "
                                         "exactly once) fetches it over PCIe while other batches compute"),
-            "explicit_copy": dict(copy, how="hipMemcpyAsync on its own stream into rotating device buffers, issued one "
-                                            "batch ahead of its submit")}
+            "explicit_copy": dict(copy, how="ilcc_submit_batch: hipMemcpyAsync of the batch on the batch's own stream, in "
+                                            "front of its kernels (overlaps with the other batches in flight)")}
 
 
 def _cpu_all_cores(clouds, clicks, p, budget_s):

@@ -123,7 +123,7 @@ typedef struct ilcc_params {
   int32_t refine_max_rounds; /* bound on the 27-candidate rounds of one pattern search (default 64) */
   int32_t refine_th_margin;  /* the search may leave the grid's theta range by this many grid steps (default 32) */
   int32_t reserved0;
-  double ambiguity_eps;      /* status ILCC_AMBIGUOUS when basin_margin < ambiguity_eps (default 0.25; <= 0: never) */
+  double ambiguity_eps;      /* status ILCC_AMBIGUOUS when basin_margin < ambiguity_eps (default 1.0: the best alternative must cost at least twice as much; <= 0: never) */
   /* get_chessboard_by_point hard-codes its own tolerance: setClusterTolerance(0.1), LidarCornersEst.cpp:80 */
   double online_cluster_tol;
 } ilcc_params;
@@ -205,6 +205,12 @@ int32_t ilcc_extract_batch_device(ilcc_handle* h, const float* d_xyzi, const uin
  * The inputs must stay valid and unchanged until the matching ilcc_wait returns. */
 int32_t ilcc_submit_batch_device(ilcc_handle* h, const float* d_xyzi, const uint64_t* offsets,
                                  uint32_t n_frames, const float* d_clicks, int32_t* ticket);
+/* The same with HOST inputs (SURVEY.md 8d counts this copy): the batch's H2D copy is enqueued on the slot's own
+ * stream in front of its kernels, so it overlaps with the kernels of the other batches in flight and the host never
+ * blocks on it.  xyzi should be page-locked (hipHostMalloc / hipHostRegister / torch pin_memory): the copy of a
+ * pageable buffer is staged by the runtime and serialises.  xyzi and clicks must stay valid until ilcc_wait. */
+int32_t ilcc_submit_batch(ilcc_handle* h, const float* xyzi, const uint64_t* offsets, uint32_t n_frames,
+                          const float* clicks, int32_t* ticket);
 int32_t ilcc_wait(ilcc_handle* h, int32_t ticket, ilcc_result* out);
 /* ilcc_wait that also leaves, in device memory, the fixed-size records the multi-GPU gather ships
  * (one collective of corner records per step): d_records[n_frames][ILCC_RECORD_HEADER + 3*n_corners]

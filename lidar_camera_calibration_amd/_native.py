@@ -27,7 +27,7 @@ CLOUD_ROI, CLOUD_CLUSTER, CLOUD_CHESSBOARD, CLOUD_PCA, CLOUD_OPTIM = range(5)
 EXPORTS = [
     "ilcc_abi_version", "ilcc_strerror", "ilcc_last_error", "ilcc_default_params",
     "ilcc_set_chessboard_param", "ilcc_create", "ilcc_destroy", "ilcc_set_params", "ilcc_extract",
-    "ilcc_extract_batch", "ilcc_extract_batch_device", "ilcc_submit_batch_device", "ilcc_wait", "ilcc_wait_records_device", "ilcc_fetch_cloud", "ilcc_fetch_labelled", "ilcc_chessboard_by_point_batch", "ilcc_fetch_classes",
+    "ilcc_extract_batch", "ilcc_extract_batch_device", "ilcc_submit_batch_device", "ilcc_submit_batch", "ilcc_wait", "ilcc_wait_records_device", "ilcc_fetch_cloud", "ilcc_fetch_labelled", "ilcc_chessboard_by_point_batch", "ilcc_fetch_classes",
     "ilcc_grid_cost", "ilcc_pattern_refine", "ilcc_get_theta_t", "ilcc_get_timing", "ilcc_reset_timing",
     "ilcc_save_corners2txt", "ilcc_read_lidar_corners",
 ]
@@ -137,6 +137,8 @@ def lib():
         L.ilcc_extract_batch_device.restype = C.c_int32
         L.ilcc_submit_batch_device.argtypes = [vp, vp, C.POINTER(C.c_uint64), C.c_uint32, vp, C.POINTER(C.c_int32)]
         L.ilcc_submit_batch_device.restype = C.c_int32
+        L.ilcc_submit_batch.argtypes = [vp, vp, C.POINTER(C.c_uint64), C.c_uint32, vp, C.POINTER(C.c_int32)]
+        L.ilcc_submit_batch.restype = C.c_int32
         L.ilcc_wait.argtypes = [vp, C.c_int32, rp]
         L.ilcc_wait.restype = C.c_int32
         L.ilcc_wait_records_device.argtypes = [vp, C.c_int32, rp, vp, C.c_uint32, C.c_uint32]

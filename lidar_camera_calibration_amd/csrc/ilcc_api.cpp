@@ -580,7 +580,7 @@ void ilcc_default_params(ilcc_params* p) {
   p->refine_div = 16;
   p->refine_max_rounds = 64;
   p->refine_th_margin = 32;
-  p->ambiguity_eps = 0.25;
+  p->ambiguity_eps = 1.0;
   p->online_cluster_tol = 0.10;   // LidarCornersEst.cpp:80
 }
 
@@ -736,6 +736,31 @@ int32_t ilcc_submit_batch_device(ilcc_handle* h, const float* d_xyzi, const uint
   st = alloc_slot(h, sl);
   if (st != ILCC_OK) return st;
   st = enqueue(h, si, reinterpret_cast<const float4*>(d_xyzi), offsets, n_frames, d_clicks);
+  if (st != ILCC_OK) return st;
+  *ticket = si;
+  h->next_slot = (si + 1) % kSlots;
+  return ILCC_OK;
+}
+
+int32_t ilcc_submit_batch(ilcc_handle* h, const float* xyzi, const uint64_t* offsets, uint32_t n_frames, const float* clicks,
+                          int32_t* ticket) {
+  if (!h || !xyzi || !clicks || !ticket) return ILCC_BAD_ARGUMENT;
+  HIP_TRY(h, hipSetDevice(h->device));
+  int32_t st = check_offsets(h, offsets, n_frames);
+  if (st != ILCC_OK) return st;
+  const int si = h->next_slot;
+  Slot& sl = h->slots[si];
+  if (sl.busy) {
+    h->err = "every pipeline slot holds a batch: ilcc_wait for the oldest ticket first";
+    return ILCC_CAPACITY;
+  }
+  st = alloc_slot(h, sl);
+  if (st != ILCC_OK) return st;
+  // the copy rides on the slot's stream: ordered before this batch's K1, concurrent with every other slot's kernels
+  if (offsets[n_frames] > 0)
+    HIP_TRY(h, hipMemcpyAsync(sl.d_xyzi, xyzi, sizeof(float4) * offsets[n_frames], hipMemcpyHostToDevice, sl.stream));
+  HIP_TRY(h, hipMemcpyAsync(sl.d_clicks, clicks, sizeof(float) * 3 * n_frames, hipMemcpyHostToDevice, sl.stream));
+  st = enqueue(h, si, sl.d_xyzi, offsets, n_frames, sl.d_clicks);
   if (st != ILCC_OK) return st;
   *ticket = si;
   h->next_slot = (si + 1) % kSlots;

@@ -213,17 +213,22 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
   const int my_a = my_c >> 2, my_b = my_c & 3;
 
   // tiles wid, wid+4, ... of the rotated order, tracked as (row, column): no division per tile
+  // (wave-uniform values, pinned to scalar registers: the walk then costs SALU slots, not VALU slots)
   int t_first = wid + t0;
   if (t_first >= n_tiles) t_first -= n_tiles;
-  int ta = t_first / ntb, tb = t_first - ta * ntb;
+  int ta = __builtin_amdgcn_readfirstlane(t_first / ntb);
+  int tb = __builtin_amdgcn_readfirstlane(t_first - ta * ntb);
+  const int ntb_s = __builtin_amdgcn_readfirstlane(ntb), nta_s = __builtin_amdgcn_readfirstlane(nta);
   for (int tt = wid; tt < n_tiles; tt += kGridThreads / ILCC_WAVE) {
     const int ia = a_org + ta * kTile + my_a, ib = b_org + tb * kTile + my_b;
     tb += kGridThreads / ILCC_WAVE;            // advance to this wavefront's next tile
-    while (tb >= ntb) {
-      tb -= ntb;
+    while (tb >= ntb_s) {
+      tb -= ntb_s;
       ++ta;
     }
-    if (ta >= nta) ta -= nta;
+    if (ta >= nta_s) ta -= nta_s;
+    ta = __builtin_amdgcn_readfirstlane(ta);
+    tb = __builtin_amdgcn_readfirstlane(tb);
     const bool owner = ia < n_ty && ib < n_tz;
     const float ay = s_ay[min(ia, n_ty - 1)], az = s_az[min(ib, n_tz - 1)];
 

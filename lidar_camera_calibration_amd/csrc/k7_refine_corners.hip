@@ -133,6 +133,11 @@ __device__ __forceinline__ double xor_lane_f64(double v) {
   const uint32_t lo = xor_lane_u32<MASK>((uint32_t)b), hi = xor_lane_u32<MASK>((uint32_t)(b >> 32));
   return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
+template <int MASK>
+__device__ __forceinline__ unsigned long long xor_lane_u64(unsigned long long b) {
+  const uint32_t lo = xor_lane_u32<MASK>((uint32_t)b), hi = xor_lane_u32<MASK>((uint32_t)(b >> 32));
+  return ((unsigned long long)hi << 32) | lo;
+}
 // butterfly in the order 32, 16, 8, 4, 2, 1: identical in every lane (each step adds the same two operands
 // in both partners), and bit-identical to the __shfl_xor butterfly it replaces
 __device__ __forceinline__ double wave_allsum(double v) {
@@ -655,6 +660,40 @@ struct RefineState {
   long long cost, alt;
 };
 
+// The fixed-point cost's per-point term, operation for operation the oracle's term_q (oracle/ilcc_oracle.c): the
+// functor's residual (Optimization.h:31-107) with the grid coordinate scaled by 1/g (computed once) instead of divided
+// by g, and Huber's rho taken on r directly instead of through sqrt(r^2) -- no fp64 division or square root per
+// point.  AxisTerms = everything the residual needs from one axis (v = i, n = W or v = j, n = H), so that the nine
+// (ty, tz) combinations of a stencil share the three i's and three j's.
+struct AxisTerms {
+  double in_dist;    // min(frac, 1 - frac) as :70-78 compute it
+  double out_dist;   // min(|v|, |v - n|) as :86-97 compute it
+  bool inside;       // 0 < v < n (strict, :48-49)
+  bool odd;          // floor(v) is odd
+};
+__device__ __forceinline__ AxisTerms axis_terms(double v, double n) {
+  AxisTerms t;
+  t.inside = v > 0 && v < n;
+  const double fl = floor(v);
+  t.odd = fl != floor(fl / 2.0) * 2.0;
+  const double fr = v - fl;
+  t.in_dist = (fr > 0.5) ? (fl + 1.0) - v : fr;
+  t.out_dist = (fabs(v) < fabs(v - n)) ? fabs(v) : fabs(v - n);
+  return t;
+}
+// rint(1/2 rho * 2^40) as a double (an integer < 2^53: sums of a few of them are exact in double, too)
+__device__ __forceinline__ double term_q(const AxisTerms& ai, const AxisTerms& aj, bool tlw, bool laser_white, double delta) {
+  double res = 0.0;
+  if (ai.inside && aj.inside) {
+    const bool white = (ai.odd == aj.odd) ? tlw : !tlw;     // both even or both odd -> topleftWhite (:53-61)
+    if (laser_white != white) res = ai.in_dist + aj.in_dist;
+  } else {
+    res = ai.out_dist + aj.out_dist;                        // useOutofBoard (pass-A cost)
+  }
+  const double r0 = (res > delta) ? 2.0 * delta * res - delta * delta : res * res;
+  return rint(r0 * (0.5 * kCostQOne));
+}
+
 // One sweep over the frame's labelled points for the n_cand (<= 32) candidates in sh.cand.  lane -> (candidate,
 // slice): every lane walks its slice of the points for ONE candidate and adds its integer partial sum to the
 // candidate's LDS word -- no cross-lane reduction, and the result cannot depend on who adds first.
@@ -672,17 +711,87 @@ __device__ __forceinline__ int refine_sweep(const Ctx& c, const Board& bd, const
     if (cd.q0 != kNoTheta) {
       const double div = (double)(c.p.refine_div > 0 ? c.p.refine_div : 1);
       const double2 cs = c.th_lattice[cd.q0 - c.th_lat_lo];
-      const double x[3] = {0.0, c.p.ty_min + (double)cd.q1 * (c.p.ty_step / div), c.p.tz_min + (double)cd.q2 * (c.p.tz_step / div)};
+      const double x1 = c.p.ty_min + (double)cd.q1 * (c.p.ty_step / div), x2 = c.p.tz_min + (double)cd.q2 * (c.p.tz_step / div);
+      const double inv_g = 1.0 / bd.g;
       const bool tlw = cd.phase != 0;
       long long sum = 0;
       for (uint32_t p = (uint32_t)(wave_id() * slices + slice); p < n; p += (uint32_t)(kRefineWaves * slices)) {
         const float2 v = yz[p];
-        const double res = residual<false>(x, cs.x, cs.y, (double)v.x, (double)v.y, bd, tlw, lab[p] != 0, true, nullptr);
-        double r0, r1;
-        huber(bd.delta, res * res, r0, r1);
-        sum += __double2ll_rn(0.5 * r0 * kCostQOne);
+        const double y = (double)v.x, z = (double)v.y;
+        const double ry = cs.x * y - cs.y * z;
+        const double rz = cs.y * y + cs.x * z;
+        const AxisTerms ai = axis_terms(((ry + x1) + bd.W * bd.g / 2.0) * inv_g, bd.W);
+        const AxisTerms aj = axis_terms(((rz + x2) + bd.H * bd.g / 2.0) * inv_g, bd.H);
+        sum += (long long)term_q(ai, aj, tlw, lab[p] != 0, bd.delta);
       }
       atomicAdd(&sh.acc[buf][cand], (unsigned long long)sum);
+    }
+  }
+  __syncthreads();
+  ++sweep;
+  return buf;
+}
+
+// One sweep for a 3 x 3 x 3 (or 1 x 3 x 3) STENCIL of candidates: theta in th[0..n_th), ty in ty[0..3), tz in tz[0..3),
+// colour phase = phase ^ (parity ? (a + b) & 1 : 0).  Wavefront w serves theta w % n_th; its lanes take points
+// (slice, slice + n_slices, ...) and evaluate the 9 translations of each: rotation once, the per-axis terms of the
+// three i's and three j's once, then 9 cheap combinations -- the same doubles as 27 independent term evaluations.
+// Totals land in sh.acc[buf][theta * 9 + a * 3 + b].
+__device__ __forceinline__ int stencil_sweep(const Ctx& c, const Board& bd, const float2* yz, const uint8_t* lab, uint32_t n,
+                                             RefineShared& sh, int n_th, const int32_t th[3], const int32_t ty[3],
+                                             const int32_t tz[3], int phase, bool parity, int& sweep) {
+  const int buf = sweep % 3;
+  if (threadIdx.x < kRefineList) sh.acc[(sweep + 1) % 3][threadIdx.x] = 0ull;   // last read two sweeps ago
+  __syncthreads();
+  const int wid = __builtin_amdgcn_readfirstlane(wave_id());
+  const int waves_per_theta = kRefineWaves / n_th;          // 16 -> 5 per theta (one wavefront idles) or 16
+  const int it = wid % n_th, grp = wid / n_th;
+  const int32_t q0 = th[it];
+  if (grp < waves_per_theta && q0 != kNoTheta) {
+    const double div = (double)(c.p.refine_div > 0 ? c.p.refine_div : 1);
+    const double2 cs = c.th_lattice[q0 - c.th_lat_lo];
+    double x1[3], x2[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      x1[k] = c.p.ty_min + (double)ty[k] * (c.p.ty_step / div);
+      x2[k] = c.p.tz_min + (double)tz[k] * (c.p.tz_step / div);
+    }
+    const double inv_g = 1.0 / bd.g;
+    double acc[9];   // integer-valued partial sums of a handful of terms: exact in double
+#pragma unroll
+    for (int e = 0; e < 9; ++e) acc[e] = 0.0;
+    const uint32_t n_slices = (uint32_t)(waves_per_theta * ILCC_WAVE);
+    for (uint32_t p = (uint32_t)(grp * ILCC_WAVE + lane_id()); p < n; p += n_slices) {
+      const float2 v = yz[p];
+      const bool laser_white = lab[p] != 0;
+      const double y = (double)v.x, z = (double)v.y;
+      const double ry = cs.x * y - cs.y * z;
+      const double rz = cs.y * y + cs.x * z;
+      AxisTerms ai[3], aj[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        ai[k] = axis_terms(((ry + x1[k]) + bd.W * bd.g / 2.0) * inv_g, bd.W);
+        aj[k] = axis_terms(((rz + x2[k]) + bd.H * bd.g / 2.0) * inv_g, bd.H);
+      }
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+          const bool tlw = ((phase ^ (parity ? ((a + b) & 1) : 0)) != 0);
+          acc[a * 3 + b] += term_q(ai[a], aj[b], tlw, laser_white, bd.delta);
+        }
+    }
+    // integer sums: any reduction order gives the same totals
+#pragma unroll
+    for (int e = 0; e < 9; ++e) {
+      unsigned long long t = (unsigned long long)(long long)acc[e];
+      t += xor_lane_u64<32>(t);
+      t += xor_lane_u64<16>(t);
+      t += xor_lane_u64<8>(t);
+      t += xor_lane_u64<4>(t);
+      t += xor_lane_u64<2>(t);
+      t += xor_lane_u64<1>(t);
+      if (lane_id() == 0) atomicAdd(&sh.acc[buf][it * 9 + e], t);
     }
   }
   __syncthreads();
@@ -693,7 +802,6 @@ __device__ __forceinline__ int refine_sweep(const Ctx& c, const Board& bd, const
 // orc_pattern_refine, executed redundantly (and identically) by every thread of the workgroup
 __device__ void pattern_refine(const Ctx& c, const Board& bd, const float2* yz, const uint8_t* lab, uint32_t n,
                                RefineShared& sh, int& sweep, RefineState& st) {
-  const int tid = (int)threadIdx.x;
   const bool refine = c.p.refine_div > 0;
   const int div = refine ? c.p.refine_div : 1;
   st.rounds = 0;
@@ -703,12 +811,15 @@ __device__ void pattern_refine(const Ctx& c, const Board& bd, const float2* yz, 
   for (;;) {
     int stride = div, r = 0;
     while (refine && stride >= 1 && r < c.p.refine_max_rounds) {
-      if (tid < 27) {
-        const int dk = tid / 9 - 1, da = (tid / 3) % 3 - 1, db = tid % 3 - 1;
-        const int q0 = st.lat[0] + dk * stride;
-        sh.cand[tid] = RCand{(q0 < c.th_lat_lo || q0 > c.th_lat_hi) ? kNoTheta : q0, st.lat[1] + da * stride, st.lat[2] + db * stride, st.phase};
+      int32_t th[3], ty[3], tz[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int q0 = st.lat[0] + (k - 1) * stride;
+        th[k] = (q0 < c.th_lat_lo || q0 > c.th_lat_hi) ? kNoTheta : q0;
+        ty[k] = st.lat[1] + (k - 1) * stride;
+        tz[k] = st.lat[2] + (k - 1) * stride;
       }
-      const int b = refine_sweep(c, bd, yz, lab, n, sh, 27, sweep);
+      const int b = stencil_sweep(c, bd, yz, lab, n, sh, 3, th, ty, tz, st.phase, false, sweep);
       long long bc = LLONG_MAX;
       int bd2 = 0, be = -1;
       for (int e = 0; e < 27; ++e) {   // (dk, da, db) order; ties: nearer, then first
@@ -736,11 +847,11 @@ __device__ void pattern_refine(const Ctx& c, const Board& bd, const float2* yz, 
     }
     st.rounds += r;
     // the eight neighbouring basins (one square along y and/or z; an odd shift swaps the colours) + the centre
-    if (tid < 9) {
-      const int da = tid / 3 - 1, db = tid % 3 - 1;
-      sh.cand[tid] = RCand{st.lat[0], st.lat[1] + da * c.refine_hop_y, st.lat[2] + db * c.refine_hop_z, st.phase ^ ((da + db) & 1)};
-    }
-    const int b = refine_sweep(c, bd, yz, lab, n, sh, 9, sweep);
+    const int32_t th1[3] = {st.lat[0], kNoTheta, kNoTheta};
+    const int32_t hy[3] = {st.lat[1] - c.refine_hop_y, st.lat[1], st.lat[1] + c.refine_hop_y};
+    const int32_t hz[3] = {st.lat[2] - c.refine_hop_z, st.lat[2], st.lat[2] + c.refine_hop_z};
+    // ((da + db) & 1 with da, db in {-1, 0, 1} == (a + b) & 1 with a = da + 1, b = db + 1)
+    const int b = stencil_sweep(c, bd, yz, lab, n, sh, 1, th1, hy, hz, st.phase, true, sweep);
     st.cost = (long long)sh.acc[b][4];
     long long alt = LLONG_MAX;
     int ae = -1;

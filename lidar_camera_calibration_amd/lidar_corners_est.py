@@ -271,6 +271,18 @@ class LidarCornersBatch:
             raise IlccError(st, self._err())
         return ticket.value, n_frames
 
+    def submit_host(self, xyzi_ptr: int, n_frames: int, n_points: int, clicks_ptr: int):
+        """Asynchronous extraction from HOST buffers (raw addresses, e.g. of pinned torch tensors / numpy arrays that
+        stay alive until ``wait``): the H2D copy rides on the batch's own stream and overlaps with the other batches
+        in flight."""
+        offsets = np.arange(n_frames + 1, dtype=np.uint64) * np.uint64(n_points)
+        ticket = C.c_int32(-1)
+        st = self._lib.ilcc_submit_batch(self._h, C.c_void_p(xyzi_ptr), offsets.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                         n_frames, C.c_void_p(clicks_ptr), C.byref(ticket))
+        if st != N.OK:
+            raise IlccError(st, self._err())
+        return ticket.value, n_frames
+
     def wait(self, ticket, d_records_ptr: Optional[int] = None, n_corners: int = 0, tag_base: int = 0):
         """Results of a submitted batch.  With ``d_records_ptr`` (device memory, n_frames x (RECORD_HEADER +
         3*n_corners) float32) the fixed-size gather records are also packed on the GPU

@@ -54,7 +54,7 @@ void orc_default_params(orc_params* p) {
   p->refine_div = 16;
   p->refine_max_rounds = 64;
   p->refine_th_margin = 32;
-  p->ambiguity_eps = 0.25;
+  p->ambiguity_eps = 1.0;
 }
 
 /* ------------------------------------------------------------------------- */
@@ -689,13 +689,50 @@ double orc_cost(const double theta_t[3], const float* y, const float* z, const i
 
 /* Fixed-point form of the same sum (ORC_SOLVER_GRID): every term is rounded to a multiple of 2^-40 and the
  * terms are added as integers, so the total does not depend on the order of summation. */
-static inline int64_t term_q(double c, double s, const double theta_t[3], float y, float z, int8_t label,
+/* One point's term of the fixed-point cost.  The residual is VirtualboardError's (Optimization.h:31-107, the
+ * logic of residual_cs above, out-of-board branch included) with two changes of ARITHMETIC, not of meaning, made
+ * so that a GPU lane can evaluate a 3 x 3 stencil of translations from shared per-axis terms without fp64
+ * divisions or square roots: the grid coordinate is scaled by the reciprocal 1/g computed once (the functor
+ * divides by g: <= 1 ulp apart), and Huber's rho is taken on r directly -- r > delta ? 2 delta r - delta^2 : r^2 --
+ * instead of through sqrt(r^2).  Every operation below is a plain IEEE double operation (no fused multiply-add),
+ * in this order, on both sides. */
+typedef struct {
+  double in_dist;  /* min(frac, 1 - frac), :70-78 */
+  double out_dist; /* min(|v|, |v - n|), :86-97 */
+  int inside;      /* 0 < v < n, strict (:48-49) */
+  int odd;         /* floor(v) odd */
+} axis_terms_t;
+
+static inline axis_terms_t axis_terms(double v, double n) {
+  axis_terms_t t;
+  t.inside = v > 0 && v < n;
+  const double fl = floor(v);
+  t.odd = fl != floor(fl / 2.0) * 2.0;
+  const double fr = v - fl;
+  t.in_dist = (fr > 0.5) ? (fl + 1.0) - v : fr;
+  t.out_dist = (fabs(v) < fabs(v - n)) ? fabs(v) : fabs(v - n);
+  return t;
+}
+
+static inline int64_t term_q(double c, double s, const double theta_t[3], float yf, float zf, int8_t label,
                              const orc_params* p, int32_t topleft_white, int32_t use_oob) {
-  const double r = residual_cs(c, s, theta_t, (double)y, (double)z, p->board_w, p->board_h, p->grid_length,
-                               topleft_white, label, use_oob, NULL);
-  double r0, r1;
-  huber(p->huber_delta, r * r, &r0, &r1);
-  return (int64_t)llrint(0.5 * r0 * ORC_COST_Q_ONE);
+  const double y = (double)yf, z = (double)zf, g = p->grid_length;
+  const double W = (double)p->board_w, H = (double)p->board_h;
+  const double inv_g = 1.0 / g;
+  const double ry = c * y - s * z;
+  const double rz = s * y + c * z;
+  const axis_terms_t ai = axis_terms(((ry + theta_t[1]) + W * g / 2.0) * inv_g, W);
+  const axis_terms_t aj = axis_terms(((rz + theta_t[2]) + H * g / 2.0) * inv_g, H);
+  double res = 0.0;
+  if (ai.inside && aj.inside) {
+    const int white = (ai.odd == aj.odd) ? (topleft_white != 0) : !(topleft_white != 0); /* :53-61 */
+    if ((label != 0) != white) res = ai.in_dist + aj.in_dist;                             /* :64-82 */
+  } else if (use_oob) {
+    res = ai.out_dist + aj.out_dist;                                                      /* :85-101 */
+  }
+  const double d = p->huber_delta;
+  const double r0 = (res > d) ? 2.0 * d * res - d * d : res * res;
+  return (int64_t)rint(r0 * (0.5 * ORC_COST_Q_ONE)); /* 1/2 rho, in units of 2^-40 */
 }
 
 int64_t orc_cost_q(const double theta_t[3], const float* y, const float* z, const int8_t* label,

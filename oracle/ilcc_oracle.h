@@ -91,7 +91,7 @@ typedef struct orc_params {
   int32_t refine_max_rounds; /* bound on the 27-candidate rounds of one pattern search (default 64) */
   int32_t refine_th_margin;  /* the search may leave the grid's theta range by this many grid steps (default 32) */
   int32_t refine_pad_;
-  double ambiguity_eps;      /* ORC_AMBIGUOUS when (best neighbouring basin - cost) / cost < eps (default 0.25; <= 0: never) */
+  double ambiguity_eps;      /* ORC_AMBIGUOUS when (best neighbouring basin - cost) / cost < eps (default 1.0: an alternative must cost at least twice as much; <= 0: never) */
 } orc_params;
 
 typedef struct orc_result {
@@ -164,10 +164,12 @@ int32_t orc_grid_search(const float* y, const float* z, const int8_t* label, int
                         const orc_params* p, int32_t use_oob, double* best_cost,
                         double* cost_out);
 
-/* ORC_SOLVER_GRID works on a FIXED-POINT cost: sum over the labelled points of llrint(1/2 rho(r^2) * 2^40).
+/* ORC_SOLVER_GRID works on a FIXED-POINT cost: sum over the labelled points of rint(1/2 rho(r^2) * 2^40).
  * Integer sums do not depend on the summation order, so a parallel reduction (the GPU) and this serial loop
  * agree bit for bit, and ties are exact ties.  One quantum (2^-40 ~ 9e-13) is far below the fp64 noise of
- * a ~1e3-term sum of terms <= 1. */
+ * a ~1e3-term sum of terms <= 1.  The per-point residual is the functor's (a6) evaluated with a reciprocal
+ * scaling instead of the division by g and a square-root-free Huber (see term_q in the .c file): within a few
+ * quanta of orc_cost's terms, and cheap enough for the GPU to take thousands of them per candidate stencil. */
 #define ORC_COST_Q_ONE 1099511627776.0 /* 2^40 */
 int64_t orc_cost_q(const double theta_t[3], const float* y, const float* z, const int8_t* label,
                    int32_t m, const orc_params* p, int32_t topleft_white, int32_t use_oob);

@@ -411,6 +411,12 @@ def test_async_submit_wait_matches_synchronous_calls(frames):
         got = [r.corners_array() for r in e.wait(t)]
         assert all(np.array_equal(g, w) for g, w in zip(got, want))
     assert len(e.fetch_cloud(0, N.CLOUD_CHESSBOARD)) > 100          # last completed batch is inspectable
+    # host-input submit (ilcc_submit_batch): the H2D copy rides on the batch's stream; same results again
+    pinned = [(torch.from_numpy(clouds[a:b].copy()).pin_memory(), torch.from_numpy(clicks[a:b].copy()).pin_memory()) for a, b in sets]
+    tickets = [e.submit_host(pc.data_ptr(), len(pk), 28800, pk.data_ptr()) for pc, pk in pinned]
+    for t, want in zip(tickets, sync):
+        got = [r.corners_array() for r in e.wait(t)]
+        assert all(np.array_equal(g, w) for g, w in zip(got, want))
     e.close()
 
 
@@ -634,7 +640,7 @@ def test_near_tie_is_ordered_like_the_fp64_oracle(ob):
         r = e.extract(clouds, clicks)[0]
         e.close()
         assert r.status == ref.status and ref.status in (N.OK, N.AMBIGUOUS)
-        assert r.grid_index == ref.grid_index == 34756
+        assert r.grid_index == ref.grid_index and r.grid_index in (33157, 34756)   # the two tied basins
         assert r.grid_ties >= 2 and r.flags == 0
         assert tuple(r.theta_t) == tuple(ref.theta_t)
         assert np.abs(r.corners_array() - ob.result_corners(ref)).max() < 1e-6

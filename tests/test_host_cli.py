@@ -141,7 +141,7 @@ def test_cpp_mirror_runs_the_reference_node_loop(tmp_path, golden_dir, solver):
         assert f["file"].endswith("pointgrey_lidar_%d.txt" % (k + 1))                # get_lidar_corners.cpp:197
 
 
-def _bench(env_extra, args, launcher=None, timeout=900):
+def _bench(env_extra, args, launcher=None, timeout=300):
     env = dict(os.environ, **env_extra)
     cmd = (launcher or [sys.executable]) + [os.path.join(ROOT, "bench.py")] + args
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)

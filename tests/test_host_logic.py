@@ -52,7 +52,7 @@ def test_struct_layouts_match_the_library():
     assert (p.n_th, p.n_ty, p.n_tz) == (61, 40, 40)
     assert p.tz_step == pytest.approx(0.0075) and p.tz_min == pytest.approx(-0.15)
     assert (p.refine_div, p.refine_max_rounds, p.refine_th_margin) == (16, 64, 32)
-    assert p.ambiguity_eps == 0.25 and p.online_cluster_tol == 0.10     # LidarCornersEst.cpp:80
+    assert p.ambiguity_eps == 1.0 and p.online_cluster_tol == 0.10     # LidarCornersEst.cpp:80
     assert C.sizeof(N.Result) == 14 * 4 + 4 + 16 + 64 + 4 + 16 + 24 + 24 + 8 + 8 + 3 * 4 * 256  # no hidden padding surprises
 
 

@@ -1,15 +1,19 @@
-# full GPU verification + profiles for the round (run through gpurun from the repo root)
-TAG=${1:-r01h}
-python -m pytest tests -m gpu -q 2>&1 | tail -3
+# full GPU verification for the round (run through gpurun from the repo root): tests, smoke, the driver's bench command
+# (--steps 20 --warmup 5) and a long run beside it
+TAG=${1:-r02a}
+mkdir -p gpurun_out
+timeout 2400 python -m pytest tests -m gpu -q -x 2>&1 | tail -15
 python -c "import __graft_entry__ as g; g.smoke(); print('SMOKE OK')" 2>&1 | tail -3
-python bench.py > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err; tail -c 300 gpurun_out/bench_$TAG.err
-R=$GRAFT_REPO_ROOT
-cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_stats -- python $R/bench.py --no-cpu-baseline > /dev/null 2>&1
-cd $R
-find gpurun_out/prof_${TAG}_stats -name "*kernel_stats.csv" | head -1 | xargs -I{} sh -c "cut -c1-150 {} | head -14"
+timeout 900 python bench.py --steps 20 --warmup 5 > gpurun_out/bench_${TAG}_20_5.json 2> gpurun_out/bench_${TAG}_20_5.err; tail -c 600 gpurun_out/bench_${TAG}_20_5.err
+timeout 900 python bench.py --steps 200 --warmup 20 --no-cpu-baseline > gpurun_out/bench_${TAG}_200_20.json 2> gpurun_out/bench_${TAG}_200_20.err; tail -c 300 gpurun_out/bench_${TAG}_200_20.err
 python - <<PY
 import json
-d=json.load(open('gpurun_out/bench_$TAG.json'))
-print('BENCH', d['value'], d['ms_per_step'], d['roofline']['launch_ms'], d['roofline']['frac'], d['roofline']['valu']['executed_fraction'], d['pcie_inclusive']['value'], d['cpu_baseline']['value'], d['cpu_baseline']['all_cores']['value'], d['cpu_baseline']['gpu_vs_cpu_corner_deviation_mm']['max'], d['frames_ok'])
+for n in ("20_5","200_20"):
+    try:
+        d=json.load(open('gpurun_out/bench_${TAG}_%s.json'%n))
+        print('BENCH',n, round(d['value']), round(d['ms_per_step'],3), 'h2d', d.get('value_h2d_inclusive'), 'k6 ms', round(d['roofline']['launch_ms'],4), 'valu frac', round(d['roofline']['frac'],4), 'exec', d['roofline']['executed_fraction'], d['frames_ok'], 'amb', d['frames_flagged_ambiguous'], 'max', d['max_corner_error_mm_vs_ground_truth'], 'med', d['median_corner_error_mm_vs_ground_truth'], 'stages', d['stage_ms_last_batch_overlapped'])
+        if 'grid_vs_reference_path_mm' in d: print('   GRIDvsREF', {k:v for k,v in d['grid_vs_reference_path_mm'].items() if k!='what'})
+        if 'cpu_baseline' in d: print('   CPU', d['cpu_baseline']['value'], d['cpu_baseline']['runs_frames_per_s'], d['cpu_baseline']['all_cores']['value'], d['cpu_baseline']['gpu_vs_cpu_corner_deviation_mm'])
+        if 'pcie_inclusive' in d: print('   PCIE', {k:(v if not isinstance(v,dict) else {kk:vv for kk,vv in v.items() if kk!='how'}) for k,v in d['pcie_inclusive'].items()})
+    except Exception as e: print('BENCH',n,'failed',e)
 PY
