@@ -77,10 +77,21 @@ uint64_t read_record(const uint8_t* p, uint64_t n, Record* r) {
 
 struct File {
   FILE* f = nullptr;
+  uint64_t size = 0;   // set once after fopen: every length field of the file is checked against it BEFORE it sizes a buffer
   ~File() {
     if (f) std::fclose(f);
   }
+  bool measure() {
+    if (fseeko(f, 0, SEEK_END) != 0) return false;
+    const off_t e = ftello(f);
+    if (e < 0) return false;
+    size = (uint64_t)e;
+    return true;
+  }
+  // [pos, pos + n) lies inside the file (no wrap-around)
+  bool holds(uint64_t pos, uint64_t n) const { return pos <= size && n <= size - pos; }
   bool read_at(uint64_t pos, void* dst, uint64_t n) {
+    if (!holds(pos, n)) return false;
     if (fseeko(f, (off_t)pos, SEEK_SET) != 0) return false;
     return std::fread(dst, 1, n, f) == n;
   }
@@ -93,7 +104,7 @@ struct File {
     if (!parse_fields(h.data(), hl, hdr)) return false;
     if (!read_at(pos + 4 + hl, data_len, 4)) return false;
     *data_pos = pos + 8 + hl;
-    return true;
+    return holds(*data_pos, *data_len);   // a data length that runs past the end of the file is a truncated / forged record
   }
 };
 
@@ -141,8 +152,18 @@ const Lz4& lz4() {
 bool inflate_chunk(const std::string& compression, std::vector<uint8_t>& raw, uint32_t size, std::vector<uint8_t>* out,
                    std::string* err) {
   if (compression == "none") {
+    if ((uint64_t)size != raw.size()) {   // the chunk header's `size` is the uncompressed length: for "none" it IS the data length
+      *err = "uncompressed chunk whose size field disagrees with its data length";
+      return false;
+    }
     out->swap(raw);
     return true;
+  }
+  // compressed chunk: bz2 / lz4 cannot expand more than ~255x / ~255x of their input; refuse declared sizes beyond that
+  // bound (and beyond 1 GiB) instead of letting a 30-byte file ask for 4 GiB
+  if ((uint64_t)size > (1ull << 30) || (uint64_t)size > 1024ull + 1024ull * (uint64_t)raw.size()) {
+    *err = "chunk declares an implausible uncompressed size";
+    return false;
   }
   out->resize(size);
   if (compression == "bz2") {
@@ -211,14 +232,15 @@ int32_t fail(int32_t code, const std::string& what) {
 
 extern "C" {
 
-int32_t ilcc_bag_first_message(const char* bag_path, const char* topic, const char* md5sum, uint8_t* msg, uint64_t cap,
-                               uint64_t* msg_bytes) {
+static int32_t bag_first_message_impl(const char* bag_path, const char* topic, const char* md5sum, uint8_t* msg, uint64_t cap,
+                                      uint64_t* msg_bytes) {
   if (!bag_path || !topic || !msg_bytes || (!msg && cap)) return fail(ILCC_BAD_ARGUMENT, "null argument");
   const std::string want_md5 = md5sum ? md5sum : kPointCloud2Md5;
   *msg_bytes = 0;
   File file;
   file.f = std::fopen(bag_path, "rb");
   if (!file.f) return fail(ILCC_IO_ERROR, std::string("cannot open ") + bag_path);
+  if (!file.measure()) return fail(ILCC_IO_ERROR, "cannot determine the size of the bag file");
   char magic[13];
   if (!file.read_at(0, magic, 13) || std::memcmp(magic, "#ROSBAG V2.0\n", 13) != 0)
     return fail(ILCC_IO_ERROR, "not a ROS bag V2.0");
@@ -239,7 +261,9 @@ int32_t ilcc_bag_first_message(const char* bag_path, const char* topic, const ch
   std::map<uint32_t, bool> conn_ok;   // connections on the topic -> md5 matches
   std::vector<ChunkRef> chunks;
   uint64_t pos = index_pos;
-  for (uint32_t k = 0; k < conn_count + chunk_count; ++k) {
+  const uint64_t n_index_records = (uint64_t)conn_count + (uint64_t)chunk_count;   // (a u32 sum could wrap)
+  if (n_index_records > file.size / 8) return fail(ILCC_IO_ERROR, "bag header declares more index records than the file can hold");
+  for (uint64_t k = 0; k < n_index_records; ++k) {
     Fields h;
     if (!file.record_at(pos, &h, &dl, &dpos) || !h.get("op", &op)) return fail(ILCC_IO_ERROR, "index section truncated");
     std::vector<uint8_t> d(dl);
@@ -313,6 +337,20 @@ int32_t ilcc_bag_first_message(const char* bag_path, const char* topic, const ch
   if (best.size() > cap) return fail(ILCC_CAPACITY, "message larger than the buffer");
   std::memcpy(msg, best.data(), best.size());
   return ILCC_OK;
+}
+
+// No exception crosses the C-ABI: allocation failures and anything else a malformed file provokes become a status.
+int32_t ilcc_bag_first_message(const char* bag_path, const char* topic, const char* md5sum, uint8_t* msg, uint64_t cap,
+                               uint64_t* msg_bytes) {
+  try {
+    return bag_first_message_impl(bag_path, topic, md5sum, msg, cap, msg_bytes);
+  } catch (const std::bad_alloc&) {
+    return fail(ILCC_IO_ERROR, "out of memory while reading the bag");
+  } catch (const std::exception& e) {
+    return fail(ILCC_IO_ERROR, std::string("bag reader: ") + e.what());
+  } catch (...) {
+    return fail(ILCC_IO_ERROR, "bag reader: unknown failure");
+  }
 }
 
 int32_t ilcc_pointcloud2_parse(const uint8_t* m, uint64_t n, ilcc_pointcloud2_layout* out) {

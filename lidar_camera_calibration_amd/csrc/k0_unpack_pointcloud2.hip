@@ -138,7 +138,13 @@ extern "C" int32_t ilcc_bag_first_cloud(int32_t device, const char* bag_path, co
   uint64_t bytes = 0;
   int32_t st = ilcc_bag_first_message(bag_path, topic, nullptr, nullptr, 0, &bytes);
   if (st != ILCC_CAPACITY && st != ILCC_OK) return st;
-  std::vector<uint8_t> msg(bytes);
+  std::vector<uint8_t> msg;
+  try {
+    msg.resize(bytes);
+  } catch (...) {   // no exception crosses the C-ABI
+    set_global_error("out of memory for the bag's message");
+    return ILCC_IO_ERROR;
+  }
   st = ilcc_bag_first_message(bag_path, topic, nullptr, msg.data(), bytes, &bytes);
   if (st != ILCC_OK) return st;
   ilcc_pointcloud2_layout L;

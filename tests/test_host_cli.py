@@ -141,6 +141,35 @@ def test_cpp_mirror_runs_the_reference_node_loop(tmp_path, golden_dir, solver):
         assert f["file"].endswith("pointgrey_lidar_%d.txt" % (k + 1))                # get_lidar_corners.cpp:197
 
 
+def test_cpp_multi_gpu_driver_gathers_with_rccl(tmp_path, golden_dir):
+    """ilcc_corners_mgpu: one thread + one ilcc_handle per GPU, contiguous shards, H2D on the batch's stream, records
+    packed on the GPU and ONE ncclGather (RCCL, C++) to rank 0, which checks tag + content word of every record and
+    writes the files.  One GPU here (a 1-rank communicator); the files must be the Python mirror's byte for byte."""
+    mgpu = os.path.join(PKG, "ilcc_corners_mgpu")
+    assert os.path.exists(mgpu)
+    yaml = os.path.join(golden_dir, "pointgrey.yaml")
+    frames = _frames(3)
+    frames.insert(1, (frames[0][0], np.array([40.0, 40.0, 40.0], np.float32)))     # a frame without a board
+    argv = [mgpu, yaml, str(tmp_path / "pointgrey"), "1"]
+    for k, (cloud, click) in enumerate(frames):
+        raw = tmp_path / ("f%d.bin" % k)
+        cloud.tofile(raw)
+        argv += [str(raw), *("%.9g" % v for v in click)]
+    r = subprocess.run(argv, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "gathered 4 records from 1 GPU(s) with one ncclGather; 3 files written" in r.stdout
+    lines = [ln.split() for ln in r.stdout.splitlines() if ln.startswith("frame ")]
+    for k, (cloud, click) in enumerate(frames):
+        f = dict(zip(lines[k][2::2], lines[k][3::2]))
+        if k == 1:
+            assert int(f["status"]) == N.NO_ROI_POINTS and f["file"] == "-"
+            continue
+        py = tmp_path / ("py_%d.txt" % k)
+        ok, st, _ = _python_mirror_file(cloud, click, yaml, str(py), N.SOLVER_GRID)
+        assert ok and int(f["status"]) == st == N.OK
+        assert open(f["file"], "rb").read() == py.read_bytes()
+
+
 def _bench(env_extra, args, launcher=None, timeout=300):
     env = dict(os.environ, **env_extra)
     cmd = (launcher or [sys.executable]) + [os.path.join(ROOT, "bench.py")] + args

@@ -96,6 +96,40 @@ def test_bad_bags(tmp_path):
         ingest.bag_first_message(str(p), "/velodyne_points")
 
 
+def _patch_field(raw: bytes, name: bytes, value: bytes, which: int = 0) -> bytes:
+    """overwrite the value of the `which`-th occurrence of header field `name` (same length)"""
+    at = -1
+    for _ in range(which + 1):
+        at = raw.index(name + b"=", at + 1)
+    at += len(name) + 1
+    return raw[:at] + value + raw[at + len(value):]
+
+
+@pytest.mark.parametrize("compression", ["none", "bz2", "lz4"])
+def test_forged_length_fields_are_refused_not_allocated(tmp_path, compression):
+    """A small file whose length fields ask for gigabytes: every one is checked against the file size
+    before it sizes a buffer, the record count is 64-bit, and nothing throws across the C-ABI -- a status comes back."""
+    p = tmp_path / "x.bag"
+    bag = W.BagWriter(str(p), compression)
+    bag.add_chunk([("/velodyne_points", *PC2, (1, 0), _msg(_cloud(50, 1)))])
+    bag.write()
+    good = p.read_bytes()
+    assert len(ingest.bag_first_message(str(p), "/velodyne_points")) > 0
+    forged = {
+        "chunk_count 2^32-1": _patch_field(good, b"chunk_count", b"\xff\xff\xff\xff"),
+        "conn_count + chunk_count wraps u32": _patch_field(_patch_field(good, b"chunk_count", b"\x02\x00\x00\x80"),
+                                                          b"conn_count", b"\xff\xff\xff\x7f"),
+        "chunk declares 4 GiB uncompressed": _patch_field(good, b"size", b"\xff\xff\xff\xff"),
+        "chunk declares 1 byte more": _patch_field(good, b"size", (W.struct.unpack("<I", good[good.index(b"size=") + 5:][:4])[0] + 1).to_bytes(4, "little")),
+    }
+    forged["index_pos beyond the file"] = _patch_field(good, b"index_pos", (1 << 40).to_bytes(8, "little"))
+    for what, raw in forged.items():
+        p.write_bytes(raw)
+        with pytest.raises(ingest.IngestError) as e:
+            ingest.bag_first_message(str(p), "/velodyne_points")
+        assert e.value.status in (N.IO_ERROR, N.BAD_ARGUMENT), what
+
+
 def test_parse_layout_and_field_matching():
     xyzi = _cloud(33, 4)
     lay = ingest.parse_pointcloud2(_msg(xyzi, seq=9, stamp=(12, 34), frame_id="/velodyne"))

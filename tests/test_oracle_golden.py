@@ -571,3 +571,39 @@ def test_solver_pinned_by_shipped_extrinsic(ob, golden_dir):
     print("iterations", it, "cost", cost, "max |T - shipped|", dev)
     assert 0 < it <= 50
     assert dev < 1e-12     # measured 4e-16: the shipped matrix is this solve, to the last bit or two
+
+
+# ----------------------------------------------------------------------------- sanitizers
+def test_oracle_runs_clean_under_asan_and_ubsan(ob, tmp_path):
+    """`make -C oracle sanitize` builds the oracle with -fsanitize=address,undefined (-fno-sanitize-recover): the whole
+    path (both solver modes, the online caller) on a synthetic frame, on an empty ROI and on a frame with non-finite
+    points must finish with exit status 0, and print what the regular build computes."""
+    import subprocess
+    odir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")
+    subprocess.check_call(["make", "-C", odir, "-s", "sanitize"])
+    pose = synth.pose_from_fixture(3)
+    cloud = synth.make_frame(synth.vlp16(), synth.Board(), pose, 99)
+    click = synth.make_click(pose, 99)
+    nan_cloud = cloud.copy()
+    nan_cloud[::53, 1] = np.nan
+    nan_cloud[7::101, 0] = np.inf
+    cases = [(cloud, click, 0, ()), (cloud, click, 1, (9, 10, 10)), (nan_cloud, click, 0, ()),
+             (cloud, np.array([40, 40, 40], np.float32), 0, ()), (cloud[:0], click, 1, (9, 10, 10))]
+    for k, (c, ck, solver, grid) in enumerate(cases):
+        raw = tmp_path / ("f%d.bin" % k)
+        np.ascontiguousarray(c, dtype=np.float32).tofile(raw)
+        r = subprocess.run([os.path.join(odir, "selftest_san"), str(raw), *("%.9g" % v for v in ck), str(solver), *map(str, grid)],
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (k, r.stderr[-3000:])
+        assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-3000:]
+        head = list(map(int, r.stdout.splitlines()[0].split()))
+        p = ob.default_params()
+        p.solver = solver
+        if grid:
+            p.n_th, p.n_ty, p.n_tz = grid
+            p.th_min = -0.5 * (p.n_th - 1) * p.th_step
+        if len(c):
+            want = ob.extract(c, ck, p)
+            assert head[:5] == [want.status, want.n_roi, want.n_cluster, want.n_plane, want.n_corners], k
+            got = np.array([list(map(float, ln.split())) for ln in r.stdout.splitlines()[1:1 + head[4]]], dtype=np.float32)
+            assert np.array_equal(got.reshape(-1, 3), ob.result_corners(want))

@@ -31,14 +31,20 @@ with cf.ThreadPoolExecutor(min(64, os.cpu_count() or 1)) as ex:
     ref = list(ex.map(lambda f: ob.extract(clouds[f], clicks[f], p), range(F)))
 print("oracle: %.1f s" % (time.perf_counter() - t0))
 same_status = sum(int(res[f].status == ref[f].status) for f in range(F))
-both = [f for f in range(F) if res[f].status == 0 and ref[f].status == 0]
+both = [f for f in range(F) if res[f].status in (0, 11) and ref[f].status in (0, 11)]
 same_idx = sum(int(res[f].grid_index == ref[f].grid_index) for f in both)
+# GRID mode refines on integer sums: theta_t, costs and margin must be the oracle's bit for bit
+same_theta = sum(int(tuple(res[f].theta_t) == tuple(ref[f].theta_t) and res[f].sel_cost == ref[f].sel_cost
+                     and res[f].basin_margin == ref[f].basin_margin) for f in both) if mode == "grid" else -1
+flagged = sum(int(res[f].status == 11) for f in range(F))
+overflow = sum(int(res[f].flags != 0) for f in range(F))
 dev = [float(np.abs(res[f].corners_array() - ob.result_corners(ref[f])).max()) for f in both]
 it = sum(int(res[f].iters_a == ref[f].iters_a and res[f].iters_b == ref[f].iters_b) for f in both)
 print("mode", mode)
-print("frames %d  status agree %d  both ok %d  grid argmin identical %d  iteration counts identical %d  "
-      "max corner deviation %.3g m  frames above 1e-6 m: %d" % (F, same_status, len(both), same_idx, it, max(dev) if dev else 0.0,
-                                                             sum(d > 1e-6 for d in dev)))
+print("frames %d  status agree %d  both with corners %d  grid argmin identical %d  rounds/hops (iterations) identical %d  "
+      "theta_t+cost+margin bit-identical %d  flagged ambiguous %d  tie-list overflows %d  max corner deviation %.3g m  "
+      "frames above 1e-6 m: %d" % (F, same_status, len(both), same_idx, it, same_theta, flagged, overflow,
+                                   max(dev) if dev else 0.0, sum(d > 1e-6 for d in dev)))
 for f in both:
     if res[f].grid_index != ref[f].grid_index:
         print("  frame", f, "gpu", res[f].grid_index, res[f].grid_cost, "oracle", ref[f].grid_index, ref[f].grid_cost)
