@@ -16,7 +16,10 @@
 
 using namespace ilcc;
 
-constexpr int kSlots = 4;   // batches in flight per handle (submit/wait); slot 0 serves the synchronous calls.
+#ifndef ILCC_SLOTS
+#define ILCC_SLOTS 4
+#endif
+constexpr int kSlots = ILCC_SLOTS;   // batches in flight per handle (submit/wait); slot 0 serves the synchronous calls.
                             // Every slot has its own stream: the process needs GPU_MAX_HW_QUEUES >= 5 (HIP default: 4), otherwise two
                             // slot streams share one hardware queue and serialise (measured: 113 k instead of 164 k frames/s)
 
@@ -437,7 +440,10 @@ int32_t enqueue(ilcc_handle* h, int si, const float4* d_xyzi, const uint64_t* of
     // durations stay clean and they do not fight for LDS); the seed and refinement passes above are small,
     // latency-bound launches and are left free to overlap with another batch's full pass, like K2/K3/K7.
     HIP_TRY(h, hipEventRecord(sl.ev[7], s));
-    if (h->k6_last >= 0 && h->k6_last != si && h->slots[h->k6_last].busy)
+#ifndef ILCC_K6_CHAIN
+#define ILCC_K6_CHAIN 1   // (A/B builds: 0 lets the full passes of different batches overlap)
+#endif
+    if (ILCC_K6_CHAIN && h->k6_last >= 0 && h->k6_last != si && h->slots[h->k6_last].busy)
       HIP_TRY(h, hipStreamWaitEvent(s, h->slots[h->k6_last].k6_done, 0));
     HIP_TRY(h, hipEventRecord(sl.ev[8], s));
     full.tie_count = sl.d_tie_count;

@@ -14,7 +14,15 @@ namespace ilcc {
 // block sizes (multiples of the 64-lane wavefront)
 constexpr int kCropThreads = 256;      // K1
 constexpr int kCropChunk = 4096;       // points per K1 block
-constexpr int kFrameThreads = 1024;    // K2..K5, K7: one workgroup per frame
+constexpr int kFrameThreads = 1024;    // K2: one workgroup per frame
+#ifndef ILCC_K3_THREADS
+#define ILCC_K3_THREADS 256    // measured in the pipelined bench: 1024: 229.6 k, 512: 230.4 k, 256: 235.2 k frames/s
+#endif
+#ifndef ILCC_K45_THREADS
+#define ILCC_K45_THREADS 1024
+#endif
+constexpr int kPlaneThreads = ILCC_K3_THREADS;    // K3: one workgroup per frame
+constexpr int kHistThreads = ILCC_K45_THREADS;    // K4/K5: one workgroup per frame
 #ifndef ILCC_K6_THREADS
 #define ILCC_K6_THREADS 256
 #endif
@@ -31,7 +39,8 @@ constexpr int kGridTableMax = 8192;       // K6: n_ty + n_tz bound (their tables
 #endif
 constexpr int kSolveThreads = ILCC_K7_THREADS;     // K7: wavefronts x 64 per (frame, phase)
 #ifndef ILCC_K7R_THREADS
-#define ILCC_K7R_THREADS 1024
+#define ILCC_K7R_THREADS 192   // 3 wavefronts, one per theta of the stencil: measured 192: 230 k, 384-768: 225 k, 1024: 219 k frames/s
+                               // (the kernel's latency is set by the few frames that walk 30+ rounds; small workgroups leave the CUs to K6)
 #endif
 constexpr int kRefineThreads = ILCC_K7R_THREADS;   // K7r: one workgroup per frame
 constexpr int kRefineList = 32;        // K7r: candidates evaluated per sweep over the points

@@ -14,11 +14,11 @@
 
 namespace ilcc {
 
-__global__ __launch_bounds__(kFrameThreads) void k45_plane_frame_hist(Ctx c) {
+__global__ __launch_bounds__(kHistThreads) void k45_plane_frame_hist(Ctx c) {
   __shared__ uint32_t sc[64];
   __shared__ double scd[16 * 6 + 8];
   __shared__ float s_pca[16];
-  __shared__ float s_mm[2 * (kFrameThreads / ILCC_WAVE) + 2];
+  __shared__ float s_mm[34];   // [0..16): per-wavefront minima, [16..32): maxima, 32/33: the totals (<= 16 wavefronts)
   __shared__ double s_gz[2];
   __shared__ int s_status;
   extern __shared__ int s_hist[];   // hist_bins + 1 counters
@@ -39,7 +39,7 @@ __global__ __launch_bounds__(kFrameThreads) void k45_plane_frame_hist(Ctx c) {
   // ------------------------------------------------------------------ K4
   double sx = 0, sy = 0, sz = 0, si = 0;
   float vmin = 3.402823466e38f, vmax = -3.402823466e38f;
-  for (uint32_t i = tid; i < M; i += kFrameThreads) {
+  for (uint32_t i = tid; i < M; i += kHistThreads) {
     const float4 q = P[i];
     sx += q.x;
     sy += q.y;
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(kFrameThreads) void k45_plane_frame_hist(Ctx c) {
   const double cz = (double)(float)(s4[2] / M);
   const double isum = s4[3];
   double cv[6] = {0, 0, 0, 0, 0, 0};
-  for (uint32_t i = tid; i < M; i += kFrameThreads) {
+  for (uint32_t i = tid; i < M; i += kHistThreads) {
     const float4 q = P[i];
     const double dx = q.x - cx, dy = q.y - cy, dz = q.z - cz;
     cv[0] += dx * dx;
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(kFrameThreads) void k45_plane_frame_hist(Ctx c) {
     s_pca[15] = 1.f;
     for (int k = 0; k < 16; ++k) r->pca[k] = s_pca[k];
     float mn = s_mm[0], mx = s_mm[16];
-    for (int w2 = 1; w2 < kFrameThreads / ILCC_WAVE; ++w2) {
+    for (int w2 = 1; w2 < kHistThreads / ILCC_WAVE; ++w2) {
       mn = fminf(mn, s_mm[w2]);
       mx = fmaxf(mx, s_mm[16 + w2]);
     }
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(kFrameThreads) void k45_plane_frame_hist(Ctx c) {
     s_mm[33] = mx;
   }
   const int HL = c.p.hist_bins;
-  for (int b = (int)tid; b <= HL; b += kFrameThreads) s_hist[b] = 0;
+  for (int b = (int)tid; b <= HL; b += kHistThreads) s_hist[b] = 0;
   __syncthreads();
 
   // transformPointCloud (float, unfused) -> m_cloud_PCA
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(kFrameThreads) void k45_plane_frame_hist(Ctx c) {
   const double mn = (double)s_mm[32], mx = (double)s_mm[33];
   const bool flat = !(mx > mn);
   const double factor = flat ? 0.0 : HL / (mx - mn);   // :235
-  for (uint32_t i = tid; i < M; i += kFrameThreads) {
+  for (uint32_t i = tid; i < M; i += kHistThreads) {
     const float4 q = P[i];
     float o[3];
 #pragma unroll
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(kFrameThreads) void k45_plane_frame_hist(Ctx c) {
   const double mean = isum / M;              // :245-248
   const double bin_width = (mx - mn) / HL;   // :258
   if (hist_ok) {
-    for (int bb = (int)tid; bb < HL; bb += kFrameThreads) {
+    for (int bb = (int)tid; bb < HL; bb += kHistThreads) {
       const int cb = s_hist[bb];
       bool first = true;
       for (int b2 = 0; b2 < bb; ++b2) first = first && (s_hist[b2] != cb);
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(kFrameThreads) void k45_plane_frame_hist(Ctx c) {
   uint8_t* __restrict__ LB = c.lab + beg;
   uint8_t* __restrict__ CL = c.cls + beg;
   uint32_t running = 0, nb = 0, nw = 0;
-  for (uint32_t base = 0; base < M; base += kFrameThreads) {
+  for (uint32_t base = 0; base < M; base += kHistThreads) {
     const uint32_t i = base + tid;
     bool keep = false;
     uint8_t l = 0;
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(kFrameThreads) void k45_plane_frame_hist(Ctx c) {
 
 void launch_plane_frame_hist(const Ctx& c, hipStream_t s) {
   const size_t lds = sizeof(int) * (size_t)(c.p.hist_bins + 1);
-  hipLaunchKernelGGL(k45_plane_frame_hist, dim3(c.n_frames), dim3(kFrameThreads), lds, s, c);
+  hipLaunchKernelGGL(k45_plane_frame_hist, dim3(c.n_frames), dim3(kHistThreads), lds, s, c);
 }
 
 }  // namespace ilcc
