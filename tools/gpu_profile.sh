@@ -15,7 +15,7 @@ if [ "$2" = "pmc" ]; then
   cd /tmp
   for C in "SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_SALU" "FETCH_SIZE" "WRITE_SIZE"; do
     N=$(echo $C | cut -d' ' -f1)
-    rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/gpurun_out/prof_${TAG}_pmc_$N -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra-legs --in-flight 1 --batches-per-step 2 > /dev/null 2>&1
+    timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/gpurun_out/prof_${TAG}_pmc_$N -- python $R/tools/pmc_target.py > /dev/null 2>&1
   done
   cd $R
   python tools/pmc_summary.py gpurun_out/prof_${TAG}_pmc_ > gpurun_out/${TAG}_pmc_summary.csv; cat gpurun_out/${TAG}_pmc_summary.csv
