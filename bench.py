@@ -57,9 +57,13 @@ K6_HBM_TRAFFIC_BYTES_128 = 26512728   # profiles/r02g_pmc_summary.csv: 6236513 +
 # VALU issue peak: 256 CU x 4 SIMD x 32 lanes x 2.4 GHz = 78.6 T lane-instructions/s
 # (= the 157.3 TFLOP/s fp32 vector peak of MI355X_MICROARCH.md when every instruction is an FMA)
 VALU_ISSUE_PEAK_T = 78.6
-# VALU instructions per (point, candidate) evaluation of k6_grid_cost (both phases), counted from
-# the gfx950 ISA of the inner loop: 110 per 4 points of a lane (DESIGN.md "K6")
-K6_VALU_OPS_PER_EVAL = 27.5
+# VALU instructions per (point, candidate) evaluation of k6_grid_cost (both phases), counted from the gfx950 ISA of
+# the inner loop bodies (DESIGN.md "K6"; same convention as round 1's 27.5 = 110 per 4-point block: the block's bound
+# test is included, tile prologues / epilogues / staging are not): 89 per 3-point block of border-class points
+# (out-of-board logic included), 56 per 3-point block of interior-class points (they cannot leave the board under any
+# translation of the grid).  The library counts the executed evaluations of both classes.
+K6_VALU_OPS_BORDER = 89.0 / 3.0
+K6_VALU_OPS_INTERIOR = 56.0 / 3.0
 
 
 def _gen_chunk(args):
@@ -279,7 +283,10 @@ def main():
         achieved = k6_bytes / (k6_ms * 1e-3) / 1e9
         evals_per_launch = tm.grid_cost_evals_sum / launches            # executed (after branch-and-bound cuts)
         evals_nominal = tm.grid_cost_evals_nominal_sum / launches       # what a cut-free exhaustive pass needs
-        valu_rate = evals_per_launch * K6_VALU_OPS_PER_EVAL / (k6_ms * 1e-3) / 1e12
+        evals_interior = tm.grid_cost_evals_interior_sum / launches
+        valu_ops_per_eval = (K6_VALU_OPS_INTERIOR * evals_interior + K6_VALU_OPS_BORDER * (evals_per_launch - evals_interior)) \
+            / max(1.0, evals_per_launch)
+        valu_rate = evals_per_launch * valu_ops_per_eval / (k6_ms * 1e-3) / 1e12
         out = {
             "metric": "chessboard-corner frames/sec + max corner error (mm), VLP-16 cloud",
             "value": fps,
@@ -343,14 +350,15 @@ def main():
                 "evals_executed_per_launch": evals_per_launch,
                 "evals_nominal_per_launch": evals_nominal,
                 "executed_fraction": evals_per_launch / evals_nominal if evals_nominal else None,
-                "valu_instr_per_eval": K6_VALU_OPS_PER_EVAL,
+                "valu_instr_per_eval": valu_ops_per_eval,
+                "interior_class_fraction_of_executed_evals": evals_interior / max(1.0, evals_per_launch),
                 "hbm": {"algorithmic_bytes_per_launch": k6_bytes, "achieved_GBps": achieved, "peak_GBps": HBM_PEAK_GBPS,
                         "frac": achieved / HBM_PEAK_GBPS,
                         "whole_path_GBps": fps / max(1, world) * bytes_per_frame / 1e9,
                         "whole_path_frac": fps / max(1, world) * bytes_per_frame / 1e9 / HBM_PEAK_GBPS},
                 "note": "k6_grid_cost is VALU-bound by construction (points staged once in LDS, ~1e8 nominal "
-                        "point-candidate evaluations per frame, no MFMA): achieved = executed evaluations x 27.5 VALU "
-                        "instructions / launch duration.  launch = the K6 stage of one batch (seed + refinement + full "
+                        "point-candidate evaluations per frame, no MFMA): achieved = executed evaluations x their VALU "
+                        "instructions (29.7 border-class, 18.7 interior-class, loop bodies incl. their bound test) / launch duration.  launch = the K6 stage of one batch (seed + refinement + full "
                         "launch), timed by HIP events on the library's stream (the wait for the previous batch's full pass "
                         "between the refinement and the full launch is excluded).  `hbm` holds the algorithmic-bytes "
                         "fraction of the 8 TB/s peak that BASELINE.json asks for",

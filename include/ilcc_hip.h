@@ -163,6 +163,8 @@ typedef struct ilcc_timing {
   double grid_cost_ms_sum;       /* their summed HIP-event duration, ms */
   uint64_t grid_cost_evals_sum;  /* point x candidate evaluations they performed (both phases = 1) */
   uint64_t grid_cost_evals_nominal_sum; /* evaluations an unpruned exhaustive pass needs */
+  uint64_t grid_cost_evals_interior_sum; /* part of grid_cost_evals_sum spent on points that cannot leave the board under any
+                                            translation of the grid (cheaper term: no out-of-board logic) */
 } ilcc_timing;
 
 int32_t ilcc_abi_version(void);

@@ -100,6 +100,7 @@ class Timing(C.Structure):
         ("grid_cost_ms_sum", C.c_double),
         ("grid_cost_evals_sum", C.c_uint64),
         ("grid_cost_evals_nominal_sum", C.c_uint64),
+        ("grid_cost_evals_interior_sum", C.c_uint64),
     ]
 
 

@@ -279,10 +279,10 @@ int32_t alloc_slot(ilcc_handle* h, Slot& sl) {
   ALLOC(sl.d_bound, sizeof(uint32_t) * mf);
   ALLOC(sl.d_tie_count, sizeof(uint32_t) * mf);
   ALLOC(sl.d_tie_list, sizeof(GridPartial) * (size_t)mf * kTieCap);
-  ALLOC(sl.d_iters, sizeof(unsigned long long) * kIterSlots);
+  ALLOC(sl.d_iters, sizeof(unsigned long long) * 2 * kIterSlots);
 #undef ALLOC
   HIP_TRY(h, hipHostMalloc((void**)&sl.h_res, sizeof(ilcc_result) * mf, hipHostMallocDefault));
-  HIP_TRY(h, hipHostMalloc((void**)&sl.h_iters, sizeof(unsigned long long) * kIterSlots, hipHostMallocDefault));
+  HIP_TRY(h, hipHostMalloc((void**)&sl.h_iters, sizeof(unsigned long long) * 2 * kIterSlots, hipHostMallocDefault));
   sl.allocated = true;
   return ILCC_OK;
 }
@@ -464,7 +464,7 @@ int32_t enqueue(ilcc_handle* h, int si, const float4* d_xyzi, const uint64_t* of
   HIP_TRY(h, hipEventRecord(sl.ev[6], s));
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipMemcpyAsync(sl.h_res, sl.d_res, sizeof(ilcc_result) * n_frames, hipMemcpyDeviceToHost, s));
-  HIP_TRY(h, hipMemcpyAsync(sl.h_iters, sl.d_iters, sizeof(unsigned long long) * kIterSlots, hipMemcpyDeviceToHost, s));
+  HIP_TRY(h, hipMemcpyAsync(sl.h_iters, sl.d_iters, sizeof(unsigned long long) * 2 * kIterSlots, hipMemcpyDeviceToHost, s));
   sl.busy = true;
   return ILCC_OK;
 }
@@ -511,8 +511,13 @@ int32_t finish(ilcc_handle* h, int si, ilcc_result* out, float* d_records = null
     t.grid_cost_evals_nominal_sum += evals;
     // (both colour phases of a (point, candidate) pair = 1 evaluation)
     unsigned long long iters = 0;
-    for (int k = 0; k < kIterSlots; ++k) iters += sl.h_iters[k];
+    unsigned long long iters_in = 0;
+    for (int k = 0; k < kIterSlots; ++k) {
+      iters += sl.h_iters[k];
+      iters_in += sl.h_iters[kIterSlots + k];
+    }
     t.grid_cost_evals_sum += (uint64_t)iters * grid_cost_evals_per_count();
+    t.grid_cost_evals_interior_sum += (uint64_t)iters_in * grid_cost_evals_per_count();
   }
   // adapt the K6 LDS staging size to the labelled-point counts actually seen (later calls)
   uint32_t want = 1024;

@@ -96,6 +96,26 @@ __device__ __forceinline__ void accumulate(const PointTerms& p, float ay, float 
   A1 = fmaf(T, w1, A1);
 }
 
+// The same term for a point that is IN the board under every translation of this workgroup's tables (see the staging
+// below): the out-of-board half of accumulate<> -- 10 of its 27.5 instructions -- is dead for it.  Same operations on
+// the in-board side, so the value is bit-identical to what accumulate<> computes for such a point.
+__device__ __forceinline__ void accumulate_interior(const PointTerms& p, float ay, float az, float delta2, float& A0, float& A1) {
+  const float i = p.pi + ay, j = p.pj + az;
+  const float fi = floorf(i), fj = floorf(j);
+  const float ai = (i - fi) - 0.5f, aj = (j - fj) - 0.5f;
+  const float R = fmaf(-2.f, fabsf(ai) + fabsf(aj), 2.f);
+  const float mf = __builtin_amdgcn_fractf(fmaf(0.5f, fi + fj, p.hw));
+  const float nmf = 0.5f - mf;
+  const float Q = fminf(R, delta2);
+  const float T = Q * fmaf(-0.5f, Q, R);
+  A0 = fmaf(T, mf, A0);
+  A1 = fmaf(T, nmf, A1);
+}
+
+#ifndef ILCC_K6_SPLIT
+#define ILCC_K6_SPLIT 1   // (A/B builds: 0 = one class of points, every point takes the full accumulate<>)
+#endif
+
 __device__ __forceinline__ uint32_t gcd_u32(uint32_t a, uint32_t b) {
   while (b) {
     const uint32_t t = a % b;
@@ -126,7 +146,7 @@ __device__ __forceinline__ Best seed_argmin(const Ctx& c, uint32_t f, int lane) 
 
 template <bool OOB, bool VOLUME, bool LDS_POINTS, bool PRUNE>
 __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, float2* s_ij, float* s_hw, Best* s_best,
-                                               uint32_t* s_iters, float* s_ay, float* s_az) {
+                                               uint32_t* s_iters, uint32_t* s_cnt, float* s_ay, float* s_az) {
   const uint32_t f = blockIdx.y;
   uint32_t k = blockIdx.x;   // theta index (refinement pass: set from the seed below)
   const ilcc_result* r = &c.res[f];
@@ -183,14 +203,63 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
     while (gcd_u32(S, M) != 1u) S += 2u;
     if (S >= M) S = 1;
   }
+  // Staged points come in two classes.  INTERIOR: in the board under EVERY translation of the tables (checked with
+  // accumulate<>'s own fp32 expressions at the four extreme translations; |i - W/2| - W/2 is V-shaped in i and every
+  // operation is monotone, so the extremes decide for all values in between) -> accumulate_interior.  BORDER: the rest.
+  // Interior points fill [0, Mi) in walk order, border points fill [Mi, M) in reverse walk order (a stable partition by
+  // ballot ranks, chunk by chunk: deterministic, so are the fp32 sums).
+  uint32_t Mi = 0;
   if (LDS_POINTS) {
-    for (uint32_t sl = threadIdx.x; sl < M; sl += kGridThreads) {
-      const uint32_t i = (uint32_t)(((uint64_t)sl * S) % M);
-      const float2 v = gyz[i];
-      // Rx(theta) on (0,y,z), already divided by g (Optimization.h:37-46)
-      s_ij[sl] = make_float2(fmaf(-sth, v.y, cth * v.x), fmaf(cth, v.y, sth * v.x));
-      s_hw[sl] = glab[i] ? 0.5f : 0.f;
+    const float Wh_ = 0.5f * (float)c.p.board_w, Hh_ = 0.5f * (float)c.p.board_h;
+    const float ay_lo = c.ay[0], ay_hi = c.ay[c.p.n_ty - 1], az_lo = c.az[0], az_hi = c.az[c.p.n_tz - 1];
+    uint32_t base_in = 0, base_out = 0;
+    for (uint32_t c0 = 0; c0 < M; c0 += kGridThreads) {
+      const uint32_t sl = c0 + threadIdx.x;
+      const bool valid = sl < M;
+      float2 ij = make_float2(0.f, 0.f);
+      float hw = 0.f;
+      bool interior = false;
+      if (valid) {
+        const uint32_t i = (uint32_t)(((uint64_t)sl * S) % M);
+        const float2 v = gyz[i];
+        // Rx(theta) on (0,y,z), already divided by g (Optimization.h:37-46)
+        ij = make_float2(fmaf(-sth, v.y, cth * v.x), fmaf(cth, v.y, sth * v.x));
+        hw = glab[i] ? 0.5f : 0.f;
+        if (ILCC_K6_SPLIT) {
+          const float u0 = fabsf((ij.x + ay_lo) - Wh_) - Wh_, u1 = fabsf((ij.x + ay_hi) - Wh_) - Wh_;
+          const float w0 = fabsf((ij.y + az_lo) - Hh_) - Hh_, w1 = fabsf((ij.y + az_hi) - Hh_) - Hh_;
+          interior = fmaxf(fmaxf(u0, u1), fmaxf(w0, w1)) < 0.f;
+        }
+      }
+      const unsigned long long m_in = __ballot(valid && interior), m_out = __ballot(valid && !interior);
+      const unsigned long long below = (1ull << lane) - 1ull;
+      if (lane == 0) {
+        s_iters[wid] = (uint32_t)__popcll(m_in);          // (s_iters / s_cnt are free until the epilogue)
+        s_cnt[wid] = (uint32_t)__popcll(m_out);
+      }
+      __syncthreads();
+      uint32_t pre_in = 0, pre_out = 0, tot_in = 0, tot_out = 0;
+#pragma unroll
+      for (int w = 0; w < kGridThreads / ILCC_WAVE; ++w) {
+        const uint32_t a = s_iters[w], b = s_cnt[w];
+        if (w < wid) {
+          pre_in += a;
+          pre_out += b;
+        }
+        tot_in += a;
+        tot_out += b;
+      }
+      if (valid) {
+        const uint32_t at = interior ? base_in + pre_in + (uint32_t)__popcll(m_in & below)
+                                     : M - 1u - (base_out + pre_out + (uint32_t)__popcll(m_out & below));
+        s_ij[at] = ij;
+        s_hw[at] = hw;
+      }
+      base_in += tot_in;
+      base_out += tot_out;
+      __syncthreads();
     }
+    Mi = (uint32_t)__builtin_amdgcn_readfirstlane((int)base_in);
   }
   // (ty, tz) tables in LDS: a cut-short tile lasts about as long as one L2 round trip, so its
   // prologue must not wait for global loads
@@ -207,7 +276,7 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
   uint32_t* bound = c.grid_bound + f;
   float shared_bound = __builtin_inff();   // what this wavefront last published
   uint32_t gb_bits = PRUNE ? __hip_atomic_load(bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0x7f800000u;
-  uint32_t pts_done = 0;
+  uint32_t pts_done = 0, pts_in = 0;   // walk positions executed by this wavefront (all / interior class)
   float* vol = VOLUME ? volume + (uint64_t)f * (uint64_t)c.p.n_th * n_ty * n_tz * 2u : nullptr;
   const int my_s = lane & (kSlices - 1), my_c = lane >> 2;
   const int my_a = my_c >> 2, my_b = my_c & 3;
@@ -261,44 +330,129 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
         return t;
       }
     };
-    PointTerms nxt[kUnroll];   // the next block's points are in flight while this block is evaluated
-    if (kStep <= M) {
+    if constexpr (LDS_POINTS) {
+      // Two interleaved walks: 12 interior points (cheap term), test, 12 border points (full term), test, ... --
+      // interleaved so that every prefix still samples both the pattern (interior) and the outline (border) of the board
+      uint32_t pin = 0, pbd = Mi;            // next walk position of each class
+      uint32_t since_refresh = 0;
+      PointTerms nin[kUnroll], nbd[kUnroll];
+      if (kStep <= Mi) {
 #pragma unroll
-      for (int u = 0; u < kUnroll; ++u) nxt[u] = fetch(u * kSlices + my_s);
-    }
-    for (; pos + kStep <= M; pos += kStep) {
-      PointTerms pt[kUnroll];
-#pragma unroll
-      for (int u = 0; u < kUnroll; ++u) pt[u] = nxt[u];
-      if (pos + 2 * kStep <= M) {
-#pragma unroll
-        for (int u = 0; u < kUnroll; ++u) nxt[u] = fetch(pos + kStep + u * kSlices + my_s);
+        for (int u = 0; u < kUnroll; ++u) nin[u] = fetch(u * kSlices + my_s);
       }
+      if (Mi + kStep <= M) {
 #pragma unroll
-      for (int u = 0; u < kUnroll; ++u) accumulate<OOB>(pt[u], ay, az, Wh, Hh, delta2, A0, A1);
-      if (PRUNE) {
+        for (int u = 0; u < kUnroll; ++u) nbd[u] = fetch(Mi + u * kSlices + my_s);
+      }
+      auto beaten = [&]() -> bool {          // every candidate of the tile provably loses
         const float part = fminf(quad_sum(A0), quad_sum(A1));
-        if (!__any(owner && !(part > lim2))) {
-          pruned = true;
-          pos += kStep;
-          break;
-        }
-        if (((pos + kStep) & (kBoundRefresh - 1)) == 0) {
+        return !__any(owner && !(part > lim2));
+      };
+      auto refresh = [&]() {
+        since_refresh += kStep;
+        if (since_refresh >= (uint32_t)kBoundRefresh) {
+          since_refresh = 0;
           lim2 = 2.f * (1.f + kTieEps) * fminf(__uint_as_float(gb_bits), best.cost);
           gb_bits = __hip_atomic_load(bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next refresh
         }
-      }
-    }
-    if (!(PRUNE && pruned)) {
-      if (!LDS_POINTS && M) idx = (uint32_t)(((uint64_t)(pos + my_s) * S) % M);
-      for (; pos < M; pos += kSlices) {   // tail (< 12 points): one point per lane and trip, lanes past the end idle
-        const uint32_t at = pos + my_s;
-        if (at < M) {
-          const PointTerms p1 = fetch(at);
-          accumulate<OOB>(p1, ay, az, Wh, Hh, delta2, A0, A1);
+      };
+      for (;;) {
+        const bool more_in = pin + kStep <= Mi, more_bd = pbd + kStep <= M;
+        if (!more_in && !more_bd) break;
+        if (more_in) {
+          PointTerms pt[kUnroll];
+#pragma unroll
+          for (int u = 0; u < kUnroll; ++u) pt[u] = nin[u];
+          if (pin + 2 * kStep <= Mi) {
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) nin[u] = fetch(pin + kStep + u * kSlices + my_s);
+          }
+#pragma unroll
+          for (int u = 0; u < kUnroll; ++u) accumulate_interior(pt[u], ay, az, delta2, A0, A1);
+          pin += kStep;
+          if (PRUNE) {
+            if (beaten()) {
+              pruned = true;
+              break;
+            }
+            refresh();
+          }
+        }
+        if (more_bd) {
+          PointTerms pt[kUnroll];
+#pragma unroll
+          for (int u = 0; u < kUnroll; ++u) pt[u] = nbd[u];
+          if (pbd + 2 * kStep <= M) {
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) nbd[u] = fetch(pbd + kStep + u * kSlices + my_s);
+          }
+#pragma unroll
+          for (int u = 0; u < kUnroll; ++u) accumulate<OOB>(pt[u], ay, az, Wh, Hh, delta2, A0, A1);
+          pbd += kStep;
+          if (PRUNE) {
+            if (beaten()) {
+              pruned = true;
+              break;
+            }
+            refresh();
+          }
         }
       }
-      pos = M;
+      if (!(PRUNE && pruned)) {   // tails (< 12 points per class): one point per lane and trip, lanes past the end idle
+        for (; pin < Mi; pin += kSlices) {
+          const uint32_t at = pin + my_s;
+          if (at < Mi) accumulate_interior(fetch(at), ay, az, delta2, A0, A1);
+        }
+        for (; pbd < M; pbd += kSlices) {
+          const uint32_t at = pbd + my_s;
+          if (at < M) accumulate<OOB>(fetch(at), ay, az, Wh, Hh, delta2, A0, A1);
+        }
+        pos = M;
+        pts_in += Mi;
+      } else {
+        pos = pin + (pbd - Mi);
+        pts_in += pin;
+      }
+    } else {
+      PointTerms nxt[kUnroll];   // the next block's points are in flight while this block is evaluated
+      if (kStep <= M) {
+  #pragma unroll
+        for (int u = 0; u < kUnroll; ++u) nxt[u] = fetch(u * kSlices + my_s);
+      }
+      for (; pos + kStep <= M; pos += kStep) {
+        PointTerms pt[kUnroll];
+  #pragma unroll
+        for (int u = 0; u < kUnroll; ++u) pt[u] = nxt[u];
+        if (pos + 2 * kStep <= M) {
+  #pragma unroll
+          for (int u = 0; u < kUnroll; ++u) nxt[u] = fetch(pos + kStep + u * kSlices + my_s);
+        }
+  #pragma unroll
+        for (int u = 0; u < kUnroll; ++u) accumulate<OOB>(pt[u], ay, az, Wh, Hh, delta2, A0, A1);
+        if (PRUNE) {
+          const float part = fminf(quad_sum(A0), quad_sum(A1));
+          if (!__any(owner && !(part > lim2))) {
+            pruned = true;
+            pos += kStep;
+            break;
+          }
+          if (((pos + kStep) & (kBoundRefresh - 1)) == 0) {
+            lim2 = 2.f * (1.f + kTieEps) * fminf(__uint_as_float(gb_bits), best.cost);
+            gb_bits = __hip_atomic_load(bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next refresh
+          }
+        }
+      }
+      if (!(PRUNE && pruned)) {
+        if (!LDS_POINTS && M) idx = (uint32_t)(((uint64_t)(pos + my_s) * S) % M);
+        for (; pos < M; pos += kSlices) {   // tail (< 12 points): one point per lane and trip, lanes past the end idle
+          const uint32_t at = pos + my_s;
+          if (at < M) {
+            const PointTerms p1 = fetch(at);
+            accumulate<OOB>(p1, ay, az, Wh, Hh, delta2, A0, A1);
+          }
+        }
+        pos = M;
+      }
     }
     pts_done += pos;
     if (PRUNE && pruned) continue;
@@ -356,12 +510,17 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
   if (lane == 0) {
     s_best[wid] = best;
     s_iters[wid] = pts_done;
+    s_cnt[wid] = pts_in;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    uint32_t it_sum = 0;
-    for (int w = 0; w < kGridThreads / ILCC_WAVE; ++w) it_sum += s_iters[w];
+    uint32_t it_sum = 0, in_sum = 0;
+    for (int w = 0; w < kGridThreads / ILCC_WAVE; ++w) {
+      it_sum += s_iters[w];
+      in_sum += s_cnt[w];
+    }
     atomicAdd(c.grid_iters + (f & (kIterSlots - 1)), (unsigned long long)it_sum);   // spread over 64 words
+    atomicAdd(c.grid_iters + kIterSlots + (f & (kIterSlots - 1)), (unsigned long long)in_sum);
     Best b = s_best[0];
     for (int w = 1; w < kGridThreads / ILCC_WAVE; ++w)
       if (better(s_best[w].cost, s_best[w].d2, s_best[w].flat, b)) b = s_best[w];
@@ -378,15 +537,16 @@ __global__ __launch_bounds__(kGridThreads) void k6_grid_cost(Ctx c, float* volum
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ Best s_best[kGridThreads / ILCC_WAVE];
   __shared__ uint32_t s_iters[kGridThreads / ILCC_WAVE];
+  __shared__ uint32_t s_cnt[kGridThreads / ILCC_WAVE];
   float2* s_ij = reinterpret_cast<float2*>(smem);
   float* s_hw = reinterpret_cast<float*>(smem + sizeof(float2) * (size_t)c.grid_lds_points);
   float* s_ay = s_hw + c.grid_lds_points;   // n_ty floats
   float* s_az = s_ay + c.p.n_ty;            // n_tz floats
   const uint32_t M = c.n_lab[blockIdx.y];
   if (M <= c.grid_lds_points)
-    grid_cost_body<OOB, VOLUME, true, PRUNE>(c, volume, s_ij, s_hw, s_best, s_iters, s_ay, s_az);
+    grid_cost_body<OOB, VOLUME, true, PRUNE>(c, volume, s_ij, s_hw, s_best, s_iters, s_cnt, s_ay, s_az);
   else
-    grid_cost_body<OOB, VOLUME, false, PRUNE>(c, volume, s_ij, s_hw, s_best, s_iters, s_ay, s_az);
+    grid_cost_body<OOB, VOLUME, false, PRUNE>(c, volume, s_ij, s_hw, s_best, s_iters, s_cnt, s_ay, s_az);
 }
 
 // executed-work unit of Ctx::grid_iters: one count = one point x one 16-candidate tile
