@@ -57,13 +57,13 @@ K6_HBM_TRAFFIC_BYTES_128 = 26512728   # profiles/r02g_pmc_summary.csv: 6236513 +
 # VALU issue peak: 256 CU x 4 SIMD x 32 lanes x 2.4 GHz = 78.6 T lane-instructions/s
 # (= the 157.3 TFLOP/s fp32 vector peak of MI355X_MICROARCH.md when every instruction is an FMA)
 VALU_ISSUE_PEAK_T = 78.6
-# VALU instructions per (point, candidate) evaluation of k6_grid_cost (both phases), counted from the gfx950 ISA of
-# the inner loop bodies (DESIGN.md "K6"; same convention as round 1's 27.5 = 110 per 4-point block: the block's bound
-# test is included, tile prologues / epilogues / staging are not): 89 per 3-point block of border-class points
-# (out-of-board logic included), 56 per 3-point block of interior-class points (they cannot leave the board under any
-# translation of the grid).  The library counts the executed evaluations of both classes.
-K6_VALU_OPS_BORDER = 89.0 / 3.0
-K6_VALU_OPS_INTERIOR = 56.0 / 3.0
+# VALU instructions of ONE (point, candidate) evaluation of k6_grid_cost (both colour phases), counted in the gfx950
+# ISA of the term itself (DESIGN.md "K6"): 26 for a border-class point (out-of-board logic included), 15 for an
+# interior-class point (it cannot leave the board under any translation of the grid).  Bound tests, tile prologues,
+# address arithmetic and staging are NOT credited (round 1's 27.5 was the one-class loop body including its share of the
+# bound test).  The library counts the executed evaluations of both classes.
+K6_VALU_OPS_BORDER = 26.0
+K6_VALU_OPS_INTERIOR = 15.0
 
 
 def _gen_chunk(args):
@@ -351,6 +351,7 @@ def main():
                 "evals_nominal_per_launch": evals_nominal,
                 "executed_fraction": evals_per_launch / evals_nominal if evals_nominal else None,
                 "valu_instr_per_eval": valu_ops_per_eval,
+                "evals_executed_per_s": evals_per_launch / (k6_ms * 1e-3),
                 "interior_class_fraction_of_executed_evals": evals_interior / max(1.0, evals_per_launch),
                 "hbm": {"algorithmic_bytes_per_launch": k6_bytes, "achieved_GBps": achieved, "peak_GBps": HBM_PEAK_GBPS,
                         "frac": achieved / HBM_PEAK_GBPS,
@@ -358,7 +359,7 @@ def main():
                         "whole_path_frac": fps / max(1, world) * bytes_per_frame / 1e9 / HBM_PEAK_GBPS},
                 "note": "k6_grid_cost is VALU-bound by construction (points staged once in LDS, ~1e8 nominal "
                         "point-candidate evaluations per frame, no MFMA): achieved = executed evaluations x their VALU "
-                        "instructions (29.7 border-class, 18.7 interior-class, loop bodies incl. their bound test) / launch duration.  launch = the K6 stage of one batch (seed + refinement + full "
+                        "instructions (26 border-class, 15 interior-class: the term only -- bound tests, prologues and address arithmetic are not credited) / launch duration.  launch = the K6 stage of one batch (seed + refinement + full "
                         "launch), timed by HIP events on the library's stream (the wait for the previous batch's full pass "
                         "between the refinement and the full launch is excluded).  `hbm` holds the algorithmic-bytes "
                         "fraction of the 8 TB/s peak that BASELINE.json asks for",

@@ -41,9 +41,10 @@ namespace ilcc {
 constexpr int kTile = 4;          // 4 x 4 candidates per wavefront; lane = ((a << 2) | b) << 2 | slice
 constexpr int kSlices = 4;        // lanes (one quad) sharing a candidate, each on every 4th point of the walk
 #ifndef ILCC_K6_UNROLL
-#define ILCC_K6_UNROLL 3
+#define ILCC_K6_UNROLL 2
 #endif
-constexpr int kUnroll = ILCC_K6_UNROLL;        // points per lane between bound tests (3 -> every 12 points of the walk; measured 2: 179 k, 3: 181 k, 4: 178 k, 6: 167 k frames/s)
+constexpr int kUnroll = ILCC_K6_UNROLL;        // points per lane and block (round 1, one class of points: 2: 179 k, 3: 181 k, 4: 178 k, 6: 167 k
+                                               // frames/s; round 2, two classes, test after every border block only: 2: 245.6 k, 3: 238 k, 4: 227 k)
 constexpr int kStep = kSlices * kUnroll;
 constexpr int kBoundRefresh = ILCC_K6_BOUND_REFRESH; // points between reloads of the frame's shared bound
 
@@ -370,7 +371,11 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
 #pragma unroll
           for (int u = 0; u < kUnroll; ++u) accumulate_interior(pt[u], ay, az, delta2, A0, A1);
           pin += kStep;
-          if (PRUNE) {
+#ifndef ILCC_K6_TEST_INTERIOR
+#define ILCC_K6_TEST_INTERIOR 0   // 0: while border points remain the bound test follows the border block only (8 interior + 8 border
+                                  // points between tests); 1: after every block.  Measured 0: 245.6 k, 1: 239.4 k frames/s
+#endif
+          if (PRUNE && (ILCC_K6_TEST_INTERIOR || !more_bd)) {
             if (beaten()) {
               pruned = true;
               break;
