@@ -164,7 +164,13 @@ int32_t upload_tables(ilcc_handle* h) {
   // pass then evaluates everything around its argmin (theta +- half a seed stride, 8 x 8 translations), which
   // on the synthetic VLP-16 set yields the exact grid minimum as the bound in 46 of 46 frames (seed alone:
   // 3-20 x the minimum).  Measured on the 128-frame batch (K6 ms): translation stride 2: 1.05, 4: 0.91, 5: 0.83.
-  h->seed_stride_th = std::max(2, p.n_th / 5);
+#ifndef ILCC_SEED_THETAS
+#define ILCC_SEED_THETAS 5
+#endif
+#ifndef ILCC_REFINE_RADIUS_DIV
+#define ILCC_REFINE_RADIUS_DIV 3   // refinement pass: theta radius = seed stride / 3 (measured in the pipelined bench: /2: 245.3 k, /3: 248.9 k, /4: 245.6 k frames/s)
+#endif
+  h->seed_stride_th = std::max(2, p.n_th / ILCC_SEED_THETAS);
   h->seed_stride_t = std::max(1, std::min(p.n_ty, p.n_tz) / 8);
   std::vector<float> cth2, sth2, ay2, az2;
   for (int k = h->seed_stride_th / 2; k < p.n_th; k += h->seed_stride_th) {
@@ -430,7 +436,7 @@ int32_t enqueue(ilcc_handle* h, int si, const float4* d_xyzi, const uint64_t* of
       {
         // refinement pass: all candidates around the seed argmin (theta +- half a seed stride, 8 x 8 translations)
         Ctx refine = full;
-        refine.refine_radius_th = std::max(1, h->seed_stride_th / 2);
+        refine.refine_radius_th = std::max(1, h->seed_stride_th / ILCC_REFINE_RADIUS_DIV);
         refine.grid_blocks = std::min((uint32_t)(2 * refine.refine_radius_th + 1), h->max_theta);
         refine.partial = sl.d_partial3;
         launch_grid_cost(refine, s, /*use_oob=*/1, nullptr, true);

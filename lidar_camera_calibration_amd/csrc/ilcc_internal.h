@@ -14,7 +14,10 @@ namespace ilcc {
 // block sizes (multiples of the 64-lane wavefront)
 constexpr int kCropThreads = 256;      // K1
 constexpr int kCropChunk = 4096;       // points per K1 block
-constexpr int kFrameThreads = 1024;    // K2: one workgroup per frame
+#ifndef ILCC_K2_THREADS
+#define ILCC_K2_THREADS 1024
+#endif
+constexpr int kFrameThreads = ILCC_K2_THREADS;    // K2: one workgroup per frame
 #ifndef ILCC_K3_THREADS
 #define ILCC_K3_THREADS 256    // measured in the pipelined bench: 1024: 229.6 k, 512: 230.4 k, 256: 235.2 k frames/s
 #endif
