@@ -53,7 +53,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0                              # MI355X_MICROARCH.md: 8 TB/s spec
 # HBM bytes of the K6 stage (seed + refinement + full launch) for one 128-frame config-2 batch, from the PMC
 # passes committed under profiles/ (see profiles/README.md)
-K6_HBM_TRAFFIC_BYTES_128 = 26512728   # profiles/r02g_pmc_summary.csv: 6236513 + 10079003 + 10197212
+K6_HBM_TRAFFIC_BYTES_128 = 26937350   # profiles/r02i_pmc_summary.csv: 6332732 + 10078681 + 10525937
 # VALU issue peak: 256 CU x 4 SIMD x 32 lanes x 2.4 GHz = 78.6 T lane-instructions/s
 # (= the 157.3 TFLOP/s fp32 vector peak of MI355X_MICROARCH.md when every instruction is an FMA)
 VALU_ISSUE_PEAK_T = 78.6
