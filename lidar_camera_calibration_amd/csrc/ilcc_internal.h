@@ -55,7 +55,10 @@ constexpr int kIterSlots = 64;         // K6 executed-iteration counters (spread
 #endif
 constexpr int kClusterAllPairsMax = ILCC_K2_ALLPAIRS_MAX;   // K2: above this many points the spatial hash finds neighbours
 constexpr int kClusterHashSize = 1 << 17;    // K2: hash buckets per frame (global memory)
-constexpr int kClusterLdsParents = 16384;  // K2 union-find parents kept in LDS (64 KiB)
+#ifndef ILCC_K2_LDS_PARENTS
+#define ILCC_K2_LDS_PARENTS 16384
+#endif
+constexpr int kClusterLdsParents = ILCC_K2_LDS_PARENTS;  // K2 union-find parents kept in LDS (64 KiB)
 
 struct GridPartial {   // per K6 workgroup best candidate
   float cost;

@@ -86,7 +86,10 @@ __device__ __forceinline__ bool nn_less(const NnKey& x, const NnKey& y) {
   return x.d2 < y.d2 || (x.d2 == y.d2 && x.idx < y.idx);
 }
 
-constexpr int kClusterGridMax = 4096;     // <= this many ROI points: cell lists entirely in LDS
+#ifndef ILCC_K2_GRID_MAX
+#define ILCC_K2_GRID_MAX 4096
+#endif
+constexpr int kClusterGridMax = ILCC_K2_GRID_MAX;     // <= this many ROI points: cell lists entirely in LDS
 constexpr int kClusterGridBuckets = 8192;
 constexpr int kClusterCells = 16384;       // direct cell grid of the wave-cooperative search (u16 run ends: 32 KiB)
 

@@ -417,6 +417,12 @@ def test_async_submit_wait_matches_synchronous_calls(frames):
     for t, want in zip(tickets, sync):
         got = [r.corners_array() for r in e.wait(t)]
         assert all(np.array_equal(g, w) for g, w in zip(got, want))
+    # pageable host memory works too (the runtime stages the copy; slower, same results)
+    pageable = [(np.ascontiguousarray(clouds[a:b]), np.ascontiguousarray(clicks[a:b])) for a, b in sets[:2]]
+    tickets = [e.submit_host(pc.ctypes.data, len(pk), 28800, pk.ctypes.data) for pc, pk in pageable]
+    for t, want in zip(tickets, sync[:2]):
+        got = [r.corners_array() for r in e.wait(t)]
+        assert all(np.array_equal(g, w) for g, w in zip(got, want))
     e.close()
 
 
