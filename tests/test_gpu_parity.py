@@ -682,3 +682,24 @@ def test_sparse_wide_roi_takes_the_hashed_lds_cell_lists(ob):
     assert r.n_cluster >= 100 and len(got) == r.n_cluster
     if r.status in (N.OK, N.AMBIGUOUS):
         assert np.abs(r.corners_array() - ob.result_corners(o)).max() < 1e-6
+
+
+def test_parameter_validation_and_second_handle():
+    """params_ok rejects what the kernels cannot run (a (ty, tz) table pair beyond the LDS the grid kernel may
+    ask for used to fail at launch and return stale data with ILCC_OK); a second handle in the same process works."""
+    from lidar_camera_calibration_amd import IlccError
+    e = LidarCornersBatch(2, 28800, N.default_params())
+    for field, value in (("refine_div", 3), ("refine_div", 128), ("refine_max_rounds", -1), ("online_cluster_tol", 0.0),
+                         ("n_ty", 5000), ("grid_prune", 2), ("board_w", 9)):
+        p = N.default_params()
+        setattr(p, field, value)
+        with pytest.raises(IlccError):   # (n_ty = 5000: an axis is limited to 4096 candidates, so that n_ty + n_tz always fits the LDS
+            # the grid kernel is allowed to ask for)
+            e.set_params(p)
+    e2 = LidarCornersBatch(2, 28800, N.default_params())       # second handle, same device
+    clouds, clicks, _, _ = synth.make_batch(2, fixture_poses=True)
+    a = [r.corners_array() for r in e.extract(clouds, clicks)]
+    b = [r.corners_array() for r in e2.extract(clouds, clicks)]
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    e.close()
+    e2.close()
