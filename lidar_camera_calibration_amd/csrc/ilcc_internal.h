@@ -113,7 +113,7 @@ struct Ctx {
   uint32_t grid_lds_points;  // K6 points staged in LDS per workgroup (multiple of 64)
   uint32_t* grid_bound;      // per frame: float bits of the best complete candidate cost so far (K6 pruning)
   // near ties: candidates of the full pass whose fp32 cost is within kTieEps of the bound at the time they
-  // complete; K7a recounts them in fp64 so that the argmin is the fp64 oracle's even when fp32 cannot order them
+  // complete; K7r recounts them on the oracle's fixed-point cost so that the argmin is the oracle's even when fp32 cannot order them
   uint32_t* tie_count;       // per frame (nullptr: this launch does not collect)
   uint32_t* tie_count_all;   // the same array, always set: K1 resets it
   GridPartial* tie_list;     // n_frames x kTieCap: cost (fp32), d2, flat

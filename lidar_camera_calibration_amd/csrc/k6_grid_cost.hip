@@ -10,7 +10,8 @@
 // 4 x 4 (ty, tz) candidates; lane = candidate * 4 + slice: the four lanes of a quad evaluate the SAME
 // candidate on four interleaved quarters of the point walk and keep private running sums (both
 // colour phases).  The branch-and-bound test therefore needs only a quad reduction -- four DPP adds --
-// and runs every 12 points: a tile stops the moment each of its candidates is provably beaten.
+// and runs every 16 points (8 interior-class + 8 border-class, see the staging): a tile stops the moment each of its
+// candidates is provably beaten.
 // History of this mapping, measured on the 128-frame batch:
 //  * lanes = points, 4 x 4 candidates in registers (round-1 first design): 14.5 VALU per evaluation
 //    thanks to separable i/j terms, but every test needed a ~130-instruction transposed reduction over
@@ -29,8 +30,9 @@
 //   1/2 rho(r^2) = q (r - q/2),  q = min(r, delta)                     (HuberLoss(0.1), :137)
 // The cell is white iff topleftWhite xor ((floor i + floor j) odd)  (:53-61), so a mismatch
 // under phase 0 is a match under phase 1: both phases come out of one pass.
-// Arithmetic is carried in doubled units (R = 2r, sums = 2 x cost; powers of two, exact): 30 VALU
-// instructions per point and lane with the out-of-board term, 26 without.
+// Arithmetic is carried in doubled units (R = 2r, sums = 2 x cost; powers of two, exact): 26 VALU
+// instructions per point and lane for a border-class point (out-of-board logic included), 15 for an interior-class
+// point (it is in the board under every translation of the grid: accumulate_interior).
 #include "ilcc_internal.h"
 
 namespace ilcc {
@@ -319,7 +321,7 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
     // slightly stale bound only delays a cut): this tile starts with the word loaded during the previous
     // one and issues the load for the next refresh right away
     // sums are 2 x cost.  The test keeps everything within kTieEps of the bound alive: fp32 sums cannot order
-    // such candidates reliably, K7a recounts them in fp64
+    // such candidates reliably, K7r re-orders them on exact fixed-point sums
     float lim2 = 2.f * (1.f + kTieEps) * fminf(__uint_as_float(gb_bits), best.cost);
     if (PRUNE) gb_bits = __hip_atomic_load(bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // lane's points: walk positions my_s, my_s + 4, ...  (LDS_POINTS = false: point index (pos * S) mod M)
@@ -340,7 +342,7 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
       }
     };
     if constexpr (LDS_POINTS) {
-      // Two interleaved walks: 12 interior points (cheap term), test, 12 border points (full term), test, ... --
+      // Two interleaved walks: 8 interior points (cheap term), 8 border points (full term), test, ... --
       // interleaved so that every prefix still samples both the pattern (interior) and the outline (border) of the board
       uint32_t pin = pin0, pbd = pbd0;       // next walk position of each class (the pre-pass may have consumed a block of each)
       uint32_t since_refresh = 0;
@@ -411,7 +413,7 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
           }
         }
       }
-      if (!(PRUNE && pruned)) {   // tails (< 12 points per class): one point per lane and trip, lanes past the end idle
+      if (!(PRUNE && pruned)) {   // tails (< 8 points per class): one point per lane and trip, lanes past the end idle
         for (; pin < Mi; pin += kSlices) {
           const uint32_t at = pin + my_s;
           if (at < Mi) accumulate_interior(fetch(at), ay, az, delta2, A0, A1);
