@@ -371,6 +371,7 @@ def main():
         if world == 1 and not args.no_extra_legs:
             out["grid_vs_reference_path_mm"], gpu_ref = reference_mode_leg(N, est, params, dptrs, d_clicks, res, F, B, FS, run,
                                                                             warm, args.steps, synth, gts, board)
+            out["single_frame_latency_ms"] = single_frame_latency(N, params, clouds, clicks, n_points, local_rank)
             if args.config == 2:
                 out["half_resolution_grid_variant"] = half_grid_leg(N, est, params, dptrs, FS, run, warm, args.steps, synth, gts, board)
             if not args.no_cpu_baseline and args.config == 2:
@@ -429,6 +430,30 @@ def reference_mode_leg(N, est, params, dptrs, d_clicks, res_grid, F, B, FS, run,
         },
     }
     return blk, gpu_ref
+
+
+def single_frame_latency(N, params, clouds, clicks, n_points, device):
+    """What the reference's node does per click: ONE frame, host buffers in, corners out (`ilcc_extract`, synchronous,
+    H2D copy and result copy included).  Median of 30 calls after 5 warm-up calls, both solver modes."""
+    import ctypes as C
+    from lidar_camera_calibration_amd import LidarCornersBatch
+    out = {}
+    cloud = np.ascontiguousarray(clouds.reshape(-1, n_points, 4)[0])
+    click = np.ascontiguousarray(clicks.reshape(-1, 3)[0])
+    for name, solver in (("grid", N.SOLVER_GRID), ("reference_local", N.SOLVER_REFERENCE_LOCAL)):
+        p = N.Params()
+        C.memmove(C.byref(p), C.byref(params), C.sizeof(N.Params))
+        p.solver = solver
+        e = LidarCornersBatch(1, n_points, p, device=device)
+        ts = []
+        for k in range(35):
+            t0 = time.perf_counter()
+            e.extract(cloud[None], click[None])
+            ts.append(time.perf_counter() - t0)
+        e.close()
+        out[name] = round(1e3 * float(np.median(ts[5:])), 4)
+    out["what"] = "one frame through ilcc_extract (host in, host out), median of 30 calls; the reference runs this once per rviz click"
+    return out
 
 
 def half_grid_leg(N, est, params, dptrs, FS, run, warm, steps, synth, gts, board):
