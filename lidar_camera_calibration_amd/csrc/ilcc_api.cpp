@@ -77,7 +77,7 @@ struct ilcc_handle {
   int32_t th_lat_lo = 0, th_lat_hi = 0, hop_y = 0, hop_z = 0;
   double* d_solve = nullptr;   // 3 theta_t + 2 (cost, iterations) for the test entries
   RefineOut* d_refine_io = nullptr;
-  uint32_t grid_lds_points = 2048;
+  uint32_t grid_lds_points = 1024;   // grows with the frames seen (finish()); frames above it take the global-memory path
   ilcc_timing timing{};
   std::string err;
 };
@@ -525,9 +525,11 @@ int32_t finish(ilcc_handle* h, int si, ilcc_result* out, float* d_records = null
     t.grid_cost_evals_sum += (uint64_t)iters * grid_cost_evals_per_count();
     t.grid_cost_evals_interior_sum += (uint64_t)iters_in * grid_cost_evals_per_count();
   }
-  // adapt the K6 LDS staging size to the labelled-point counts actually seen (later calls)
-  uint32_t want = 1024;
-  while (want < max_lab && want < (uint32_t)kGridLdsPointsMax) want <<= 1;
+  // adapt the K6 / K7 LDS staging size to the labelled-point counts actually seen (later calls): the largest count so far,
+  // rounded up to 256 points.  (Not to a power of two: 1 781 points -- the largest of the bench frames -- need 21.8 KB per K6
+  // workgroup at 1 792 and 24.9 KB at 2 048: seven instead of six workgroups per CU -- which, the kernel being VALU-bound,
+  // measured no difference: 248.8 k vs 250 k frames/s.)
+  uint32_t want = std::min<uint32_t>((uint32_t)kGridLdsPointsMax, std::max<uint32_t>(1024u, (max_lab + 255u) & ~255u));
   if (want > h->grid_lds_points) h->grid_lds_points = want;
   return ILCC_OK;
 }
