@@ -3,9 +3,9 @@
 
 A "step" is one pass of the whole hot path (K1 crop -> K2 cluster -> K3 RANSAC plane -> K4/K5 plane frame + gray
 zone -> K6 exhaustive (theta,ty,tz) x phase grid cost -> K7r monotone refinement + basin check -> K7b corners) over
-configs[3]'s 1024 synthetic frames PER GPU, fed as 8 DISTINCT batches of 128 frames (configs[1] frames: 16 rings x
+configs[3]'s 1024 synthetic frames PER GPU, fed as 4 DISTINCT batches of 256 frames (configs[1] frames: 16 rings x
 1800 azimuths = 28 800 XYZI points, 7x5-corner board @0.15 m, one random board pose per frame) through the
-library's submit/wait pipeline (up to 4 batches in flight).  The 8 batches are 472 MB of distinct input per GPU --
+library's submit/wait pipeline (up to 4 batches in flight).  The 4 batches are 472 MB of distinct input per GPU --
 more than the 256 MB Infinity Cache -- so K1 reads HBM, not cache.  Inputs are resident in HBM when the timed region
 starts (the bench contract); the same pipeline with every batch starting in pinned HOST memory is timed right
 after and reported as `value_h2d_inclusive` (SURVEY.md 8d counts that copy).  Per-frame result records come back
@@ -51,7 +51,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0                              # MI355X_MICROARCH.md: 8 TB/s spec
-# HBM bytes of the K6 stage (seed + refinement + full launch) for one 128-frame config-2 batch, from the PMC
+# HBM bytes of the K6 stage (seed + refinement + full launch) per 128 config-2 frames, from the PMC
 # passes committed under profiles/ (see profiles/README.md)
 K6_HBM_TRAFFIC_BYTES_128 = 26937350   # profiles/r02i_pmc_summary.csv: 6332732 + 10078681 + 10525937
 # VALU issue peak: 256 CU x 4 SIMD x 32 lanes x 2.4 GHz = 78.6 T lane-instructions/s
@@ -95,8 +95,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", type=int, default=2, choices=(2, 5),
                     help="2: BASELINE configs[1] frames (the headline); 5: configs[4], the dense-cloud fine-grid run")
-    ap.add_argument("--frames-per-batch", type=int, default=0, help="default 128 (config 2) / 16 (config 5)")
-    ap.add_argument("--batches-per-step", type=int, default=8, help="distinct batches per step and GPU")
+    ap.add_argument("--frames-per-batch", type=int, default=0, help="default 256 (config 2) / 64 (config 5)")
+    ap.add_argument("--batches-per-step", type=int, default=0, help="distinct batches per step and GPU: default 4 (config 2) / 2 (config 5)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline time budget (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the H2D-inclusive / reference-mode legs (profiling runs)")
@@ -106,8 +106,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    F = args.frames_per_batch or (128 if args.config == 2 else 16)
-    B = max(1, args.batches_per_step)
+    # batch size measured on one MI355X (1024 frames per step either way): 128: 249 k, 192: 266 k, 256: 275 k, 320: 273 k,
+    # 384: 269 k, 512: 273 k, 1024: 269 k frames/s (config 5: 16: 2.87 k, 32: 3.30 k, 64: 3.54 k) -- 128 per-frame
+    # workgroups fill only half of the 256 CUs
+    F = args.frames_per_batch or (256 if args.config == 2 else 64)
+    B = max(1, args.batches_per_step or (4 if args.config == 2 else 2))
     FS = F * B                                        # frames per step and GPU
 
     # synthetic inputs first (forked workers; nothing has touched the HIP runtime yet).  Weak scaling: every rank
@@ -341,10 +344,10 @@ def main():
                 "peak": VALU_ISSUE_PEAK_T,
                 "unit": "T lane-instr/s",
                 "frac": valu_rate / VALU_ISSUE_PEAK_T,
-                "traffic": K6_HBM_TRAFFIC_BYTES_128 if (F == 128 and args.config == 2) else None,
+                "traffic": K6_HBM_TRAFFIC_BYTES_128 * F // 128 if (F % 128 == 0 and args.config == 2) else None,
                 "traffic_note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (profiles/): "
                                 "(2 x FETCH_SIZE + WRITE_SIZE) x 1024 summed over the stage's three launches "
-                                "(seed, refinement, full pass) for one 128-frame batch",
+                                "(seed, refinement, full pass), measured on a 128-frame batch and scaled to this batch size",
                 "launch_ms": k6_ms,
                 "launches_timed": int(tm.grid_cost_launches),
                 "evals_executed_per_launch": evals_per_launch,
