@@ -118,7 +118,9 @@ def main():
     from lidar_camera_calibration_amd import synth
     t_gen = time.perf_counter()
     cores = os.cpu_count() or 1
-    clouds, clicks, gts = generate(args.config, FS, 0xC0FFEE + rank * FS, max(1, min(16, cores // max(1, min(world, 8)))))
+    # (ILCC_BENCH_GEN_WORKERS=1: no forked workers -- for runs under rocprofv3, whose tool library does not like forks)
+    workers = int(os.environ.get("ILCC_BENCH_GEN_WORKERS", "0")) or max(1, min(16, cores // max(1, min(world, 8))))
+    clouds, clicks, gts = generate(args.config, FS, 0xC0FFEE + rank * FS, workers)
     t_gen = time.perf_counter() - t_gen
 
     import torch

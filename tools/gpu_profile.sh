@@ -6,7 +6,7 @@ mkdir -p $R/gpurun_out
 python tools/dev_batch_timeline.py 1 30 2>/dev/null | tail -1
 python tools/dev_batch_timeline.py 0 30 2>/dev/null | tail -1
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_stats -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra-legs > $R/gpurun_out/prof_${TAG}_bench.json 2> /dev/null
+ILCC_BENCH_GEN_WORKERS=1 timeout 420 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_stats -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra-legs > $R/gpurun_out/prof_${TAG}_bench.json 2> /dev/null
 cd $R
 find gpurun_out/prof_${TAG}_stats -name "*kernel_stats.csv" | head -1 | xargs -I{} sh -c "cp {} gpurun_out/${TAG}_kernel_stats.csv; cut -c1-160 {} | head -16"
 python -c "
