@@ -59,8 +59,10 @@ enum {
 
 /* ilcc_result.flags */
 enum {
-  ILCC_FLAG_TIE_OVERFLOW = 1 /* more than 256 grid candidates within 2e-5 of the minimum: the fixed-point recount of
-                                near ties was skipped and the fp32 argmin (same tie-break) was used */
+  ILCC_FLAG_TIE_OVERFLOW = 1, /* more than 256 grid candidates within 2e-5 of the minimum: the fixed-point recount of
+                                 near ties was skipped and the fp32 argmin (same tie-break) was used */
+  ILCC_FLAG_REFINE_CAPPED = 2 /* a pattern search stopped at refine_max_rounds before its stride reached the finest lattice:
+                                 theta_t is a valid (cheaper-than-start) point but not a lattice minimum */
 };
 
 /* how (theta, ty, tz) is found */

@@ -17,7 +17,7 @@ MAX_CORNERS = 256
 
 OK, NO_ROI_POINTS, NO_CLUSTER, NO_PLANE, DEGENERATE_HIST, TOO_FEW_POINTS, BAD_ARGUMENT, CAPACITY, \
     HIP_ERROR, IO_ERROR, BOARD_NOT_FOUND, AMBIGUOUS = range(12)
-FLAG_TIE_OVERFLOW = 1
+FLAG_TIE_OVERFLOW, FLAG_REFINE_CAPPED = 1, 2
 RECORD_HEADER = 20
 COST_Q_ONE = float(1 << 40)
 SOLVER_REFERENCE_LOCAL, SOLVER_GRID = 0, 1

@@ -656,7 +656,7 @@ struct RefineShared {
 
 struct RefineState {
   int32_t lat[3];
-  int32_t phase, rounds, hops;
+  int32_t phase, rounds, hops, capped;
   long long cost, alt;
 };
 
@@ -806,6 +806,7 @@ __device__ void pattern_refine(const Ctx& c, const Board& bd, const float2* yz, 
   const int div = refine ? c.p.refine_div : 1;
   st.rounds = 0;
   st.hops = 0;
+  st.capped = 0;
   st.cost = 0;
   st.alt = 0;
   for (;;) {
@@ -846,6 +847,7 @@ __device__ void pattern_refine(const Ctx& c, const Board& bd, const float2* yz, 
       }
     }
     st.rounds += r;
+    if (refine && stride >= 1) st.capped = 1;   // left the loop on the round cap, not on the stride
     // the eight neighbouring basins (one square along y and/or z; an odd shift swaps the colours) + the centre
     const int32_t th1[3] = {st.lat[0], kNoTheta, kNoTheta};
     const int32_t hy[3] = {st.lat[1] - c.refine_hop_y, st.lat[1], st.lat[1] + c.refine_hop_y};
@@ -991,7 +993,7 @@ __device__ void refine_frame(const Ctx& c, SolveRec* rec, float2* s_yz, uint8_t*
     out->iters_b = st.hops;
     out->phase = st.phase;
     out->valid = 1;
-    out->flags = flags;
+    out->flags = flags | (st.capped ? ILCC_FLAG_REFINE_CAPPED : 0);
     out->ties = (int32_t)n_ties;
   }
 }

@@ -291,7 +291,15 @@ def test_ambiguous_frames_are_flagged_not_silently_returned(ob):
     assert len(e.fetch_cloud(0, N.CLOUD_OPTIM)) == r.n_plane
     p.ambiguity_eps = 0.0
     e.set_params(p)
-    assert e.extract(cut[None], click[None])[0].status == N.OK
+    r0 = e.extract(cut[None], click[None])[0]
+    assert r0.status == N.OK and r0.flags == 0
+    p.refine_max_rounds = 2          # the pattern search is cut off long before its stride reaches the lattice: flagged
+    e.set_params(p)
+    r2 = e.extract(cut[None], click[None])[0]
+    op.refine_max_rounds, op.ambiguity_eps = 2, 0.0
+    o2 = ob.extract(cut, click, op)
+    assert r2.flags & N.FLAG_REFINE_CAPPED and r2.iters_a == o2.iters_a and tuple(r2.theta_t) == tuple(o2.theta_t)
+    assert r2.sel_cost >= r0.sel_cost
     e.close()
     m = LidarCornersEst(max_points_per_frame=len(cut))
     m.setROI(cut, click)
