@@ -34,9 +34,22 @@
 // instructions per point and lane for a border-class point (out-of-board logic included), 15 for an interior-class
 // point (it is in the board under every translation of the grid: accumulate_interior).
 #include "ilcc_internal.h"
+#ifdef ILCC_K6_TIMING
+#include <algorithm>
+#include <vector>
+#endif
 
 namespace ilcc {
 
+// -DILCC_K6_TIMING: per-wavefront cycle budget of the FULL pass (s_memtime around the phases of a workgroup's life), summed
+// into k6_prof[] and read back through ilcc_debug_k6_profile (tools/dev_k6_timing.py).  Costs ~10 % of the kernel's time.
+#ifdef ILCC_K6_TIMING
+constexpr int kProfWaves = 1 << 17, kProfWords = 12;
+__device__ unsigned long long k6_prof[kProfWaves * kProfWords];   // one record per wavefront: plain stores, no atomics
+#define K6_NOW() __builtin_readcyclecounter()
+#else
+#define K6_NOW() 0ull
+#endif
 #ifndef ILCC_K6_BOUND_REFRESH
 #define ILCC_K6_BOUND_REFRESH 256
 #endif
@@ -155,6 +168,8 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
                                                uint32_t* s_iters, uint32_t* s_cnt, float* s_ay, float* s_az) {
   const uint32_t f = blockIdx.y;
   uint32_t k = blockIdx.x;   // theta index (refinement pass: set from the seed below)
+  [[maybe_unused]] const unsigned long long t_entry = K6_NOW();
+  [[maybe_unused]] unsigned long long t_rej = 0, t_surv = 0, n_rej = 0, n_surv = 0, n_done = 0, p_surv = 0;
   const ilcc_result* r = &c.res[f];
   const int lane = lane_id();
   const int wid = __builtin_amdgcn_readfirstlane(wave_id());
@@ -272,6 +287,7 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
   for (int i = threadIdx.x; i < c.p.n_ty; i += kGridThreads) s_ay[i] = c.ay[i];
   for (int i = threadIdx.x; i < c.p.n_tz; i += kGridThreads) s_az[i] = c.az[i];
   __syncthreads();
+  [[maybe_unused]] const unsigned long long t_staged = K6_NOW();
 
   const float Wh = 0.5f * (float)c.p.board_w, Hh = 0.5f * (float)c.p.board_h;
   const float delta2 = 2.f * (float)c.p.huber_delta;
@@ -304,6 +320,19 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
     ta = __builtin_amdgcn_readfirstlane(ta);
     tb = __builtin_amdgcn_readfirstlane(tb);
   };
+
+  // first block of each class in registers (see run_tile); needs a full block of both classes
+  const bool first_block = LDS_POINTS && Mi >= (uint32_t)kStep && M - Mi >= (uint32_t)kStep;
+  PointTerms first_in[kUnroll], first_bd[kUnroll];
+  if (LDS_POINTS && first_block) {
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const uint32_t ai = (uint32_t)(u * kSlices + my_s), ab = Mi + ai;
+      const float2 vi = s_ij[ai], vb = s_ij[ab];
+      first_in[u] = PointTerms{vi.x, vi.y, s_hw[ai]};
+      first_bd[u] = PointTerms{vb.x, vb.y, s_hw[ab]};
+    }
+  }
 
   // one 4 x 4 tile, quad-sliced (lane = candidate * 4 + slice), from walk positions (pin0, pbd0) on, sums starting at
   // (a0_init, a1_init)
@@ -344,17 +373,8 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
     if constexpr (LDS_POINTS) {
       // Two interleaved walks: 8 interior points (cheap term), 8 border points (full term), test, ... --
       // interleaved so that every prefix still samples both the pattern (interior) and the outline (border) of the board
-      uint32_t pin = pin0, pbd = pbd0;       // next walk position of each class (the pre-pass may have consumed a block of each)
+      uint32_t pin = pin0, pbd = pbd0;       // next walk position of each class
       uint32_t since_refresh = 0;
-      PointTerms nin[kUnroll], nbd[kUnroll];
-      if (pin + kStep <= Mi) {
-#pragma unroll
-        for (int u = 0; u < kUnroll; ++u) nin[u] = fetch(pin + u * kSlices + my_s);
-      }
-      if (pbd + kStep <= M) {
-#pragma unroll
-        for (int u = 0; u < kUnroll; ++u) nbd[u] = fetch(pbd + u * kSlices + my_s);
-      }
       auto beaten = [&]() -> bool {          // every candidate of the tile provably loses
         const float part = fminf(quad_sum(A0), quad_sum(A1));
         return !__any(owner && !(part > lim2));
@@ -367,42 +387,41 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
           gb_bits = __hip_atomic_load(bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next refresh
         }
       };
-      for (;;) {
-        const bool more_in = pin + kStep <= Mi, more_bd = pbd + kStep <= M;
-        if (!more_in && !more_bd) break;
-        if (more_in) {
-          PointTerms pt[kUnroll];
+      // The first block of each class is the SAME 16 walk positions for every tile of the workgroup, and 96 % of the tiles
+      // die at the test that follows it: those points live in registers (first_in / first_bd, loaded once per wavefront), so
+      // the rejection path of a tile touches LDS only for its (ty, tz) pair and never prefetches a block it will not use
+      if (first_block) {
 #pragma unroll
-          for (int u = 0; u < kUnroll; ++u) pt[u] = nin[u];
-          if (pin + 2 * kStep <= Mi) {
+        for (int u = 0; u < kUnroll; ++u) accumulate_interior(first_in[u], ay, az, delta2, A0, A1);
 #pragma unroll
-            for (int u = 0; u < kUnroll; ++u) nin[u] = fetch(pin + kStep + u * kSlices + my_s);
-          }
-#pragma unroll
-          for (int u = 0; u < kUnroll; ++u) accumulate_interior(pt[u], ay, az, delta2, A0, A1);
-          pin += kStep;
-#ifndef ILCC_K6_TEST_INTERIOR
-#define ILCC_K6_TEST_INTERIOR 0   // 0: while border points remain the bound test follows the border block only (8 interior + 8 border
-                                  // points between tests); 1: after every block.  Measured 0: 245.6 k, 1: 239.4 k frames/s
-#endif
-          if (PRUNE && (ILCC_K6_TEST_INTERIOR || !more_bd)) {
-            if (beaten()) {
-              pruned = true;
-              break;
-            }
+        for (int u = 0; u < kUnroll; ++u) accumulate<OOB>(first_bd[u], ay, az, Wh, Hh, delta2, A0, A1);
+        pin = kStep;
+        pbd = Mi + kStep;
+        if (PRUNE) {
+          if (beaten())
+            pruned = true;
+          else
             refresh();
-          }
         }
-        if (more_bd) {
-          PointTerms pt[kUnroll];
+      }
+      // Survivors of the first test -- 72 % of the kernel's VALU instructions are spent here (tools/dev_k6_timing.py) -- walk
+      // on in a loop made for the common case, "both classes still have a full block": one bound test per 8 + 8 positions, a
+      // scalar trip count, and NO software prefetch: with 6-7 resident wavefronts per SIMD the LDS latency is covered by the
+      // other wavefronts, and the registers of a second block in flight cost a wavefront of occupancy (measured with two
+      // named register sets: 83 VGPRs, 267 k instead of 281 k frames/s).
+      if (!(PRUNE && pruned)) {
+        uint32_t both = (uint32_t)__builtin_amdgcn_readfirstlane((int)min((Mi - min(pin, Mi)) / (uint32_t)kStep, (M - pbd) / (uint32_t)kStep));
+        for (; both; --both) {
+          PointTerms bi[kUnroll], bb[kUnroll];
 #pragma unroll
-          for (int u = 0; u < kUnroll; ++u) pt[u] = nbd[u];
-          if (pbd + 2 * kStep <= M) {
+          for (int u = 0; u < kUnroll; ++u) bi[u] = fetch(pin + u * kSlices + my_s);
 #pragma unroll
-            for (int u = 0; u < kUnroll; ++u) nbd[u] = fetch(pbd + kStep + u * kSlices + my_s);
-          }
+          for (int u = 0; u < kUnroll; ++u) bb[u] = fetch(pbd + u * kSlices + my_s);
 #pragma unroll
-          for (int u = 0; u < kUnroll; ++u) accumulate<OOB>(pt[u], ay, az, Wh, Hh, delta2, A0, A1);
+          for (int u = 0; u < kUnroll; ++u) accumulate_interior(bi[u], ay, az, delta2, A0, A1);
+#pragma unroll
+          for (int u = 0; u < kUnroll; ++u) accumulate<OOB>(bb[u], ay, az, Wh, Hh, delta2, A0, A1);
+          pin += kStep;
           pbd += kStep;
           if (PRUNE) {
             if (beaten()) {
@@ -411,6 +430,28 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
             }
             refresh();
           }
+        }
+      }
+      // what is left when one class runs out of full blocks (a few dozen positions at the end of a complete walk)
+      for (; !(PRUNE && pruned);) {
+        const bool more_in = pin + kStep <= Mi, more_bd = pbd + kStep <= M;
+        if (!more_in && !more_bd) break;
+        if (more_in) {
+#pragma unroll
+          for (int u = 0; u < kUnroll; ++u) accumulate_interior(fetch(pin + u * kSlices + my_s), ay, az, delta2, A0, A1);
+          pin += kStep;
+        }
+        if (more_bd) {
+#pragma unroll
+          for (int u = 0; u < kUnroll; ++u) accumulate<OOB>(fetch(pbd + u * kSlices + my_s), ay, az, Wh, Hh, delta2, A0, A1);
+          pbd += kStep;
+        }
+        if (PRUNE) {
+          if (beaten()) {
+            pruned = true;
+            break;
+          }
+          refresh();
         }
       }
       if (!(PRUNE && pruned)) {   // tails (< 8 points per class): one point per lane and trip, lanes past the end idle
@@ -521,8 +562,32 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
   for (int tt = wid; tt < n_tiles; tt += kGridThreads / ILCC_WAVE) {
     const int tile_a = ta, tile_b = tb;
     advance();
+#ifdef ILCC_K6_TIMING
+    const unsigned long long tt0 = K6_NOW();
+    const uint32_t pd0 = pts_done;
+    const float bc0 = best.cost;
+    const uint32_t bf0 = best.flat;
+#endif
     run_tile(tile_a, tile_b, 0.f, 0.f, 0u, Mi);
+#ifdef ILCC_K6_TIMING
+    {
+      const unsigned long long dt = K6_NOW() - tt0;
+      const uint32_t walked = pts_done - pd0;
+      if (walked <= (uint32_t)(2 * kStep) && walked < M) {
+        ++n_rej;
+        t_rej += dt;
+      } else {
+        ++n_surv;
+        t_surv += dt;
+        p_surv += walked;
+        if (walked >= M) ++n_done;
+      }
+      (void)bc0;
+      (void)bf0;
+    }
+#endif
   }
+  [[maybe_unused]] const unsigned long long t_tiles = K6_NOW();
 
   // lanes hold different candidates: wavefront argmin, then across the 4 wavefronts
 #pragma unroll
@@ -554,6 +619,25 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
     out->d2 = b.d2;
     out->flat = b.flat;
   }
+#ifdef ILCC_K6_TIMING
+  if (lane == 0 && c.tie_count != nullptr) {   // the full pass only
+    const unsigned long long t_end = K6_NOW();
+    const uint32_t w = ((f * c.grid_blocks + blockIdx.x) * (kGridThreads / ILCC_WAVE) + (uint32_t)wid) & (kProfWaves - 1);
+    unsigned long long* o = k6_prof + (size_t)w * kProfWords;
+    o[0] = 1ull;
+    o[1] = t_end - t_entry;
+    o[2] = t_staged - t_entry;
+    o[3] = n_rej;
+    o[4] = t_rej;
+    o[5] = n_surv;
+    o[6] = t_surv;
+    o[7] = p_surv;
+    o[8] = n_done;
+    o[9] = t_end - t_tiles;
+    o[10] = (unsigned long long)M;
+    o[11] = (unsigned long long)Mi;
+  }
+#endif
 }
 
 // dynamic LDS: [grid_lds_points float2][grid_lds_points float][n_ty + n_tz floats]; frames with more
@@ -574,6 +658,21 @@ __global__ __launch_bounds__(kGridThreads) void k6_grid_cost(Ctx c, float* volum
   else
     grid_cost_body<OOB, VOLUME, false, PRUNE>(c, volume, s_ij, s_hw, s_best, s_iters, s_cnt, s_ay, s_az);
 }
+
+#ifdef ILCC_K6_TIMING
+extern "C" int ilcc_debug_k6_profile(unsigned long long* out16, int clear) {
+  static std::vector<unsigned long long> host((size_t)kProfWaves * kProfWords);
+  if (hipMemcpyFromSymbol(host.data(), HIP_SYMBOL(k6_prof), host.size() * sizeof(unsigned long long)) != hipSuccess) return -1;
+  for (int k = 0; k < 16; ++k) out16[k] = 0;
+  for (size_t w = 0; w < (size_t)kProfWaves; ++w)
+    for (int k = 0; k < kProfWords; ++k) out16[k] += host[w * kProfWords + k];
+  if (clear) {
+    std::fill(host.begin(), host.end(), 0ull);
+    if (hipMemcpyToSymbol(HIP_SYMBOL(k6_prof), host.data(), host.size() * sizeof(unsigned long long)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif
 
 // executed-work unit of Ctx::grid_iters: one count = one point x one 16-candidate tile
 uint32_t grid_cost_evals_per_count() { return kTile * kTile; }
