@@ -37,7 +37,7 @@ struct Slot {
   float4 *d_roi = nullptr, *d_cluster = nullptr, *d_board = nullptr, *d_pca = nullptr, *d_optim = nullptr;
   float2* d_yz = nullptr;
   uint8_t *d_lab = nullptr, *d_cls = nullptr;
-  uint32_t *d_nlab = nullptr, *d_counts = nullptr, *d_parent = nullptr, *d_count = nullptr;
+  uint32_t *d_nlab = nullptr, *d_walk = nullptr, *d_counts = nullptr, *d_parent = nullptr, *d_count = nullptr;
   unsigned long long* d_masks = nullptr;
   uint32_t *d_hash_head = nullptr, *d_hash_next = nullptr;
   GridPartial *d_partial = nullptr, *d_partial2 = nullptr, *d_partial3 = nullptr;
@@ -218,7 +218,7 @@ int32_t upload_tables(ilcc_handle* h) {
 
 void free_slot(Slot& sl) {
   void* bufs[] = {sl.d_xyzi, sl.d_clicks, sl.d_off, sl.d_res, sl.d_roi, sl.d_cluster, sl.d_board, sl.d_pca, sl.d_optim,
-                  sl.d_yz, sl.d_lab, sl.d_cls, sl.d_nlab, sl.d_counts, sl.d_parent, sl.d_count, sl.d_hash_head, sl.d_hash_next, sl.d_partial, sl.d_partial2, sl.d_partial3, sl.d_masks,
+                  sl.d_yz, sl.d_lab, sl.d_cls, sl.d_nlab, sl.d_walk, sl.d_counts, sl.d_parent, sl.d_count, sl.d_hash_head, sl.d_hash_next, sl.d_partial, sl.d_partial2, sl.d_partial3, sl.d_masks,
                   sl.d_solverec, sl.d_bound, sl.d_iters, sl.d_tie_count, sl.d_tie_list};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -272,6 +272,7 @@ int32_t alloc_slot(ilcc_handle* h, Slot& sl) {
   ALLOC(sl.d_lab, np);
   ALLOC(sl.d_cls, np);
   ALLOC(sl.d_nlab, sizeof(uint32_t) * mf);
+  ALLOC(sl.d_walk, sizeof(uint32_t) * mf);
   ALLOC(sl.d_counts, sizeof(uint32_t) * h->crop_chunks_cap);
   ALLOC(sl.d_masks, sizeof(unsigned long long) * (size_t)h->crop_chunks_cap * (kCropChunk / 64));
   ALLOC(sl.d_parent, sizeof(uint32_t) * np);
@@ -311,6 +312,7 @@ Ctx make_ctx(ilcc_handle* h, Slot& sl, const float4* d_xyzi, const float* d_clic
   c.lab = sl.d_lab;
   c.cls = sl.d_cls;
   c.n_lab = sl.d_nlab;
+  c.walk_stride = sl.d_walk;
   c.crop_counts = sl.d_counts;
   c.crop_masks = sl.d_masks;
   c.uf_parent = sl.d_parent;
@@ -946,6 +948,8 @@ static int32_t stage_labelled(ilcc_handle* h, const float* yz, const uint8_t* la
   HIP_TRY(h, hipMemcpyAsync(sl.d_off, off, sizeof(off), hipMemcpyHostToDevice, s));
   HIP_TRY(h, hipMemcpyAsync(sl.d_res, &r, sizeof(r), hipMemcpyHostToDevice, s));
   HIP_TRY(h, hipMemcpyAsync(sl.d_nlab, &m, sizeof(m), hipMemcpyHostToDevice, s));
+  const uint32_t stride = walk_stride(m);
+  HIP_TRY(h, hipMemcpyAsync(sl.d_walk, &stride, sizeof(stride), hipMemcpyHostToDevice, s));
   if (m > 0) {
     HIP_TRY(h, hipMemcpyAsync(sl.d_yz, yz, sizeof(float2) * m, hipMemcpyHostToDevice, s));
     HIP_TRY(h, hipMemcpyAsync(sl.d_lab, label, m, hipMemcpyHostToDevice, s));

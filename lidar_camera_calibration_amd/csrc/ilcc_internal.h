@@ -100,6 +100,7 @@ struct Ctx {
   float2* yz;                // labelled (non-gray) points, plane-frame y,z
   uint8_t* lab;              // 0 black, 1 white
   uint32_t* n_lab;           // per frame
+  uint32_t* walk_stride;     // per frame: K6's point-walk stride, walk_stride(n_lab) -- written with n_lab (K4/K5, stage_labelled)
   uint8_t* cls;              // color_by_gray_zone class of every plane point: 0 black, 1 gray, 2 white
   uint32_t* crop_counts;     // n_frames x crop_chunks
   unsigned long long* crop_masks;  // n_frames x crop_chunks x (kCropChunk / 64) keep-bits of the count pass
@@ -139,6 +140,25 @@ struct Ctx {
   ilcc_params p;
   int32_t c_th, c_ty, c_tz;  // index of the candidate nearest zero on each axis
 };
+
+// K6 walks a frame's M labelled points in the order slot s <- point (s * S) mod M with S ~ 0.618 M coprime to M (a
+// golden-ratio permutation: every prefix of the walk is a sample spread over the whole board).  Computed ONCE per frame
+// where n_lab is written -- the Euclid loop costs a few hundred instructions and every one of K6's ~150 workgroups per
+// frame used to repeat it.
+__host__ __device__ inline uint32_t walk_stride(uint32_t M) {
+  if (M <= 2) return 1u;
+  uint32_t S = ((uint32_t)((float)M * 0.6180339f)) | 1u;
+  for (;; S += 2u) {
+    uint32_t a = S, b = M;
+    while (b) {
+      const uint32_t t = a % b;
+      a = b;
+      b = t;
+    }
+    if (a == 1u) break;
+  }
+  return S >= M ? 1u : S;
+}
 
 // ---------------------------------------------------------------- wave / block helpers
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (ILCC_WAVE - 1); }

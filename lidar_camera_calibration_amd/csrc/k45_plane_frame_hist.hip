@@ -239,6 +239,7 @@ __global__ __launch_bounds__(kHistThreads) void k45_plane_frame_hist(Ctx c) {
     r->n_white = (int32_t)nw;
     r->n_gray = (int32_t)(M - running);
     c.n_lab[f] = running;
+    c.walk_stride[f] = walk_stride(running);
   }
 }
 

@@ -135,30 +135,20 @@ __device__ __forceinline__ void accumulate_interior(const PointTerms& p, float a
 #define ILCC_K6_SPLIT 1   // (A/B builds: 0 = one class of points, every point takes the full accumulate<>)
 #endif
 
-__device__ __forceinline__ uint32_t gcd_u32(uint32_t a, uint32_t b) {
-  while (b) {
-    const uint32_t t = a % b;
-    a = b;
-    b = t;
-  }
-  return a;
-}
-
-// the seed pass's best candidate of frame f (every lane returns the same record)
-__device__ __forceinline__ Best seed_argmin(const Ctx& c, uint32_t f, int lane) {
+// the seed pass's best candidate of frame f and the seed workgroup (= seed theta index) that found it; wave-uniform.
+// A handful of records: every lane reads them all (uniform addresses, scalar-cache loads) -- no cross-lane reduction.
+__device__ __forceinline__ Best seed_argmin(const Ctx& c, uint32_t f, uint32_t& k2, uint32_t& ab) {
   const GridPartial* sp = c.seed_partial + (uint64_t)f * c.seed_blocks;
   Best sb{__builtin_inff(), 0xFFFFFFFFu, 0xFFFFFFFFu};
-  for (uint32_t q = (uint32_t)lane; q < c.seed_blocks; q += ILCC_WAVE) {
+  k2 = 0;
+  ab = 0;
+  for (uint32_t q = 0; q < c.seed_blocks; ++q) {
     const GridPartial g = sp[q];
-    if (better(g.cost, g.d2, g.flat, sb)) sb = Best{g.cost, g.d2, g.flat};
-  }
-#pragma unroll
-  for (int o = ILCC_WAVE / 2; o > 0; o >>= 1) {
-    Best tb;
-    tb.cost = __shfl_xor(sb.cost, o, ILCC_WAVE);
-    tb.d2 = __shfl_xor(sb.d2, o, ILCC_WAVE);
-    tb.flat = __shfl_xor(sb.flat, o, ILCC_WAVE);
-    if (better(tb.cost, tb.d2, tb.flat, sb)) sb = tb;
+    if (better(g.cost, g.d2, g.flat, sb)) {
+      sb = Best{g.cost, g.d2, g.flat};
+      k2 = q;
+      ab = g.pad;   // (a << 16) | b of the record's candidate in ITS launch's tables
+    }
   }
   return sb;
 }
@@ -179,6 +169,7 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
       out->cost = __builtin_inff();
       out->d2 = 0xFFFFFFFFu;
       out->flat = 0xFFFFFFFFu;
+      out->pad = 0u;
     }
     return;
   }
@@ -191,11 +182,11 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
   int a_org = 0, b_org = 0;   // first candidate of tile (0, 0)
   int t0 = 0;
   if (PRUNE && c.seed_partial != nullptr) {
-    const Best sb = seed_argmin(c, f, lane);
+    uint32_t k2u, ab;
+    const Best sb = seed_argmin(c, f, k2u, ab);
     if (sb.flat != 0xFFFFFFFFu) {
-      const uint32_t cell = sb.flat >> 1;
-      const int b2 = (int)(cell % (uint32_t)c.seed_n_tz), a2 = (int)((cell / (uint32_t)c.seed_n_tz) % (uint32_t)c.seed_n_ty);
-      const int k2 = (int)(cell / ((uint32_t)c.seed_n_tz * (uint32_t)c.seed_n_ty));
+      const int a2 = __builtin_amdgcn_readfirstlane((int)(ab >> 16)), b2 = __builtin_amdgcn_readfirstlane((int)(ab & 0xFFFFu));
+      const int k2 = __builtin_amdgcn_readfirstlane((int)k2u);
       const int sa = min(a2 * c.seed_stride_t, n_ty - 1), sbb = min(b2 * c.seed_stride_t, n_tz - 1);
       if (c.refine_radius_th > 0) {
         // refinement pass: every candidate within +-radius theta steps and the 8 x 8 (ty, tz) window
@@ -218,12 +209,7 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
   // Point order: slot s holds point (s * S) mod M with S ~ 0.618 M coprime to M, so that EVERY prefix
   // of the walk is a sample spread over the whole board (ring order would spend the first points on
   // one scan line, which says little about a candidate): the bound test cuts tiles sooner.
-  uint32_t S = 1;
-  if (M > 2) {
-    S = ((uint32_t)((float)M * 0.6180339f)) | 1u;
-    while (gcd_u32(S, M) != 1u) S += 2u;
-    if (S >= M) S = 1;
-  }
+  const uint32_t S = M ? c.walk_stride[f] : 1u;   // walk_stride(M), computed where n_lab is written
   // Staged points come in two classes.  INTERIOR: in the board under EVERY translation of the tables (checked with
   // accumulate<>'s own fp32 expressions at the four extreme translations; |i - W/2| - W/2 is V-shaped in i and every
   // operation is monotone, so the extremes decide for all values in between) -> accumulate_interior.  BORDER: the rest.
@@ -234,14 +220,19 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
     const float Wh_ = 0.5f * (float)c.p.board_w, Hh_ = 0.5f * (float)c.p.board_h;
     const float ay_lo = c.ay[0], ay_hi = c.ay[c.p.n_ty - 1], az_lo = c.az[0], az_hi = c.az[c.p.n_tz - 1];
     uint32_t base_in = 0, base_out = 0;
+    // slot sl <- point (sl * S) mod M, advanced chunk by chunk (M <= 8192 here: the products fit 32 bits)
+    uint32_t pidx = M ? (threadIdx.x * S) % M : 0u;
+    const uint32_t pstep = M ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(((uint32_t)kGridThreads * S) % M)) : 0u;
     for (uint32_t c0 = 0; c0 < M; c0 += kGridThreads) {
       const uint32_t sl = c0 + threadIdx.x;
       const bool valid = sl < M;
       float2 ij = make_float2(0.f, 0.f);
       float hw = 0.f;
       bool interior = false;
+      const uint32_t i = pidx;
+      pidx += pstep;
+      if (pidx >= M) pidx -= M;
       if (valid) {
-        const uint32_t i = (uint32_t)(((uint64_t)sl * S) % M);
         const float2 v = gyz[i];
         // Rx(theta) on (0,y,z), already divided by g (Optimization.h:37-46)
         ij = make_float2(fmaf(-sth, v.y, cth * v.x), fmaf(cth, v.y, sth * v.x));
@@ -618,6 +609,13 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
     out->cost = b.cost;
     out->d2 = b.d2;
     out->flat = b.flat;
+    // (a << 16) | b of the winner in this launch's tables: the next launch reads it instead of dividing the flat index
+    uint32_t ab = 0;
+    if (b.flat != 0xFFFFFFFFu) {
+      const uint32_t cell = b.flat >> 1;
+      ab = (((cell / (uint32_t)n_tz) % (uint32_t)n_ty) << 16) | (cell % (uint32_t)n_tz);
+    }
+    out->pad = ab;
   }
 #ifdef ILCC_K6_TIMING
   if (lane == 0 && c.tie_count != nullptr) {   // the full pass only
