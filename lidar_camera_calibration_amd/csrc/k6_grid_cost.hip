@@ -30,7 +30,7 @@
 //   1/2 rho(r^2) = q (r - q/2),  q = min(r, delta)                     (HuberLoss(0.1), :137)
 // The cell is white iff topleftWhite xor ((floor i + floor j) odd)  (:53-61), so a mismatch
 // under phase 0 is a match under phase 1: both phases come out of one pass.
-// Arithmetic is carried in doubled units (R = 2r, sums = 2 x cost; powers of two, exact): 26 VALU
+// A lane's sums carry cost / 2 (the colour weight is 0 or 1/2; powers of two, exact): 26 VALU
 // instructions per point and lane for a border-class point (out-of-board logic included), 15 for an interior-class
 // point (it is in the board under every translation of the grid: accumulate_interior).
 #include "ilcc_internal.h"
@@ -83,14 +83,14 @@ struct PointTerms {   // uniform across the wavefront
   float pi, pj, hw;   // rotated coordinates / g, and 0.5 * (label == white)
 };
 
-// one point under this lane's translation: adds 2 x cost to (A0, A1)
+// one point under this lane's translation: adds cost / 2 to (A0, A1)
 template <bool OOB>
-__device__ __forceinline__ void accumulate(const PointTerms& p, float ay, float az, float Wh, float Hh, float delta2,
+__device__ __forceinline__ void accumulate(const PointTerms& p, float ay, float az, float Wh, float Hh, float delta,
                                            float& A0, float& A1) {
   const float i = p.pi + ay, j = p.pj + az;
   const float fi = floorf(i), fj = floorf(j);
   const float ai = (i - fi) - 0.5f, aj = (j - fj) - 0.5f;       // dist to the nearest integer = 0.5 - |a|
-  const float Rin = fmaf(-2.f, fabsf(ai) + fabsf(aj), 2.f);     // 2 (dist_i + dist_j)
+  const float Rin = 1.f - (fabsf(ai) + fabsf(aj));              // dist_i + dist_j
   const float mf = __builtin_amdgcn_fractf(fmaf(0.5f, fi + fj, p.hw));   // 0.5 iff (floor i + floor j + white) odd
   const float nmf = 0.5f - mf;
   const float ui = fabsf(i - Wh) - Wh, uj = fabsf(j - Hh) - Hh; // < 0 inside; |.| = min(|i|, |i-W|)
@@ -100,8 +100,7 @@ __device__ __forceinline__ void accumulate(const PointTerms& p, float ay, float 
   auto sel = [&](float if_oob, float otherwise) -> float { return oob ? if_oob : otherwise; };
   float R, w0, w1;
   if (OOB) {
-    const float so = fabsf(ui) + fabsf(uj);
-    R = sel(so + so, Rin);
+    R = sel(fabsf(ui) + fabsf(uj), Rin);
     w0 = sel(0.5f, mf);
     w1 = sel(0.5f, nmf);
   } else {
@@ -109,23 +108,23 @@ __device__ __forceinline__ void accumulate(const PointTerms& p, float ay, float 
     w0 = mf;
     w1 = nmf;
   }
-  const float Q = fminf(R, delta2);
-  const float T = Q * fmaf(-0.5f, Q, R);    // 4 q (r - q/2)
-  A0 = fmaf(T, w0, A0);                     // += 2 x cost under topleftWhite = false
+  const float Q = fminf(R, delta);
+  const float T = Q * fmaf(-0.5f, Q, R);    // q (r - q/2) = 1/2 rho(r^2)
+  A0 = fmaf(T, w0, A0);                     // += cost / 2 under topleftWhite = false
   A1 = fmaf(T, w1, A1);
 }
 
 // The same term for a point that is IN the board under every translation of this workgroup's tables (see the staging
 // below): the out-of-board half of accumulate<> -- 10 of its 27.5 instructions -- is dead for it.  Same operations on
 // the in-board side, so the value is bit-identical to what accumulate<> computes for such a point.
-__device__ __forceinline__ void accumulate_interior(const PointTerms& p, float ay, float az, float delta2, float& A0, float& A1) {
+__device__ __forceinline__ void accumulate_interior(const PointTerms& p, float ay, float az, float delta, float& A0, float& A1) {
   const float i = p.pi + ay, j = p.pj + az;
   const float fi = floorf(i), fj = floorf(j);
   const float ai = (i - fi) - 0.5f, aj = (j - fj) - 0.5f;
-  const float R = fmaf(-2.f, fabsf(ai) + fabsf(aj), 2.f);
+  const float R = 1.f - (fabsf(ai) + fabsf(aj));
   const float mf = __builtin_amdgcn_fractf(fmaf(0.5f, fi + fj, p.hw));
   const float nmf = 0.5f - mf;
-  const float Q = fminf(R, delta2);
+  const float Q = fminf(R, delta);
   const float T = Q * fmaf(-0.5f, Q, R);
   A0 = fmaf(T, mf, A0);
   A1 = fmaf(T, nmf, A1);
@@ -281,7 +280,7 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
   [[maybe_unused]] const unsigned long long t_staged = K6_NOW();
 
   const float Wh = 0.5f * (float)c.p.board_w, Hh = 0.5f * (float)c.p.board_h;
-  const float delta2 = 2.f * (float)c.p.huber_delta;
+  const float delta2 = (float)c.p.huber_delta;   // (the terms carry plain r and q: a lane's sums are cost / 2)
   const int n_tiles = nta * ntb;
   const uint32_t dk = (uint32_t)((int)k - c.c_th) * (uint32_t)((int)k - c.c_th);
 
@@ -330,6 +329,7 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
   auto run_tile = [&](int tile_a, int tile_b, float a0_init, float a1_init, uint32_t pin0, uint32_t pbd0) {
     const int ia = a_org + tile_a * kTile + my_a, ib = b_org + tile_b * kTile + my_b;
     const bool owner = ia < n_ty && ib < n_tz;
+    const unsigned long long owner_mask = __ballot(owner);   // an SGPR pair: the bound test is then ballot & mask, no VALU select
     const float ay = s_ay[min(ia, n_ty - 1)], az = s_az[min(ib, n_tz - 1)];
 
     // Branch and bound (PRUNE): costs are sums of non-negative terms, so a candidate whose partial
@@ -340,9 +340,9 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
     // the shared bound is fetched ahead of its use (an L2 round trip is longer than a cut-short tile, and a
     // slightly stale bound only delays a cut): this tile starts with the word loaded during the previous
     // one and issues the load for the next refresh right away
-    // sums are 2 x cost.  The test keeps everything within kTieEps of the bound alive: fp32 sums cannot order
+    // sums are cost / 2.  The test keeps everything within kTieEps of the bound alive: fp32 sums cannot order
     // such candidates reliably, K7r re-orders them on exact fixed-point sums
-    float lim2 = 2.f * (1.f + kTieEps) * fminf(__uint_as_float(gb_bits), best.cost);
+    float lim2 = 0.5f * (1.f + kTieEps) * fminf(__uint_as_float(gb_bits), best.cost);
     if (PRUNE) gb_bits = __hip_atomic_load(bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // lane's points: walk positions my_s, my_s + 4, ...  (LDS_POINTS = false: point index (pos * S) mod M)
     // (M == 0: no point is ever fetched, every candidate costs 0; keep the modulo defined)
@@ -368,13 +368,13 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
       uint32_t since_refresh = 0;
       auto beaten = [&]() -> bool {          // every candidate of the tile provably loses
         const float part = fminf(quad_sum(A0), quad_sum(A1));
-        return !__any(owner && !(part > lim2));
+        return (__ballot(!(part > lim2)) & owner_mask) == 0ull;
       };
       auto refresh = [&]() {
         since_refresh += kStep;
         if (since_refresh >= (uint32_t)kBoundRefresh) {
           since_refresh = 0;
-          lim2 = 2.f * (1.f + kTieEps) * fminf(__uint_as_float(gb_bits), best.cost);
+          lim2 = 0.5f * (1.f + kTieEps) * fminf(__uint_as_float(gb_bits), best.cost);
           gb_bits = __hip_atomic_load(bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next refresh
         }
       };
@@ -478,13 +478,13 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
         for (int u = 0; u < kUnroll; ++u) accumulate<OOB>(pt[u], ay, az, Wh, Hh, delta2, A0, A1);
         if (PRUNE) {
           const float part = fminf(quad_sum(A0), quad_sum(A1));
-          if (!__any(owner && !(part > lim2))) {
+          if ((__ballot(!(part > lim2)) & owner_mask) == 0ull) {
             pruned = true;
             pos += kStep;
             break;
           }
           if (((pos + kStep) & (kBoundRefresh - 1)) == 0) {
-            lim2 = 2.f * (1.f + kTieEps) * fminf(__uint_as_float(gb_bits), best.cost);
+            lim2 = 0.5f * (1.f + kTieEps) * fminf(__uint_as_float(gb_bits), best.cost);
             gb_bits = __hip_atomic_load(bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next refresh
           }
         }
@@ -508,8 +508,8 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
     if (owner) {
       const uint32_t cell = ((uint32_t)k * (uint32_t)n_ty + (uint32_t)ia) * (uint32_t)n_tz + (uint32_t)ib;
       const uint32_t d2 = dk + (uint32_t)((ia - c.c_ty) * (ia - c.c_ty)) + (uint32_t)((ib - c.c_tz) * (ib - c.c_tz));
-      const float c0 = 0.5f * t0s, c1 = 0.5f * t1s;
-      if (c.tie_count != nullptr && my_s == 0 && fminf(c0, c1) <= 0.5f * lim2) {   // full pass: near ties of the bound
+      const float c0 = 2.f * t0s, c1 = 2.f * t1s;
+      if (c.tie_count != nullptr && my_s == 0 && fminf(c0, c1) <= 2.f * lim2) {   // full pass: near ties of the bound
         // completions are rare: afford a fresh look at the frame's bound so that little junk is listed while it is loose
         const float fresh = __uint_as_float(__hip_atomic_load(bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         const float thr = (1.f + kTieEps) * fminf(fresh, fminf(best.cost, fminf(c0, c1)));

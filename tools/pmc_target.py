@@ -1,14 +1,32 @@
-"""Minimal target for rocprofv3 --pmc passes: three synchronous 128-frame config-2 batches (GRID mode), one batch
-alone on the chip each time -- per-dispatch counters of every kernel of the path without bench.py's other legs."""
+"""Light target for rocprofv3 --pmc / --kernel-trace passes: three synchronous batches (GRID mode), one batch alone on
+the chip each time -- per-dispatch counters of every kernel of the path without bench.py's other legs.
+usage: pmc_target.py [frames_per_batch=256] [config=2|5]      (the batch sizes bench.py runs: 256 / 64)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
 import torch
 from lidar_camera_calibration_amd import LidarCornersBatch, synth
 from lidar_camera_calibration_amd import _native as N
-F = 128
-clouds, clicks, _, _ = synth.make_batch(F, seed=0xC0FFEE)
+config = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+F = int(sys.argv[1]) if len(sys.argv) > 1 else (256 if config == 2 else 64)
+params = N.default_params()
+if config == 5:      # BASELINE configs[4], as bench.py --config 5 sets it up
+    lidar = synth.hdl64()
+    clouds, clicks, _, _ = synth.make_batch(F, lidar, synth.Board(9, 12, 0.10), seed=0xC0FFEE, range_m=(2.0, 3.0),
+                                            yaw_deg=25.0, pitch_deg=15.0, roll_deg=30.0)
+    params.board_w, params.board_h, params.grid_length = 9, 12, 0.10
+    params.n_th = params.n_ty = params.n_tz = 129
+    params.th_min, params.th_step = -16.0 * np.pi / 180.0, 0.25 * np.pi / 180.0
+    params.ty_min = params.tz_min = -0.10
+    params.ty_step = params.tz_step = 0.10 / 64
+    n = lidar.n_points
+else:
+    clouds, clicks, _, _ = synth.make_batch(F, seed=0xC0FFEE)
+    n = 28800
 d_c = torch.from_numpy(clouds).cuda(); d_k = torch.from_numpy(clicks).cuda()
-est = LidarCornersBatch(F, 28800, N.default_params())
+est = LidarCornersBatch(F, n, params)
 for _ in range(3):
-    est.extract_device(d_c.data_ptr(), F, 28800, d_k.data_ptr())
+    est.extract_device(d_c.data_ptr(), F, n, d_k.data_ptr())
+t = est.timing()
+print("pmc_target config %d, %d frames: grid_cost %.4f ms, total %.4f ms" % (config, F, t.grid_cost, t.total))
 est.close()
