@@ -36,7 +36,7 @@ extern "C" {
 #endif
 
 #define ILCC_MAX_CORNERS 256
-#define ILCC_ABI_VERSION 2
+#define ILCC_ABI_VERSION 3
 
 /* per-frame / per-call status */
 enum {
@@ -185,6 +185,14 @@ ilcc_handle* ilcc_create(int32_t device, const ilcc_params* p, uint32_t max_fram
                          uint64_t max_total_points);
 void ilcc_destroy(ilcc_handle* h);
 int32_t ilcc_set_params(ilcc_handle* h, const ilcc_params* p);
+/* Optional sizing hint (ABI 3).  Two on-chip staging capacities follow the data: the labelled (black/white) points per
+ * frame the grid search keeps in LDS, and the ROI points per frame the clustering workgroup keeps in LDS.  A fresh handle
+ * starts small (1024 / 2048) and grows them after each batch to what that batch needed; a frame above the current
+ * capacity takes a slower path with IDENTICAL results (points walked through L2; clustering by one workgroup in global
+ * memory), so only the first such batch is slower.  ilcc_reserve sets the capacities up front so that the first batch
+ * runs like the hundredth: pass the largest counts expected (e.g. 2000 / 2500 for VLP-16 at 2-3.5 m; 4500 / 25000 for a
+ * 64-ring sensor).  roi_points_per_frame > 4096 also arms the multi-workgroup clustering kernels. */
+int32_t ilcc_reserve(ilcc_handle* h, uint32_t labelled_points_per_frame, uint32_t roi_points_per_frame);
 
 /* one frame, host buffers: xyzi = n x {x,y,z,intensity} float32 (pcl::PointXYZI payload) */
 int32_t ilcc_extract(ilcc_handle* h, const float* xyzi, uint32_t n, const float click[3],

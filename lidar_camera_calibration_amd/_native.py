@@ -26,7 +26,7 @@ CLOUD_ROI, CLOUD_CLUSTER, CLOUD_CHESSBOARD, CLOUD_PCA, CLOUD_OPTIM = range(5)
 # every symbol include/ilcc_hip.h declares
 EXPORTS = [
     "ilcc_abi_version", "ilcc_strerror", "ilcc_last_error", "ilcc_default_params",
-    "ilcc_set_chessboard_param", "ilcc_create", "ilcc_destroy", "ilcc_set_params", "ilcc_extract",
+    "ilcc_set_chessboard_param", "ilcc_create", "ilcc_destroy", "ilcc_set_params", "ilcc_reserve", "ilcc_extract",
     "ilcc_extract_batch", "ilcc_extract_batch_device", "ilcc_submit_batch_device", "ilcc_submit_batch", "ilcc_wait", "ilcc_wait_records_device", "ilcc_fetch_cloud", "ilcc_fetch_labelled", "ilcc_chessboard_by_point_batch", "ilcc_fetch_classes",
     "ilcc_grid_cost", "ilcc_pattern_refine", "ilcc_get_theta_t", "ilcc_get_timing", "ilcc_reset_timing",
     "ilcc_save_corners2txt", "ilcc_read_lidar_corners",
@@ -130,6 +130,8 @@ def lib():
         L.ilcc_destroy.argtypes = [vp]
         L.ilcc_set_params.argtypes = [vp, pp]
         L.ilcc_set_params.restype = C.c_int32
+        L.ilcc_reserve.argtypes = [vp, C.c_uint32, C.c_uint32]
+        L.ilcc_reserve.restype = C.c_int32
         L.ilcc_extract.argtypes = [vp, fp, C.c_uint32, fp, rp]
         L.ilcc_extract.restype = C.c_int32
         L.ilcc_extract_batch.argtypes = [vp, fp, C.POINTER(C.c_uint64), C.c_uint32, fp, rp]

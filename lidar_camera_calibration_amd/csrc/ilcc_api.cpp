@@ -39,7 +39,7 @@ struct Slot {
   uint8_t *d_lab = nullptr, *d_cls = nullptr;
   uint32_t *d_nlab = nullptr, *d_walk = nullptr, *d_counts = nullptr, *d_parent = nullptr, *d_count = nullptr;
   unsigned long long* d_masks = nullptr;
-  uint32_t *d_hash_head = nullptr, *d_hash_next = nullptr;
+  uint32_t *d_hash_head = nullptr, *d_hash_next = nullptr, *d_big = nullptr;   // d_big: [0] count, [1..] listed frames
   GridPartial *d_partial = nullptr, *d_partial2 = nullptr, *d_partial3 = nullptr;
   SolveRec* d_solverec = nullptr;
   uint32_t* d_bound = nullptr;
@@ -78,6 +78,9 @@ struct ilcc_handle {
   double* d_solve = nullptr;   // 3 theta_t + 2 (cost, iterations) for the test entries
   RefineOut* d_refine_io = nullptr;
   uint32_t grid_lds_points = 1024;   // grows with the frames seen (finish()); frames above it take the global-memory path
+  uint32_t cluster_lds_points = 2048;   // K2's LDS capacity in ROI points per frame: grows likewise (<= 4096); larger frames take the multi-workgroup path
+  uint32_t big_grid = 1024;          // workgroups of K2's persistent kernels (4 x the device's CUs)
+  bool big_armed = false;            // K2's multi-workgroup kernels are launched: set once a frame above the LDS capacity was seen (finish()) or by ilcc_reserve
   ilcc_timing timing{};
   std::string err;
 };
@@ -218,7 +221,7 @@ int32_t upload_tables(ilcc_handle* h) {
 
 void free_slot(Slot& sl) {
   void* bufs[] = {sl.d_xyzi, sl.d_clicks, sl.d_off, sl.d_res, sl.d_roi, sl.d_cluster, sl.d_board, sl.d_pca, sl.d_optim,
-                  sl.d_yz, sl.d_lab, sl.d_cls, sl.d_nlab, sl.d_walk, sl.d_counts, sl.d_parent, sl.d_count, sl.d_hash_head, sl.d_hash_next, sl.d_partial, sl.d_partial2, sl.d_partial3, sl.d_masks,
+                  sl.d_yz, sl.d_lab, sl.d_cls, sl.d_nlab, sl.d_walk, sl.d_counts, sl.d_parent, sl.d_count, sl.d_hash_head, sl.d_hash_next, sl.d_big, sl.d_partial, sl.d_partial2, sl.d_partial3, sl.d_masks,
                   sl.d_solverec, sl.d_bound, sl.d_iters, sl.d_tie_count, sl.d_tie_list};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -279,6 +282,7 @@ int32_t alloc_slot(ilcc_handle* h, Slot& sl) {
   ALLOC(sl.d_count, sizeof(uint32_t) * np);
   ALLOC(sl.d_hash_head, sizeof(uint32_t) * (size_t)mf * kClusterHashSize);
   ALLOC(sl.d_hash_next, sizeof(uint32_t) * np);
+  ALLOC(sl.d_big, sizeof(uint32_t) * ((size_t)mf + 1));
   ALLOC(sl.d_partial, sizeof(GridPartial) * (size_t)mf * h->max_theta);
   ALLOC(sl.d_partial2, sizeof(GridPartial) * (size_t)mf * h->max_theta);
   ALLOC(sl.d_partial3, sizeof(GridPartial) * (size_t)mf * h->max_theta);
@@ -319,6 +323,11 @@ Ctx make_ctx(ilcc_handle* h, Slot& sl, const float4* d_xyzi, const float* d_clic
   c.uf_count = sl.d_count;
   c.uf_hash_head = sl.d_hash_head;
   c.uf_hash_next = sl.d_hash_next;
+  c.cluster_lds_points = h->cluster_lds_points;
+  c.big_count = sl.d_big;
+  c.big_list = sl.d_big + 1;
+  c.big_grid = h->big_grid;
+  c.big_armed = h->big_armed ? 1u : 0u;
   c.partial = sl.d_partial;
   c.solve_rec = sl.d_solverec;
   c.grid_blocks = (uint32_t)h->p.n_th;
@@ -505,9 +514,11 @@ int32_t finish(ilcc_handle* h, int si, ilcc_result* out, float* d_records = null
   t.grid_cost = ms[4];
   t.refine_corners = ms[5];
   t.total = tot;
-  uint32_t max_lab = 0;
+  uint32_t max_lab = 0, max_roi = 0;
   uint64_t evals = 0;
   for (uint32_t f = 0; f < n_frames; ++f) {
+    if (out[f].n_roi > 0 && (uint32_t)out[f].n_roi <= (uint32_t)kClusterLdsPointsMax) max_roi = std::max(max_roi, (uint32_t)out[f].n_roi);
+    if (out[f].n_roi > kClusterLdsPointsMax) h->big_armed = true;
     if (out[f].status != ILCC_OK && out[f].status != ILCC_AMBIGUOUS) continue;
     const uint32_t m = (uint32_t)(out[f].n_black + out[f].n_white);
     max_lab = std::max(max_lab, m);
@@ -533,6 +544,10 @@ int32_t finish(ilcc_handle* h, int si, ilcc_result* out, float* d_records = null
   // measured no difference: 248.8 k vs 250 k frames/s.)
   uint32_t want = std::min<uint32_t>((uint32_t)kGridLdsPointsMax, std::max<uint32_t>(1024u, (max_lab + 255u) & ~255u));
   if (want > h->grid_lds_points) h->grid_lds_points = want;
+  // the same for K2's one-workgroup LDS path (ROI points per frame, steps of 512): what it does not hold of a CU's 160 KiB
+  // is room for K6 workgroups of other batches
+  want = std::min<uint32_t>((uint32_t)kClusterLdsPointsMax, (max_roi + 511u) & ~511u);
+  if (want > h->cluster_lds_points) h->cluster_lds_points = want;
   return ILCC_OK;
 }
 
@@ -692,6 +707,11 @@ ilcc_handle* ilcc_create(int32_t device, const ilcc_params* p, uint32_t max_fram
   } else {
     (void)hipGetDevice(&h->device);
   }
+  {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess && cus > 0)
+      h->big_grid = (uint32_t)(4 * cus);
+  }
   // dynamic-LDS limits are kept per (function, device): raise them for THIS device, and say so when that fails
   if ((e = set_kernel_attributes_k2()) != hipSuccess || (e = set_kernel_attributes_k6()) != hipSuccess ||
       (e = set_kernel_attributes_k7()) != hipSuccess)
@@ -740,6 +760,21 @@ int32_t ilcc_set_params(ilcc_handle* h, const ilcc_params* p) {
   st = upload_tables(h);
   if (st != ILCC_OK) h->p = old;
   return st;
+}
+
+int32_t ilcc_reserve(ilcc_handle* h, uint32_t labelled_points_per_frame, uint32_t roi_points_per_frame) {
+  if (!h) return ILCC_BAD_ARGUMENT;
+  for (const Slot& sl : h->slots)
+    if (sl.busy) {
+      h->err = "ilcc_reserve with a batch in flight: ilcc_wait first";
+      return ILCC_BAD_ARGUMENT;
+    }
+  const uint32_t lab = std::min<uint32_t>((uint32_t)kGridLdsPointsMax, (std::max(labelled_points_per_frame, 1u) + 255u) & ~255u);
+  h->grid_lds_points = std::max(h->grid_lds_points, std::max(1024u, lab));
+  const uint32_t roi = std::min<uint32_t>((uint32_t)kClusterLdsPointsMax, (std::max(roi_points_per_frame, 1u) + 511u) & ~511u);
+  h->cluster_lds_points = std::max(h->cluster_lds_points, std::max((uint32_t)kClusterLdsPointsMin, roi));
+  if (roi_points_per_frame > (uint32_t)kClusterLdsPointsMax) h->big_armed = true;
+  return ILCC_OK;
 }
 
 int32_t ilcc_submit_batch_device(ilcc_handle* h, const float* d_xyzi, const uint64_t* offsets, uint32_t n_frames,

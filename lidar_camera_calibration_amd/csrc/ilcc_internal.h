@@ -30,6 +30,14 @@ constexpr int kHistThreads = ILCC_K45_THREADS;    // K4/K5: one workgroup per fr
 #define ILCC_K6_THREADS 256
 #endif
 constexpr int kGridThreads = ILCC_K6_THREADS;      // K6: wavefronts x 64 per workgroup (measured: see DESIGN.md)
+#ifndef ILCC_K6_THREADS_LARGE
+#define ILCC_K6_THREADS_LARGE 512
+#endif
+constexpr int kGridThreadsLarge = ILCC_K6_THREADS_LARGE;   // K6 on frames staged above kGridLargeFrom points per workgroup
+#ifndef ILCC_K6_LARGE_FROM
+#define ILCC_K6_LARGE_FROM 2048
+#endif
+constexpr int kGridLargeFrom = ILCC_K6_LARGE_FROM;
 constexpr int kTileA = 4;              // K6 candidate tile: ty values per wavefront pass
 #ifndef ILCC_TILE_B
 #define ILCC_TILE_B 4
@@ -55,10 +63,8 @@ constexpr int kIterSlots = 64;         // K6 executed-iteration counters (spread
 #endif
 constexpr int kClusterAllPairsMax = ILCC_K2_ALLPAIRS_MAX;   // K2: above this many points the spatial hash finds neighbours
 constexpr int kClusterHashSize = 1 << 17;    // K2: hash buckets per frame (global memory)
-#ifndef ILCC_K2_LDS_PARENTS
-#define ILCC_K2_LDS_PARENTS 16384
-#endif
-constexpr int kClusterLdsParents = ILCC_K2_LDS_PARENTS;  // K2 union-find parents kept in LDS (64 KiB)
+constexpr int kClusterLdsPointsMax = 4096;   // K2: largest LDS capacity (ROI points per frame) of the one-workgroup path
+constexpr int kClusterLdsPointsMin = 1024;   // K2: smallest (the handle grows it in steps of 512 with the ROI sizes it sees)
 
 struct GridPartial {   // per K6 workgroup best candidate
   float cost;
@@ -108,6 +114,11 @@ struct Ctx {
   uint32_t* uf_count;        // K2 component sizes
   uint32_t* uf_hash_head;    // K2 spatial hash: n_frames x kClusterHashSize bucket heads
   uint32_t* uf_hash_next;    // K2 spatial hash: chain links, one per point
+  uint32_t cluster_lds_points;   // K2: ROI points per frame the one-workgroup LDS path is sized for; larger frames are listed
+  uint32_t* big_count;       // K2: number of listed frames of this batch (reset by K1)
+  uint32_t* big_list;        // K2: their frame indices
+  uint32_t big_grid;         // K2: workgroups of the persistent multi-workgroup kernels
+  uint32_t big_armed;        // K2: 1 = those kernels are launched for this batch and large frames are left to them
   GridPartial* partial;      // n_frames x grid_blocks
   SolveRec* solve_rec;       // n_frames x 2
   uint32_t grid_blocks;      // K6 workgroups per frame

@@ -1,20 +1,24 @@
 // K2 seeded_cluster -- replaces pcl::EuclideanClusterExtraction + nearestKSearch of
 // LidarCornersEst::EuclideanCluster (/root/reference/ilcc2/src/LidarCornersEst.cpp:124-153).
 //
-// One 1024-thread workgroup per frame.  Single-linkage components of the radius graph
-// (squared float distance dx*dx+dy*dy+dz*dz < (float)(tol*tol), FLANN's strict test) are
-// built with a lock-free union-find whose parents live in LDS (<= 16384 ROI points, else a
-// global scratch array).  Roots are always the smallest member index, so the labelling is
-// deterministic.  Neighbour search, four ways with identical results:
-//   <= ILCC_K2_ALLPAIRS_MAX (256) points  tiled all-pairs (1024 "j" points per LDS tile, broadcast reads);
-//   <= 4096 points (the ROI case)          wave-cooperative search on a direct cell grid in LDS: points
-//                                          counting-sorted by cell, a wavefront per occupied cell, candidates in
-//                                          the lanes, own points through v_readlane, unions queued and executed
-//                                          64 at a time -- or, when the bounding box needs more than 16384 cells,
-//                                          per-point scans of counting-sorted hashed buckets in LDS;
-//   above                                  a spatial hash with chained buckets in global memory: what un-cropped
-//                                          clouds (the online caller get_chessboard_by_point,
-//                                          LidarCornersEst.cpp:72-115) need.
+// Single-linkage components of the radius graph (squared float distance dx*dx+dy*dy+dz*dz < (float)(tol*tol),
+// FLANN's strict test) are built with a lock-free union-find.  Roots are always the smallest member index, so the
+// labelling is deterministic.  Neighbour search, four ways with identical results:
+//   frames of <= cluster_lds_points ROI points (the handle's LDS capacity, <= 4096): ONE 1024-thread workgroup per
+//   frame, parents in LDS:
+//     <= ILCC_K2_ALLPAIRS_MAX (256) points  tiled all-pairs (1024 "j" points per LDS tile, broadcast reads);
+//     else (the ROI case)                   wave-cooperative search on a direct cell grid in LDS: points
+//                                           counting-sorted by cell, a wavefront per occupied cell, candidates in
+//                                           the lanes, own points through v_readlane, unions queued and executed
+//                                           64 at a time -- or, when the bounding box needs more than 16384 cells,
+//                                           per-point scans of counting-sorted hashed buckets in LDS;
+//   larger frames (dense clouds: BASELINE config 5's ~20 k ROI points; un-cropped clouds of the online caller
+//   get_chessboard_by_point, LidarCornersEst.cpp:72-115): SEVERAL workgroups per frame.  The frame's own workgroup only
+//   resets the parents and the frame's hash table and puts the frame on the batch's list; k2l_insert / k2l_search
+//   (persistent grids over (frame, 256-point chunk) items of the listed frames) build a spatial hash with chained
+//   buckets in global memory and unite neighbours with device-scope atomics; k2l_finish (one workgroup per listed
+//   frame) labels, sizes, picks and compacts exactly like the LDS path.  (Round 2 ran this search inside the frame's one
+//   workgroup: 64 workgroups on 256 CUs, 16 ms per 64-frame config-5 batch.)
 // Cluster choice follows the reference: components with
 // cluster_min <= size <= cluster_max, sorted by size (largest = index 0); the one containing
 // the exact 1-NN of the click wins, otherwise index 0.  Members are emitted in index order.
@@ -89,20 +93,22 @@ __device__ __forceinline__ bool nn_less(const NnKey& x, const NnKey& y) {
 #ifndef ILCC_K2_GRID_MAX
 #define ILCC_K2_GRID_MAX 4096
 #endif
-constexpr int kClusterGridMax = ILCC_K2_GRID_MAX;     // <= this many ROI points: cell lists entirely in LDS
+constexpr int kClusterGridMax = ILCC_K2_GRID_MAX;     // upper bound of the LDS path's capacity (= kClusterLdsPointsMax)
+static_assert(kClusterGridMax == kClusterLdsPointsMax, "one constant");
 constexpr int kClusterGridBuckets = 8192;
 constexpr int kClusterCells = 16384;       // direct cell grid of the wave-cooperative search (u16 run ends: 32 KiB)
 
 template <bool LDS_PARENT>
+__device__ void cluster_finish(const Ctx& c, uint32_t f, uint32_t* parent, uint32_t* sc);
+
+// one workgroup, parents in LDS: frames of at most `cap` = c.cluster_lds_points ROI points
 __device__ void cluster_frame(const Ctx& c, uint32_t f, uint32_t* lds_parent, float4* tile,
-                              uint32_t* sc, float4* s_pts) {
+                              uint32_t* sc, float4* s_pts, uint32_t cap) {
   ilcc_result* r = &c.res[f];
-  if (r->status != ILCC_OK) return;
   const uint32_t M = (uint32_t)r->n_roi;
   const uint64_t beg = c.off[f];
   const float4* __restrict__ P = c.roi + beg;
-  uint32_t* gparent = c.uf_parent + beg;
-  uint32_t* parent = LDS_PARENT ? lds_parent : gparent;
+  uint32_t* parent = lds_parent;
   uint32_t* count = c.uf_count + beg;   // zeroed below, together with the parents
   const float tol2 = (float)(c.p.cluster_tol * c.p.cluster_tol);
   const uint32_t tid = threadIdx.x;
@@ -123,7 +129,7 @@ __device__ void cluster_frame(const Ctx& c, uint32_t f, uint32_t* lds_parent, fl
   float3 blo = make_float3(0.f, 0.f, 0.f);
   int gnx = 1, gny = 1, gnz = 1;
   const float inv_cell_d = 1.0f / ((float)c.p.cluster_tol * 1.001f);
-  if (LDS_PARENT && M <= (uint32_t)kClusterGridMax && M > (uint32_t)kClusterAllPairsMax) {
+  if (M > (uint32_t)kClusterAllPairsMax) {
     float3 lo = make_float3(3.0e38f, 3.0e38f, 3.0e38f), hi = make_float3(-3.0e38f, -3.0e38f, -3.0e38f);
     for (uint32_t i = tid; i < M; i += kFrameThreads) {
       const float4 q = P[i];
@@ -163,10 +169,10 @@ __device__ void cluster_frame(const Ctx& c, uint32_t f, uint32_t* lds_parent, fl
     // the other -- every lane busy, a fifth of the LDS traffic of a per-point scan.  Pairs that pass the cheap
     // parent test are queued and united 64 at a time (a union is two chains of dependent LDS atomics; done in
     // place it would stall the wavefront for one lane).  Same pairs, same distance arithmetic, same partition.
-    uint32_t* key = lds_parent + kClusterGridMax;                               // cell of point i
-    uint16_t* cur16 = reinterpret_cast<uint16_t*>(lds_parent + 2 * kClusterGridMax);   // kClusterCells run ends
-    uint32_t* cur32 = lds_parent + 2 * kClusterGridMax;                          // the same words, two cells each
-    uint16_t* occ = reinterpret_cast<uint16_t*>(s_pts + kClusterGridMax);       // occupied cells (<= M), 8 KiB
+    uint32_t* key = lds_parent + cap;                               // cell of point i
+    uint16_t* cur16 = reinterpret_cast<uint16_t*>(lds_parent + 2 * cap);   // kClusterCells run ends
+    uint32_t* cur32 = lds_parent + 2 * cap;                          // the same words, two cells each
+    uint16_t* occ = reinterpret_cast<uint16_t*>(s_pts + cap);       // occupied cells (<= M)
     uint32_t* n_occ = sc + 120;
     if (tid == 0) *n_occ = 0;
     for (uint32_t k = tid; k < (uint32_t)kClusterCells / 2; k += kFrameThreads) cur32[k] = 0u;
@@ -327,7 +333,7 @@ __device__ void cluster_frame(const Ctx& c, uint32_t f, uint32_t* lds_parent, fl
     if (f == 0 && lane == 0) printf("K2 f0 wave %d: iterations %llu pushes %llu flushes %llu cycles in flushes %llu\n", (int)wave_id(), n_iter, n_push, n_flush, t_flush);
     if (f == 0 && tid == 0) printf("K2 f0 direct: box+build %llu walk %llu cycles, occupied cells %u, grid %d x %d x %d\n", tmark[8] - tmark[1], tmark[9] - tmark[8], cells_occ, gnx, gny, gnz);
 #endif
-  } else if (LDS_PARENT && M <= (uint32_t)kClusterGridMax && M > (uint32_t)kClusterAllPairsMax) {
+  } else if (M > (uint32_t)kClusterAllPairsMax) {
     // ---- cell lists in LDS (the ROI case).  Cells of (slightly more than) the tolerance, hashed into 8192
     // buckets; the points are counting-sorted by bucket INTO LDS (xyz + original index), so a bucket is a
     // contiguous run.  One task per (neighbouring cell offset, point in sorted order): the 64 lanes of a
@@ -335,8 +341,8 @@ __device__ void cluster_frame(const Ctx& c, uint32_t f, uint32_t* lds_parent, fl
     // same run (identical LDS addresses: broadcasts, no bank conflicts, equal trip counts).  Same pairs, same
     // distance arithmetic, same partition as the other two searches; union-find indices stay the original
     // ones, so roots (smallest member index) and labels are unchanged.
-    uint32_t* key = lds_parent + kClusterGridMax;          // bucket of point i
-    uint32_t* cur = lds_parent + 2 * kClusterGridMax;      // kClusterGridBuckets words: counts -> run ends
+    uint32_t* key = lds_parent + cap;          // bucket of point i
+    uint32_t* cur = lds_parent + 2 * cap;      // kClusterGridBuckets words: counts -> run ends
     float3 lo = make_float3(3.0e38f, 3.0e38f, 3.0e38f);
     for (uint32_t i = tid; i < M; i += kFrameThreads) {
       const float4 q = P[i];
@@ -486,75 +492,6 @@ __device__ void cluster_frame(const Ctx& c, uint32_t f, uint32_t* lds_parent, fl
       const uint2 e = wq[lane];
       uf_unite(parent, e.x, e.y);
     }
-  } else if (M > (uint32_t)kClusterAllPairsMax) {
-    // ---- spatial hash: cells of (slightly more than) the tolerance, buckets chained through
-    // `next`; every point tests the 27 cells around its own.  Bucket order depends on the race of
-    // the insertions, the resulting partition does not.
-    float3 lo = make_float3(3.0e38f, 3.0e38f, 3.0e38f);
-    for (uint32_t i = tid; i < M; i += kFrameThreads) {
-      const float4 q = P[i];
-      lo.x = fminf(lo.x, q.x);
-      lo.y = fminf(lo.y, q.y);
-      lo.z = fminf(lo.z, q.z);
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      lo.x = fminf(lo.x, __shfl_xor(lo.x, o, ILCC_WAVE));
-      lo.y = fminf(lo.y, __shfl_xor(lo.y, o, ILCC_WAVE));
-      lo.z = fminf(lo.z, __shfl_xor(lo.z, o, ILCC_WAVE));
-    }
-    float* scf = reinterpret_cast<float*>(sc);
-    __syncthreads();
-    if (lane_id() == 0) {
-      scf[wave_id()] = lo.x;
-      scf[16 + wave_id()] = lo.y;
-      scf[32 + wave_id()] = lo.z;
-    }
-    __syncthreads();
-    for (int w = 0; w < kFrameThreads / ILCC_WAVE; ++w) {
-      lo.x = fminf(lo.x, scf[w]);
-      lo.y = fminf(lo.y, scf[16 + w]);
-      lo.z = fminf(lo.z, scf[32 + w]);
-    }
-    __syncthreads();
-    const float inv_cell = 1.0f / ((float)c.p.cluster_tol * 1.001f);
-    uint32_t* head = c.uf_hash_head + (uint64_t)f * kClusterHashSize;
-    uint32_t* next = c.uf_hash_next + beg;
-    for (uint32_t k = tid; k < (uint32_t)kClusterHashSize; k += kFrameThreads) head[k] = 0xFFFFFFFFu;
-    __syncthreads();
-    for (uint32_t i = tid; i < M; i += kFrameThreads) {
-      const float4 q = P[i];
-      const int cx = (int)floorf((q.x - lo.x) * inv_cell), cy = (int)floorf((q.y - lo.y) * inv_cell),
-                cz = (int)floorf((q.z - lo.z) * inv_cell);
-      next[i] = atomicExch(&head[cell_hash(cx, cy, cz)], i);
-    }
-    __syncthreads();
-    for (uint32_t i = tid; i < M; i += kFrameThreads) {
-      const float4 pi = P[i];
-      const int cx = (int)floorf((pi.x - lo.x) * inv_cell), cy = (int)floorf((pi.y - lo.y) * inv_cell),
-                cz = (int)floorf((pi.z - lo.z) * inv_cell);
-      for (int dz = -1; dz <= 1; ++dz)
-        for (int dy = -1; dy <= 1; ++dy)
-          for (int dx = -1; dx <= 1; ++dx) {
-            const int nx = cx + dx, ny = cy + dy, nz = cz + dz;
-            uint32_t j = __hip_atomic_load(&head[cell_hash(nx, ny, nz)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            while (j != 0xFFFFFFFFu) {
-              if (j < i) {   // each pair once
-                const float4 q = P[j];
-                const float ex = q.x - pi.x, ey = q.y - pi.y, ez = q.z - pi.z;
-                float d2 = ex * ex;
-                d2 = d2 + ey * ey;
-                d2 = d2 + ez * ez;
-                if (d2 < tol2) {
-                  const uint32_t qi = __hip_atomic_load(&parent[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                  const uint32_t qj = __hip_atomic_load(&parent[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                  if (qi != qj) uf_unite(parent, i, j);
-                }
-              }
-              j = next[j];
-            }
-          }
-    }
   } else {
   // ---- all pairs (j < i), tiles of 1024
     for (uint32_t ic = 0; ic < M; ic += kFrameThreads) {
@@ -593,8 +530,24 @@ __device__ void cluster_frame(const Ctx& c, uint32_t f, uint32_t* lds_parent, fl
     __syncthreads();
   }
   __syncthreads();
-
   K2_MARK(2);
+  cluster_finish<true>(c, f, parent, sc);
+}
+
+// Labels, component sizes, exact 1-NN of the click, the reference's choice rule, compaction: shared by the LDS path
+// (parent = the workgroup's LDS parents) and the multi-workgroup path (parent = the frame's global parents).
+template <bool LDS_PARENT>
+__device__ void cluster_finish(const Ctx& c, uint32_t f, uint32_t* parent, uint32_t* sc) {
+  ilcc_result* r = &c.res[f];
+  const uint32_t M = (uint32_t)r->n_roi;
+  const uint64_t beg = c.off[f];
+  const float4* __restrict__ P = c.roi + beg;
+  uint32_t* gparent = c.uf_parent + beg;
+  uint32_t* count = c.uf_count + beg;
+  const uint32_t tid = threadIdx.x;
+#ifdef ILCC_K2_TIMING
+  __shared__ unsigned long long tmark[12];
+#endif
   // ---- flatten: label = root (smallest member index)
   for (uint32_t base = 0; base < M; base += kFrameThreads) {
     const uint32_t i = base + tid;
@@ -732,39 +685,180 @@ __device__ void cluster_frame(const Ctx& c, uint32_t f, uint32_t* lds_parent, fl
   K2_MARK(7);
 #ifdef ILCC_K2_TIMING
   if (f == 0 && tid == 0)
-    printf("K2 f0 M=%u cycles: init %llu search %llu flatten %llu count %llu nn %llu largest %llu compact %llu total %llu\n", M,
-           tmark[1] - tmark[0], tmark[2] - tmark[1], tmark[3] - tmark[2], tmark[4] - tmark[3], tmark[5] - tmark[4],
-           tmark[6] - tmark[5], tmark[7] - tmark[6], tmark[7] - tmark[0]);
+    printf("K2 f0 M=%u cycles: flatten %llu count %llu nn %llu largest %llu compact %llu\n", M, tmark[3] - tmark[2],
+           tmark[4] - tmark[3], tmark[5] - tmark[4], tmark[6] - tmark[5], tmark[7] - tmark[6]);
 #endif
+}
+
+// ------------------------------------------------------------------ frames above the LDS capacity: several workgroups per frame
+constexpr int kBigChunk = 256;        // points per work item
+constexpr int kBigBlock = 1024;       // listed frames whose chunk prefix sums a workgroup keeps in LDS at a time
+
+// calls fn(f, first point of the chunk) for this workgroup's share of the (listed frame, chunk) items; every thread
+// of the workgroup makes the same calls
+template <typename Fn>
+__device__ __forceinline__ void for_each_big_chunk(const Ctx& c, uint32_t* s_pref, Fn fn) {
+  const uint32_t nbig = __hip_atomic_load(c.big_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (uint32_t base = 0; base < nbig; base += kBigBlock) {
+    const uint32_t nb = min((uint32_t)kBigBlock, nbig - base);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t run = 0;
+      for (uint32_t j = 0; j < nb; ++j) {
+        s_pref[j] = run;
+        run += ((uint32_t)c.res[c.big_list[base + j]].n_roi + kBigChunk - 1) / kBigChunk;
+      }
+      s_pref[nb] = run;
+    }
+    __syncthreads();
+    const uint32_t total = s_pref[nb];
+    for (uint32_t item = blockIdx.x; item < total; item += gridDim.x) {
+      uint32_t lo = 0, hi = nb;   // last j with s_pref[j] <= item
+      while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (s_pref[mid] <= item) lo = mid; else hi = mid;
+      }
+      fn(c.big_list[base + lo], (item - s_pref[lo]) * kBigChunk);
+    }
+  }
+}
+
+__device__ __forceinline__ void big_cell(const Ctx& c, const float4& q, int& cx, int& cy, int& cz) {
+  const float inv_cell = 1.0f / ((float)c.p.cluster_tol * 1.001f);   // cells of slightly more than the tolerance
+  cx = (int)floorf(q.x * inv_cell);
+  cy = (int)floorf(q.y * inv_cell);
+  cz = (int)floorf(q.z * inv_cell);
+}
+
+// spatial hash of a frame: buckets chained through `next` (bucket order depends on the race of the insertions, the
+// resulting partition does not)
+__device__ __forceinline__ void big_insert_point(const Ctx& c, uint32_t f, uint32_t i) {
+  const uint64_t beg = c.off[f];
+  uint32_t* head = c.uf_hash_head + (uint64_t)f * kClusterHashSize;
+  int cx, cy, cz;
+  big_cell(c, c.roi[beg + i], cx, cy, cz);
+  c.uf_hash_next[beg + i] = atomicExch(&head[cell_hash(cx, cy, cz)], i);
+}
+
+// point i tests the 27 cells around its own; pairs within the tolerance whose parents differ are united
+__device__ __forceinline__ void big_search_point(const Ctx& c, uint32_t f, uint32_t i, float tol2) {
+  const uint64_t beg = c.off[f];
+  const float4* __restrict__ P = c.roi + beg;
+  uint32_t* parent = c.uf_parent + beg;
+  const uint32_t* head = c.uf_hash_head + (uint64_t)f * kClusterHashSize;
+  const uint32_t* next = c.uf_hash_next + beg;
+  const float4 pi = P[i];
+  int cx, cy, cz;
+  big_cell(c, pi, cx, cy, cz);
+  for (int dz = -1; dz <= 1; ++dz)
+    for (int dy = -1; dy <= 1; ++dy)
+      for (int dx = -1; dx <= 1; ++dx) {
+        uint32_t j = __hip_atomic_load(&head[cell_hash(cx + dx, cy + dy, cz + dz)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while (j != 0xFFFFFFFFu) {
+          if (j < i) {   // each pair once
+            const float4 q = P[j];
+            const float ex = q.x - pi.x, ey = q.y - pi.y, ez = q.z - pi.z;
+            float d2 = ex * ex;
+            d2 = d2 + ey * ey;
+            d2 = d2 + ez * ez;
+            if (d2 < tol2) {
+              const uint32_t qi = __hip_atomic_load(&parent[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              const uint32_t qj = __hip_atomic_load(&parent[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              if (qi != qj) uf_unite(parent, i, j);
+            }
+          }
+          j = next[j];
+        }
+      }
+}
+
+__global__ __launch_bounds__(kBigChunk) void k2l_insert(Ctx c) {
+  __shared__ uint32_t s_pref[kBigBlock + 1];
+  for_each_big_chunk(c, s_pref, [&](uint32_t f, uint32_t first) {
+    const uint32_t i = first + threadIdx.x;
+    if (i < (uint32_t)c.res[f].n_roi) big_insert_point(c, f, i);
+  });
+}
+
+__global__ __launch_bounds__(kBigChunk) void k2l_search(Ctx c) {
+  __shared__ uint32_t s_pref[kBigBlock + 1];
+  const float tol2 = (float)(c.p.cluster_tol * c.p.cluster_tol);
+  for_each_big_chunk(c, s_pref, [&](uint32_t f, uint32_t first) {
+    const uint32_t i = first + threadIdx.x;
+    if (i < (uint32_t)c.res[f].n_roi) big_search_point(c, f, i, tol2);
+  });
+}
+
+__global__ __launch_bounds__(kFrameThreads) void k2l_finish(Ctx c) {
+  __shared__ uint32_t sc[128];
+  const uint32_t nbig = __hip_atomic_load(c.big_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (blockIdx.x >= nbig) return;
+  const uint32_t f = c.big_list[blockIdx.x];
+  cluster_finish<false>(c, f, c.uf_parent + c.off[f], sc);
 }
 
 __global__ __launch_bounds__(kFrameThreads) void k2_seeded_cluster(Ctx c) {
   extern __shared__ __align__(16) unsigned char smem[];
+  const uint32_t cap = c.cluster_lds_points;
   float4* tile = reinterpret_cast<float4*>(smem);                          // 16 KiB
   uint32_t* sc = reinterpret_cast<uint32_t*>(smem + sizeof(float4) * kFrameThreads);  // 128 words
-  uint32_t* lds_parent = sc + 128;                                          // 64 KiB
-  float4* s_pts = reinterpret_cast<float4*>(lds_parent + kClusterLdsParents);  // 64 KiB (cell-list path)
+  uint32_t* lds_parent = sc + 128;                                          // cap parents, cap keys, 32 KiB of cell run ends
+  float4* s_pts = reinterpret_cast<float4*>(lds_parent + 2 * cap + kClusterCells / 2);  // cap points (+ cap u16 occupied cells)
   const uint32_t f = blockIdx.x;
+  if (c.res[f].status != ILCC_OK) return;
   const uint32_t M = (uint32_t)c.res[f].n_roi;
-  if (M <= (uint32_t)kClusterLdsParents)
-    cluster_frame<true>(c, f, lds_parent, tile, sc, s_pts);
-  else
-    cluster_frame<false>(c, f, lds_parent, tile, sc, s_pts);
+  if (M <= cap) {
+    cluster_frame(c, f, lds_parent, tile, sc, s_pts, cap);
+    return;
+  }
+  // above the LDS capacity: reset the frame's parents, component counters and hash table ...
+  const uint64_t beg = c.off[f];
+  uint32_t* gparent = c.uf_parent + beg;
+  uint32_t* count = c.uf_count + beg;
+  uint32_t* head = c.uf_hash_head + (uint64_t)f * kClusterHashSize;
+  for (uint32_t i = threadIdx.x; i < M; i += kFrameThreads) {
+    gparent[i] = i;
+    count[i] = 0u;
+  }
+  for (uint32_t k = threadIdx.x; k < (uint32_t)kClusterHashSize; k += kFrameThreads) head[k] = 0xFFFFFFFFu;
+  if (c.big_armed) {
+    // ... and list the frame for the multi-workgroup kernels that follow on the stream
+    if (threadIdx.x == 0) c.big_list[atomicAdd(c.big_count, 1u)] = f;
+    return;
+  }
+  // The handle has not met such a frame yet and did not launch those kernels (on a stream of ROI-cropped VLP-16 batches
+  // their three empty launches cost 2.6 % of the frame rate): this workgroup does the same work alone -- same hash, same
+  // pairs, same partition, ~4x slower per batch of large frames -- and the handle arms the fast path for its later batches
+  // (ilcc_reserve arms it up front).
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < M; i += kFrameThreads) big_insert_point(c, f, i);
+  __syncthreads();
+  const float tol2 = (float)(c.p.cluster_tol * c.p.cluster_tol);
+  for (uint32_t i = threadIdx.x; i < M; i += kFrameThreads) big_search_point(c, f, i, tol2);
+  __syncthreads();
+  cluster_finish<false>(c, f, gparent, sc);
 }
 
-static constexpr size_t kClusterLdsBytes = sizeof(float4) * kFrameThreads + 128 * sizeof(uint32_t) +
-                                           sizeof(uint32_t) * kClusterLdsParents + sizeof(float4) * kClusterGridMax +
-                                           sizeof(uint16_t) * kClusterGridMax;
+static_assert(kClusterGridBuckets * sizeof(uint32_t) == kClusterCells * sizeof(uint16_t), "the two LDS cell-list layouts share one 32 KiB region");
+size_t cluster_lds_bytes(uint32_t cap) {
+  return sizeof(float4) * kFrameThreads + 128 * sizeof(uint32_t) + 2 * sizeof(uint32_t) * (size_t)cap + sizeof(uint16_t) * kClusterCells +
+         sizeof(float4) * (size_t)cap + sizeof(uint16_t) * (size_t)cap;
+}
 
-// 152 KiB of dynamic LDS (> the 64 KiB default cap; one 1024-thread workgroup per CU either way).  Called by
-// ilcc_create for the handle's device: the attribute is kept per (function, device).
+// up to 152.5 KiB of dynamic LDS at the largest capacity (> the 64 KiB default cap).  Called by ilcc_create for the
+// handle's device: the attribute is kept per (function, device).
 hipError_t set_kernel_attributes_k2() {
-  return hipFuncSetAttribute((const void*)k2_seeded_cluster, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kClusterLdsBytes);
+  return hipFuncSetAttribute((const void*)k2_seeded_cluster, hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)cluster_lds_bytes(kClusterLdsPointsMax));
 }
 
 void launch_cluster(const Ctx& c, hipStream_t s) {
-  const size_t lds = kClusterLdsBytes;
-  hipLaunchKernelGGL(k2_seeded_cluster, dim3(c.n_frames), dim3(kFrameThreads), lds, s, c);
+  hipLaunchKernelGGL(k2_seeded_cluster, dim3(c.n_frames), dim3(kFrameThreads), cluster_lds_bytes(c.cluster_lds_points), s, c);
+  if (!c.big_armed) return;   // no frame above the LDS capacity seen by this handle so far: see k2_seeded_cluster
+  const uint32_t grid = c.big_grid;
+  hipLaunchKernelGGL(k2l_insert, dim3(grid), dim3(kBigChunk), 0, s, c);
+  hipLaunchKernelGGL(k2l_search, dim3(grid), dim3(kBigChunk), 0, s, c);
+  hipLaunchKernelGGL(k2l_finish, dim3(c.n_frames), dim3(kFrameThreads), 0, s, c);
 }
 
 }  // namespace ilcc

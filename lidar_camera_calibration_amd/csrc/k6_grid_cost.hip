@@ -152,7 +152,7 @@ __device__ __forceinline__ Best seed_argmin(const Ctx& c, uint32_t f, uint32_t& 
   return sb;
 }
 
-template <bool OOB, bool VOLUME, bool LDS_POINTS, bool PRUNE>
+template <bool OOB, bool VOLUME, bool LDS_POINTS, bool PRUNE, int THREADS>
 __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, float2* s_ij, float* s_hw, Best* s_best,
                                                uint32_t* s_iters, uint32_t* s_cnt, float* s_ay, float* s_az) {
   const uint32_t f = blockIdx.y;
@@ -221,8 +221,8 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
     uint32_t base_in = 0, base_out = 0;
     // slot sl <- point (sl * S) mod M, advanced chunk by chunk (M <= 8192 here: the products fit 32 bits)
     uint32_t pidx = M ? (threadIdx.x * S) % M : 0u;
-    const uint32_t pstep = M ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(((uint32_t)kGridThreads * S) % M)) : 0u;
-    for (uint32_t c0 = 0; c0 < M; c0 += kGridThreads) {
+    const uint32_t pstep = M ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(((uint32_t)THREADS * S) % M)) : 0u;
+    for (uint32_t c0 = 0; c0 < M; c0 += THREADS) {
       const uint32_t sl = c0 + threadIdx.x;
       const bool valid = sl < M;
       float2 ij = make_float2(0.f, 0.f);
@@ -251,7 +251,7 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
       __syncthreads();
       uint32_t pre_in = 0, pre_out = 0, tot_in = 0, tot_out = 0;
 #pragma unroll
-      for (int w = 0; w < kGridThreads / ILCC_WAVE; ++w) {
+      for (int w = 0; w < THREADS / ILCC_WAVE; ++w) {
         const uint32_t a = s_iters[w], b = s_cnt[w];
         if (w < wid) {
           pre_in += a;
@@ -274,8 +274,8 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
   }
   // (ty, tz) tables in LDS: a cut-short tile lasts about as long as one L2 round trip, so its
   // prologue must not wait for global loads
-  for (int i = threadIdx.x; i < c.p.n_ty; i += kGridThreads) s_ay[i] = c.ay[i];
-  for (int i = threadIdx.x; i < c.p.n_tz; i += kGridThreads) s_az[i] = c.az[i];
+  for (int i = threadIdx.x; i < c.p.n_ty; i += THREADS) s_ay[i] = c.ay[i];
+  for (int i = threadIdx.x; i < c.p.n_tz; i += THREADS) s_az[i] = c.az[i];
   __syncthreads();
   [[maybe_unused]] const unsigned long long t_staged = K6_NOW();
 
@@ -301,7 +301,7 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
   int tb = __builtin_amdgcn_readfirstlane(t_first - ta * ntb);
   const int ntb_s = __builtin_amdgcn_readfirstlane(ntb), nta_s = __builtin_amdgcn_readfirstlane(nta);
   auto advance = [&]() {   // to this wavefront's next tile
-    tb += kGridThreads / ILCC_WAVE;
+    tb += THREADS / ILCC_WAVE;
     while (tb >= ntb_s) {
       tb -= ntb_s;
       ++ta;
@@ -550,7 +550,7 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
   // only the surviving tiles into the quad-sliced loop.  An instruction-count model from simulated death times promised
   // -12 %; on the chip: 85 instead of 72 VGPRs (5 instead of 7 waves per SIMD) and sixteen serial evaluations per lane:
   // 0.611 instead of 0.564 ms per batch, 235 k instead of 250.6 k frames/s.)
-  for (int tt = wid; tt < n_tiles; tt += kGridThreads / ILCC_WAVE) {
+  for (int tt = wid; tt < n_tiles; tt += THREADS / ILCC_WAVE) {
     const int tile_a = ta, tile_b = tb;
     advance();
 #ifdef ILCC_K6_TIMING
@@ -597,14 +597,14 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
   __syncthreads();
   if (threadIdx.x == 0) {
     uint32_t it_sum = 0, in_sum = 0;
-    for (int w = 0; w < kGridThreads / ILCC_WAVE; ++w) {
+    for (int w = 0; w < THREADS / ILCC_WAVE; ++w) {
       it_sum += s_iters[w];
       in_sum += s_cnt[w];
     }
     atomicAdd(c.grid_iters + (f & (kIterSlots - 1)), (unsigned long long)it_sum);   // spread over 64 words
     atomicAdd(c.grid_iters + kIterSlots + (f & (kIterSlots - 1)), (unsigned long long)in_sum);
     Best b = s_best[0];
-    for (int w = 1; w < kGridThreads / ILCC_WAVE; ++w)
+    for (int w = 1; w < THREADS / ILCC_WAVE; ++w)
       if (better(s_best[w].cost, s_best[w].d2, s_best[w].flat, b)) b = s_best[w];
     out->cost = b.cost;
     out->d2 = b.d2;
@@ -620,7 +620,7 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
 #ifdef ILCC_K6_TIMING
   if (lane == 0 && c.tie_count != nullptr) {   // the full pass only
     const unsigned long long t_end = K6_NOW();
-    const uint32_t w = ((f * c.grid_blocks + blockIdx.x) * (kGridThreads / ILCC_WAVE) + (uint32_t)wid) & (kProfWaves - 1);
+    const uint32_t w = ((f * c.grid_blocks + blockIdx.x) * (THREADS / ILCC_WAVE) + (uint32_t)wid) & (kProfWaves - 1);
     unsigned long long* o = k6_prof + (size_t)w * kProfWords;
     o[0] = 1ull;
     o[1] = t_end - t_entry;
@@ -640,21 +640,24 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
 
 // dynamic LDS: [grid_lds_points float2][grid_lds_points float][n_ty + n_tz floats]; frames with more
 // labelled points than the staged capacity read (and rotate) them through L1/L2 instead.
-template <bool OOB, bool VOLUME, bool PRUNE>
-__global__ __launch_bounds__(kGridThreads) void k6_grid_cost(Ctx c, float* volume) {
+// THREADS: 256 (4 wavefronts) is the measured optimum for VLP-16-sized frames; frames of several thousand labelled points
+// (BASELINE config 5: 4 198) stage 50+ KB per workgroup, three workgroups fit a CU, and 512 threads then double the
+// resident wavefronts per SIMD (3 -> 6).  Same sums either way: a candidate's points are added by its quad in walk order.
+template <bool OOB, bool VOLUME, bool PRUNE, int THREADS>
+__global__ __launch_bounds__(THREADS) void k6_grid_cost(Ctx c, float* volume) {
   extern __shared__ __align__(16) unsigned char smem[];
-  __shared__ Best s_best[kGridThreads / ILCC_WAVE];
-  __shared__ uint32_t s_iters[kGridThreads / ILCC_WAVE];
-  __shared__ uint32_t s_cnt[kGridThreads / ILCC_WAVE];
+  __shared__ Best s_best[THREADS / ILCC_WAVE];
+  __shared__ uint32_t s_iters[THREADS / ILCC_WAVE];
+  __shared__ uint32_t s_cnt[THREADS / ILCC_WAVE];
   float2* s_ij = reinterpret_cast<float2*>(smem);
   float* s_hw = reinterpret_cast<float*>(smem + sizeof(float2) * (size_t)c.grid_lds_points);
   float* s_ay = s_hw + c.grid_lds_points;   // n_ty floats
   float* s_az = s_ay + c.p.n_ty;            // n_tz floats
   const uint32_t M = c.n_lab[blockIdx.y];
   if (M <= c.grid_lds_points)
-    grid_cost_body<OOB, VOLUME, true, PRUNE>(c, volume, s_ij, s_hw, s_best, s_iters, s_cnt, s_ay, s_az);
+    grid_cost_body<OOB, VOLUME, true, PRUNE, THREADS>(c, volume, s_ij, s_hw, s_best, s_iters, s_cnt, s_ay, s_az);
   else
-    grid_cost_body<OOB, VOLUME, false, PRUNE>(c, volume, s_ij, s_hw, s_best, s_iters, s_cnt, s_ay, s_az);
+    grid_cost_body<OOB, VOLUME, false, PRUNE, THREADS>(c, volume, s_ij, s_hw, s_best, s_iters, s_cnt, s_ay, s_az);
 }
 
 #ifdef ILCC_K6_TIMING
@@ -678,9 +681,10 @@ uint32_t grid_cost_evals_per_count() { return kTile * kTile; }
 // allow > 64 KiB of dynamic LDS (gfx950 has 160 KiB per CU): the staged points plus the (ty, tz) tables, whose
 // combined length params_ok bounds by kGridTableMax.  Called by ilcc_create for the handle's device.
 hipError_t set_kernel_attributes_k6() {
-  const void* fns[] = {(const void*)k6_grid_cost<true, true, false>,  (const void*)k6_grid_cost<true, false, false>,
-                       (const void*)k6_grid_cost<false, true, false>, (const void*)k6_grid_cost<false, false, false>,
-                       (const void*)k6_grid_cost<true, false, true>,  (const void*)k6_grid_cost<false, false, true>};
+  const void* fns[] = {(const void*)k6_grid_cost<true, true, false, kGridThreads>,  (const void*)k6_grid_cost<true, false, false, kGridThreads>,
+                       (const void*)k6_grid_cost<false, true, false, kGridThreads>, (const void*)k6_grid_cost<false, false, false, kGridThreads>,
+                       (const void*)k6_grid_cost<true, false, true, kGridThreads>,  (const void*)k6_grid_cost<false, false, true, kGridThreads>,
+                       (const void*)k6_grid_cost<true, false, true, kGridThreadsLarge>};
   const int cap = (int)((sizeof(float2) + sizeof(float)) * (size_t)kGridLdsPointsMax + sizeof(float) * (size_t)kGridTableMax);
   for (const void* fn : fns) {
     const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
@@ -695,19 +699,21 @@ void launch_grid_cost(const Ctx& c, hipStream_t s, int32_t use_oob, float* cost_
   // the diagnostic volume is always a complete evaluation (no pruning)
   if (cost_volume) {
     if (use_oob)
-      hipLaunchKernelGGL((k6_grid_cost<true, true, false>), grid, block, lds, s, c, cost_volume);
+      hipLaunchKernelGGL((k6_grid_cost<true, true, false, kGridThreads>), grid, block, lds, s, c, cost_volume);
     else
-      hipLaunchKernelGGL((k6_grid_cost<false, true, false>), grid, block, lds, s, c, cost_volume);
+      hipLaunchKernelGGL((k6_grid_cost<false, true, false, kGridThreads>), grid, block, lds, s, c, cost_volume);
   } else if (prune) {
-    if (use_oob)
-      hipLaunchKernelGGL((k6_grid_cost<true, false, true>), grid, block, lds, s, c, cost_volume);
+    if (use_oob && c.grid_lds_points > (uint32_t)kGridLargeFrom)   // the pipeline's launches on large frames
+      hipLaunchKernelGGL((k6_grid_cost<true, false, true, kGridThreadsLarge>), grid, dim3(kGridThreadsLarge), lds, s, c, cost_volume);
+    else if (use_oob)
+      hipLaunchKernelGGL((k6_grid_cost<true, false, true, kGridThreads>), grid, block, lds, s, c, cost_volume);
     else
-      hipLaunchKernelGGL((k6_grid_cost<false, false, true>), grid, block, lds, s, c, cost_volume);
+      hipLaunchKernelGGL((k6_grid_cost<false, false, true, kGridThreads>), grid, block, lds, s, c, cost_volume);
   } else {
     if (use_oob)
-      hipLaunchKernelGGL((k6_grid_cost<true, false, false>), grid, block, lds, s, c, cost_volume);
+      hipLaunchKernelGGL((k6_grid_cost<true, false, false, kGridThreads>), grid, block, lds, s, c, cost_volume);
     else
-      hipLaunchKernelGGL((k6_grid_cost<false, false, false>), grid, block, lds, s, c, cost_volume);
+      hipLaunchKernelGGL((k6_grid_cost<false, false, false, kGridThreads>), grid, block, lds, s, c, cost_volume);
   }
 }
 

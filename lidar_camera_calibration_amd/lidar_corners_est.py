@@ -232,6 +232,13 @@ class LidarCornersBatch:
         if st != N.OK:
             raise IlccError(st, self._err())
 
+    def reserve(self, labelled_points_per_frame: int, roi_points_per_frame: int):
+        """ilcc_reserve: size the on-chip staging (grid search: labelled points; clustering: ROI points) up front, so the
+        first batch takes the same kernels as a warmed handle.  Results never depend on it."""
+        st = self._lib.ilcc_reserve(self._h, int(labelled_points_per_frame), int(roi_points_per_frame))
+        if st != N.OK:
+            raise IlccError(st, self._err())
+
     def extract(self, clouds: np.ndarray, clicks: np.ndarray, offsets: Optional[np.ndarray] = None):
         """clouds: [F,N,4] (or [total,4] with ``offsets`` [F+1]); clicks: [F,3].  Returns Result array."""
         clouds = np.ascontiguousarray(clouds, dtype=np.float32)

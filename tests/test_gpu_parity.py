@@ -535,6 +535,77 @@ def test_large_roi_takes_the_global_memory_paths(ob):
     e.close()
 
 
+def test_large_roi_one_workgroup_and_multi_workgroup_clustering_agree(ob):
+    """K2 above its LDS capacity: a fresh handle has not armed the multi-workgroup kernels (the frame's own workgroup
+    does the work), a reserved / warmed one launches them -- identical clusters, planes and corners, and both equal
+    to the oracle (previous test)."""
+    board = synth.Board(9, 12, 0.10)
+    rng = np.random.default_rng(33)
+    clouds, clicks = [], []
+    for k in range(3):
+        pose = synth.random_pose(rng, range_m=(2.0, 2.6), yaw_deg=10, pitch_deg=8, roll_deg=20)
+        clouds.append(synth.make_frame(synth.hdl64(), board, pose, 40 + k))
+        clicks.append(synth.make_click(pose, 40 + k))
+    clouds, clicks = np.stack(clouds), np.stack(clicks)
+    p = N.default_params()
+    p.board_w, p.board_h, p.grid_length = 9, 12, 0.10
+    p.n_th, p.n_ty, p.n_tz = 9, 8, 8
+    p.th_min, p.th_step = -0.04, 0.01
+    p.ty_min = p.tz_min = -0.04
+    p.ty_step = p.tz_step = 0.01
+    cold = LidarCornersBatch(3, 131072, p)
+    r_cold = cold.extract(clouds, clicks)            # unarmed: one workgroup per large frame
+    r_warm = cold.extract(clouds, clicks)            # the handle has seen n_roi > 4096: multi-workgroup kernels
+    res = LidarCornersBatch(3, 131072, p)
+    res.reserve(4500, 25000)
+    r_res = res.extract(clouds, clicks)              # armed up front
+    assert min(r.n_roi for r in r_cold) > 4096
+    for a, b, c in zip(r_cold, r_warm, r_res):
+        for r in (b, c):
+            assert (a.status, a.n_roi, a.n_cluster, a.n_plane, a.grid_index) == (r.status, r.n_roi, r.n_cluster, r.n_plane, r.grid_index)
+            assert tuple(a.theta_t) == tuple(r.theta_t) and np.array_equal(a.corners_array(), r.corners_array())
+    for f in range(3):
+        assert np.array_equal(cold.fetch_cloud(f, N.CLOUD_CLUSTER), res.fetch_cloud(f, N.CLOUD_CLUSTER))
+    cold.close()
+    res.close()
+
+
+def test_reserved_handle_runs_its_first_batch_like_a_warmed_one(frames):
+    """ilcc_reserve: the staging capacities no longer depend on what the handle has seen.  A frame
+    with more labelled points than a fresh handle's 1024 takes K6's LDS walk on the FIRST call of a reserved handle,
+    exactly like on a warmed one: same results, interior-class evaluations counted (the L2 walk has one class only),
+    executed evaluations within the run-to-run spread of the branch and bound."""
+    board = synth.Board()
+    rng = np.random.default_rng(77)
+    clouds, clicks = [], []
+    for k in range(4):
+        pose = synth.random_pose(rng, range_m=(2.0, 2.2), yaw_deg=5, pitch_deg=5, roll_deg=10)   # close: > 1024 labelled points
+        clouds.append(synth.make_frame(synth.vlp16(), board, pose, 700 + k))
+        clicks.append(synth.make_click(pose, 700 + k))
+    clouds, clicks = np.stack(clouds), np.stack(clicks)
+    warm = LidarCornersBatch(4, 28800, N.default_params())
+    r0 = warm.extract(clouds, clicks)
+    assert max(r.n_black + r.n_white for r in r0) > 1024
+    cold_t = warm.timing()
+    assert cold_t.grid_cost_evals_interior_sum == 0          # the fresh handle walked the points through L2
+    warm.reset_timing()
+    r1 = warm.extract(clouds, clicks)
+    t1 = warm.timing()
+    res = LidarCornersBatch(4, 28800, N.default_params())
+    res.reserve(2048, 2560)
+    r2 = res.extract(clouds, clicks)
+    t2 = res.timing()
+    assert t1.grid_cost_evals_interior_sum > 0 and t2.grid_cost_evals_interior_sum > 0
+    assert abs(int(t1.grid_cost_evals_sum) - int(t2.grid_cost_evals_sum)) <= 0.05 * t1.grid_cost_evals_sum
+    assert abs(int(t1.grid_cost_evals_interior_sum) - int(t2.grid_cost_evals_interior_sum)) <= 0.05 * t1.grid_cost_evals_interior_sum
+    for a, b, c in zip(r0, r1, r2):
+        assert (a.status, a.grid_index) == (b.status, b.grid_index) == (c.status, c.grid_index)
+        assert tuple(a.theta_t) == tuple(b.theta_t) == tuple(c.theta_t)
+        assert np.array_equal(b.corners_array(), c.corners_array())
+    warm.close()
+    res.close()
+
+
 def test_cluster_size_gates_and_non_finite_points(ob, frames):
     """EuclideanClusterExtraction's [min, max] size gate: when the click's component is inadmissible the
     largest admissible one is taken (plane_index 0); NaN/inf points never reach the clustering."""

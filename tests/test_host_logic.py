@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     lib = N.lib()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.ilcc_abi_version() == 2
+    assert lib.ilcc_abi_version() == 3
 
 
 def test_calib_library_exports_every_declared_symbol():
