@@ -17,7 +17,7 @@ MAX_CORNERS = 256
 
 OK, NO_ROI_POINTS, NO_CLUSTER, NO_PLANE, DEGENERATE_HIST, TOO_FEW_POINTS, BAD_ARGUMENT, CAPACITY, \
     HIP_ERROR, IO_ERROR, BOARD_NOT_FOUND, AMBIGUOUS = range(12)
-FLAG_TIE_OVERFLOW, FLAG_REFINE_CAPPED = 1, 2
+FLAG_TIE_OVERFLOW, FLAG_REFINE_CAPPED, FLAG_LOW_COVERAGE = 1, 2, 4
 RECORD_HEADER = 20
 COST_Q_ONE = float(1 << 40)
 SOLVER_REFERENCE_LOCAL, SOLVER_GRID = 0, 1
@@ -60,6 +60,7 @@ class Params(C.Structure):
         ("refine_th_margin", C.c_int32), ("reserved0", C.c_int32),
         ("ambiguity_eps", C.c_double),
         ("online_cluster_tol", C.c_double),
+        ("min_cell_coverage", C.c_double),
     ]
 
 
@@ -84,6 +85,8 @@ class Result(C.Structure):
         ("basin_margin", C.c_double),
         ("flags", C.c_int32),
         ("grid_ties", C.c_int32),
+        ("cells_hit", C.c_int32),
+        ("n_oob", C.c_int32),
         ("corners", C.c_float * (MAX_CORNERS * 3)),
     ]
 

@@ -131,6 +131,8 @@ bool params_ok(const ilcc_params& p, std::string& why) {
   if (p.refine_th_margin < 0 || p.refine_th_margin > 4096) return bad("refine_th_margin");
   if (!(p.online_cluster_tol > 0)) return bad("online_cluster_tol must be > 0");
   if (!(p.ambiguity_eps == p.ambiguity_eps)) return bad("ambiguity_eps is NaN");
+  if (!(p.min_cell_coverage == p.min_cell_coverage) || p.min_cell_coverage > 1.0) return bad("min_cell_coverage must be <= 1");
+  if (p.board_w * p.board_h > kCoverageCellsMax) return bad("board has more squares than the coverage mask holds");
   if ((uint64_t)p.n_th * p.n_ty * p.n_tz * 2ull >= 0xFFFFFFFFull) return bad("grid too large");
   if (!(p.th_step > 0) || !(p.ty_step > 0) || !(p.tz_step > 0)) return bad("grid steps must be > 0");
   return true;
@@ -618,6 +620,7 @@ void ilcc_default_params(ilcc_params* p) {
   p->refine_th_margin = 32;
   p->ambiguity_eps = 1.0;
   p->online_cluster_tol = 0.10;   // LidarCornersEst.cpp:80
+  p->min_cell_coverage = 0.9;
 }
 
 // Minimal OpenCV-FileStorage YAML reader for the three scalar keys the path uses

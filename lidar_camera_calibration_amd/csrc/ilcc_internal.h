@@ -57,6 +57,7 @@ constexpr int kRefineThreads = ILCC_K7R_THREADS;   // K7r: one workgroup per fra
 constexpr int kRefineList = 32;        // K7r: candidates evaluated per sweep over the points
 constexpr int kTieCap = 256;           // K6 -> K7a: near-tie candidates kept per frame for the fp64 recount
 constexpr float kTieEps = 2e-5f;       // relative cost window of a near-tie (fp32 sums of ~1e3 terms agree to ~1e-6)
+constexpr int kCoverageCellsMax = 1024;   // K7b: board squares tracked by the coverage mask (board_w x board_h)
 constexpr int kIterSlots = 64;         // K6 executed-iteration counters (spread to avoid one hot atomic); [0,64): all points, [64,128): interior-class points
 #ifndef ILCC_K2_ALLPAIRS_MAX
 #define ILCC_K2_ALLPAIRS_MAX 256

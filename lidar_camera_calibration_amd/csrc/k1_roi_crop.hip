@@ -64,6 +64,7 @@ __global__ __launch_bounds__(kCropThreads) void k1_roi_count(Ctx c) {
     r->phase = 0;
     r->iters_a = r->iters_b = 0;
     r->grid_index = -1;
+    r->cells_hit = r->n_oob = 0;
     r->grid_cost = 0.f;
     r->cost_a = r->cost_b = r->sel_cost = 0.0;
     r->theta_t[0] = r->theta_t[1] = r->theta_t[2] = 0.0;

@@ -1054,6 +1054,8 @@ __device__ __forceinline__ void inv_rigid_apply(const float* T, const float in[3
 
 __global__ __launch_bounds__(kSolveThreads) void k7b_corners(Ctx c, const SolveRec* rec, int n_slots) {
   __shared__ float s_T[16];
+  __shared__ uint32_t s_hit[kCoverageCellsMax / 32];
+  __shared__ uint32_t s_oob;
   const uint32_t f = blockIdx.x;
   ilcc_result* r = &c.res[f];
   if (r->status != ILCC_OK) return;
@@ -1087,10 +1089,41 @@ __global__ __launch_bounds__(kSolveThreads) void k7b_corners(Ctx c, const SolveR
     const float E = cosf(roll), F = sinf(roll);
     const float T[16] = {1, 0, 0, 0, 0, E, -F, (float)best.x[1], 0, F, E, (float)best.x[2], 0, 0, 0, 1};
     for (int k = 0; k < 16; ++k) s_T[k] = T[k];
+    s_oob = 0u;
   }
+  for (int k = (int)tid; k < kCoverageCellsMax / 32; k += kSolveThreads) s_hit[k] = 0u;
   __syncthreads();
 
   const int W = c.p.board_w, H = c.p.board_h;
+  // Coverage of the virtual board by the labelled points (orc_coverage): the functor's own coordinates
+  // (Optimization.h:37-49) in double.  What the operator checks at the viewer before pressing 'o' (:415-441).
+  {
+    const double g = c.p.grid_length, ct = cos(best.x[0]), st = sin(best.x[0]);
+    const uint32_t nl = c.n_lab[f];
+    const float2* __restrict__ yz = c.yz + beg;
+    uint32_t oob = 0;
+    for (uint32_t k = tid; k < nl; k += kSolveThreads) {
+      const float2 v = yz[k];
+      const double yy = ct * (double)v.x - st * (double)v.y + best.x[1];
+      const double zz = st * (double)v.x + ct * (double)v.y + best.x[2];
+      const double i = (yy + W * g / 2.0) / g, j = (zz + H * g / 2.0) / g;
+      if (i > 0.0 && i < (double)W && j > 0.0 && j < (double)H) {
+        const int cell = (int)floor(i) * H + (int)floor(j);
+        atomicOr(&s_hit[cell >> 5], 1u << (cell & 31));
+      } else {
+        ++oob;
+      }
+    }
+    if (oob) atomicAdd(&s_oob, oob);
+    __syncthreads();
+    if (tid == 0) {
+      int cells = 0;
+      for (int k = 0; k < (W * H + 31) / 32; ++k) cells += __popc(s_hit[k]);
+      r->cells_hit = cells;
+      r->n_oob = (int32_t)s_oob;
+      if (c.p.min_cell_coverage > 0.0 && (double)cells < c.p.min_cell_coverage * (double)(W * H)) r->flags = best.flags | ILCC_FLAG_LOW_COVERAGE;
+    }
+  }
   const int nc = (W - 1) * (H - 1);
   const int ncc = nc < ILCC_MAX_CORNERS ? nc : ILCC_MAX_CORNERS;
   for (int t = (int)tid; t < ncc; t += kSolveThreads) {

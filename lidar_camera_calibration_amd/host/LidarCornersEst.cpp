@@ -100,6 +100,13 @@ bool LidarCornersEst::get_corners(std::vector<std::array<double, 3>>& corners) {
     std::cout << "reject this scan" << std::endl;   // :439
     return false;
   }
+  if ((m_result.flags & ILCC_FLAG_LOW_COVERAGE) && !accept_ambiguous) {
+    // the second half of the operator's look at the viewer: the virtual board must sit ON the points.  With more than
+    // 10 % of the squares empty a one-square slip can fit better than the truth (include/ilcc_hip.h "accepting a frame")
+    std::cout << "reject this scan (pattern under-sampled: " << m_result.cells_hit << " of "
+              << m_params.board_w * m_params.board_h << " squares hold points)" << std::endl;
+    return false;
+  }
   m_cloud_optim = fetch(ILCC_CLOUD_OPTIM);
   m_cloud_corners.reset(new myPointCloud);
   for (int32_t i = 0; i < m_result.n_corners; ++i) {

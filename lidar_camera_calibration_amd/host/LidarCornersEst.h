@@ -40,8 +40,9 @@ class LidarCornersEst {
   void PCA();                                                 // :366-372
   bool get_corners(std::vector<std::array<double, 3>>& corners);   // :374-450
 
-  // ILCC_AMBIGUOUS scans (GRID solver: a basin one square away costs about the same): get_corners returns false
-  // unless this is set -- the automatic stand-in for the operator who would press 'r' at the viewer
+  // ILCC_AMBIGUOUS scans (GRID solver: a basin one square away costs about the same) and scans flagged
+  // ILCC_FLAG_LOW_COVERAGE (more than 10 % of the squares empty): get_corners returns false unless this is set -- the
+  // automatic stand-in for the operator who would press 'r' at the viewer
   bool accept_ambiguous = false;
 
   PointXYZI m_click_point{};

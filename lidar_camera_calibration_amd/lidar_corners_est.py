@@ -42,8 +42,8 @@ class LidarCornersEst:
         self._cloud = None
         self._click = None
         self._result: Optional[N.Result] = None
-        # ILCC_AMBIGUOUS scans (a basin one square away costs about the same): get_corners() returns False unless
-        # this is set -- the automatic stand-in for the operator who would press 'r' at the viewer
+        # ILCC_AMBIGUOUS scans (a basin one square away costs about the same) and ILCC_FLAG_LOW_COVERAGE scans (more than
+        # 10 % of the squares empty): get_corners() returns False unless this is set -- the automatic stand-in for the operator who would press 'r' at the viewer
         self.accept_ambiguous = False
         self.m_click_point = None
         self.m_cloud_ROI = self.m_cloud_chessboard = self.m_cloud_PCA = None
@@ -188,6 +188,10 @@ class LidarCornersEst:
             return False
         if res.status not in (N.OK, N.AMBIGUOUS):
             print("reject this scan")
+            return False
+        if (res.flags & N.FLAG_LOW_COVERAGE) and not self.accept_ambiguous:
+            print("reject this scan (pattern under-sampled: %d of %d squares hold points)"
+                  % (res.cells_hit, self.params.board_w * self.params.board_h))
             return False
         c = res.corners_array()
         self.m_cloud_optim = self._fetch(N.CLOUD_OPTIM)

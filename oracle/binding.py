@@ -41,6 +41,7 @@ class Params(C.Structure):
         ("refine_div", C.c_int32), ("refine_max_rounds", C.c_int32),
         ("refine_th_margin", C.c_int32), ("refine_pad_", C.c_int32),
         ("ambiguity_eps", C.c_double),
+        ("min_cell_coverage", C.c_double),
     ]
 
 
@@ -59,6 +60,7 @@ class Result(C.Structure):
         ("sel_cost", C.c_double),
         ("grid_cost", C.c_double),
         ("basin_margin", C.c_double),
+        ("flags", C.c_int32), ("cells_hit", C.c_int32), ("n_oob", C.c_int32), ("pad_", C.c_int32),
         ("pca", C.c_float * 16),
         ("corners", C.c_float * (MAX_CORNERS * 3)),
     ]
@@ -67,6 +69,7 @@ class Result(C.Structure):
 SOLVER_REFERENCE_LOCAL = 0
 SOLVER_GRID = 1
 OK, AMBIGUOUS = 0, 11
+FLAG_REFINE_CAPPED, FLAG_LOW_COVERAGE = 2, 4
 COST_Q_ONE = float(1 << 40)
 
 

@@ -53,6 +53,7 @@ void orc_default_params(orc_params* p) {
   p->tz_min = -0.15;
   p->refine_div = 16;
   p->refine_max_rounds = 64;
+  p->min_cell_coverage = 0.9;
   p->refine_th_margin = 32;
   p->ambiguity_eps = 1.0;
 }
@@ -1444,6 +1445,12 @@ static int64_t lattice_cost(const float* y, const float* z, const int8_t* label,
 
 int64_t orc_pattern_refine(const float* y, const float* z, const int8_t* label, int32_t m, const orc_params* p,
                            int32_t lat[3], int32_t* phase, int64_t* alt_cost, int32_t* rounds, int32_t* hops) {
+  return orc_pattern_refine2(y, z, label, m, p, lat, phase, alt_cost, rounds, hops, NULL);
+}
+
+int64_t orc_pattern_refine2(const float* y, const float* z, const int8_t* label, int32_t m, const orc_params* p, int32_t lat[3],
+                            int32_t* phase, int64_t* alt_cost, int32_t* rounds, int32_t* hops, int32_t* capped) {
+  int32_t was_capped = 0;
   const int32_t div = p->refine_div > 0 ? p->refine_div : 1;
   /* theta may leave the grid's range by refine_th_margin grid steps (the extent of the GPU kernel's cos/sin table) */
   const int32_t th_lo = -p->refine_th_margin * div, th_hi = (p->n_th - 1 + p->refine_th_margin) * div;
@@ -1486,6 +1493,7 @@ int64_t orc_pattern_refine(const float* y, const float* z, const int8_t* label, 
       }
     }
     n_rounds += r;
+    if (p->refine_div > 0 && stride >= 1) was_capped = 1; /* left the loop on the round cap, not on the stride */
     /* the eight neighbouring basins: one square along y and/or z; an odd shift swaps the colours */
     alt = INT64_MAX;
     int32_t aq[3] = {0, 0, 0}, aph = 0;
@@ -1517,7 +1525,33 @@ int64_t orc_pattern_refine(const float* y, const float* z, const int8_t* label, 
   if (alt_cost) *alt_cost = alt;
   if (rounds) *rounds = n_rounds;
   if (hops) *hops = n_hops;
+  if (capped) *capped = was_capped;
   return c;
+}
+
+/* ------------------------------------------------------------------------- */
+/* coverage of the virtual board by the labelled points (confidence signal)   */
+/* ------------------------------------------------------------------------- */
+void orc_coverage(const double theta_t[3], const float* y, const float* z, int32_t m, const orc_params* p, int32_t* cells_hit,
+                  int32_t* n_oob) {
+  const int32_t W = p->board_w, H = p->board_h;
+  const double g = p->grid_length, c = cos(theta_t[0]), s = sin(theta_t[0]);
+  uint8_t* hit = (uint8_t*)calloc((size_t)(W * H), 1);
+  int32_t oob = 0, cells = 0;
+  for (int32_t k = 0; k < m; ++k) {
+    const double yy = c * (double)y[k] - s * (double)z[k] + theta_t[1]; /* Optimization.h:37-42 */
+    const double zz = s * (double)y[k] + c * (double)z[k] + theta_t[2];
+    const double i = (yy + W * g / 2.0) / g, j = (zz + H * g / 2.0) / g; /* :45-46 */
+    if (i > 0.0 && i < (double)W && j > 0.0 && j < (double)H) {            /* :48-49, strict */
+      hit[(int32_t)floor(i) * H + (int32_t)floor(j)] = 1;
+    } else {
+      ++oob;
+    }
+  }
+  for (int32_t k = 0; k < W * H; ++k) cells += hit[k];
+  free(hit);
+  *cells_hit = cells;
+  *n_oob = oob;
 }
 
 /* ------------------------------------------------------------------------- */
@@ -1629,7 +1663,9 @@ int32_t orc_extract(const float* xyzi, int32_t n, const float click[3], const or
       int32_t lat[3] = {(cell / (p->n_tz * p->n_ty)) * div, ((cell / p->n_tz) % p->n_ty) * div, (cell % p->n_tz) * div};
       int64_t alt = 0;
       int32_t rounds = 0, hops = 0;
-      const int64_t c = orc_pattern_refine(y, z, lab, nl, p, lat, &phase, &alt, &rounds, &hops);
+      int32_t capped = 0;
+      const int64_t c = orc_pattern_refine2(y, z, lab, nl, p, lat, &phase, &alt, &rounds, &hops, &capped);
+      if (capped) out->flags |= ORC_FLAG_REFINE_CAPPED;
       orc_lattice_point(p, lat, out->theta_t);
       out->phase = phase;
       out->iters_a = rounds;
@@ -1675,6 +1711,9 @@ int32_t orc_extract(const float* xyzi, int32_t n, const float click[3], const or
       }
     }
     }
+    orc_coverage(out->theta_t, y, z, nl, p, &out->cells_hit, &out->n_oob);
+    if (p->min_cell_coverage > 0.0 && (double)out->cells_hit < p->min_cell_coverage * (double)(p->board_w * p->board_h))
+      out->flags |= ORC_FLAG_LOW_COVERAGE;
     free(y);
     free(z);
     free(lab);

@@ -92,6 +92,7 @@ typedef struct orc_params {
   int32_t refine_th_margin;  /* the search may leave the grid's theta range by this many grid steps (default 32) */
   int32_t refine_pad_;
   double ambiguity_eps;      /* ORC_AMBIGUOUS when (best neighbouring basin - cost) / cost < eps (default 1.0: an alternative must cost at least twice as much; <= 0: never) */
+  double min_cell_coverage;  /* ORC_FLAG_LOW_COVERAGE when fewer than this fraction of the board's squares hold a labelled point under the final pose (default 0.9; <= 0: never) */
 } orc_params;
 
 typedef struct orc_result {
@@ -108,11 +109,24 @@ typedef struct orc_result {
   double sel_cost;             /* with-OOB cost at the final theta_t (phase selection metric) */
   double grid_cost;
   double basin_margin;         /* ORC_SOLVER_GRID: (cost of the best one-square-shifted basin - sel_cost) / sel_cost */
+  int32_t flags;               /* ORC_FLAG_* (the HIP library's ILCC_FLAG_* without the fp32-specific tie overflow) */
+  int32_t cells_hit;           /* board squares that hold >= 1 labelled point under the final (theta, ty, tz) */
+  int32_t n_oob;               /* labelled points outside the board under the final pose */
+  int32_t pad_;
   float pca[16];               /* row-major 4x4, lidar -> plane frame (pca_matrix) */
   float corners[ORC_MAX_CORNERS * 3];
 } orc_result;
 
+#define ORC_FLAG_REFINE_CAPPED 2
+#define ORC_FLAG_LOW_COVERAGE 4
+
 void orc_default_params(orc_params* p);
+
+/* board squares holding >= 1 labelled point / labelled points outside the board under theta_t: the functor's own
+ * coordinates (Optimization.h:37-49), double.  The operator's eye at the viewer (LidarCornersEst.cpp:415-441) checks
+ * exactly this -- does the virtual board sit ON the points -- before pressing 'o'. */
+void orc_coverage(const double theta_t[3], const float* y, const float* z, int32_t m, const orc_params* p, int32_t* cells_hit,
+                  int32_t* n_oob);
 
 /* ---- stage functions (each usable on its own from tests) ---- */
 
@@ -181,6 +195,8 @@ int64_t orc_cost_q(const double theta_t[3], const float* y, const float* z, cons
  * Then the eight neighbouring basins (one square along y and/or z; an odd shift flips the colour phase) are
  * evaluated once; a cheaper one is adopted and refined again (at most two hops).  Returns the final cost,
  * *alt_cost = cheapest neighbouring basin, rounds / hops executed. */
+int64_t orc_pattern_refine2(const float* y, const float* z, const int8_t* label, int32_t m, const orc_params* p, int32_t lat[3],
+                            int32_t* phase, int64_t* alt_cost, int32_t* rounds, int32_t* hops, int32_t* capped);
 int64_t orc_pattern_refine(const float* y, const float* z, const int8_t* label, int32_t m, const orc_params* p,
                            int32_t lat[3], int32_t* phase, int64_t* alt_cost, int32_t* rounds, int32_t* hops);
 /* lattice -> (theta, ty, tz) */

@@ -87,6 +87,9 @@ def test_every_stage_matches_the_oracle(ob, est, frames, solver):
         assert (r.iters_a, r.iters_b) == (o.iters_a, o.iters_b)
         dev = np.abs(r.corners_array() - ob.result_corners(o)).max()
         worst = max(worst, dev)
+        # the confidence signal (squares holding points / points off the board under the final pose) and its flag
+        assert (r.cells_hit, r.n_oob) == (o.cells_hit, o.n_oob), (f, r.cells_hit, o.cells_hit, r.n_oob, o.n_oob)
+        assert (r.flags & ~N.FLAG_TIE_OVERFLOW) == o.flags, (f, r.flags, o.flags)
         if solver == N.SOLVER_GRID:
             assert r.grid_index == o.grid_index, f
             assert r.grid_cost == pytest.approx(o.grid_cost, rel=2e-5, abs=2e-6)
@@ -94,7 +97,7 @@ def test_every_stage_matches_the_oracle(ob, est, frames, solver):
             assert tuple(r.theta_t) == tuple(o.theta_t), (f, list(r.theta_t), list(o.theta_t))
             assert (r.cost_a, r.cost_b, r.sel_cost, r.basin_margin) == (o.cost_a, o.cost_b, o.sel_cost, o.basin_margin)
             assert r.sel_cost <= o.grid_cost          # monotone: never above the grid argmin's cost
-            assert r.flags == 0
+            assert (r.flags & (N.FLAG_TIE_OVERFLOW | N.FLAG_REFINE_CAPPED)) == 0
             assert dev < 1e-6, (f, dev)
         else:
             assert np.allclose(r.theta_t, o.theta_t, atol=1e-6), (f, list(r.theta_t), list(o.theta_t))
@@ -124,7 +127,9 @@ def test_bundled_pose_corners_config3(ob, est, golden_dir):
             assert np.abs(got - ob.result_corners(o)).max() < 1e-5      # config 3: |GPU - CPU oracle| <= 1e-3 m
             errs.append(synth.corner_error(got, fix, BOARD))
         print("config 3, VLP-16 frames, solver %d: |GPU - bundled file| = %s mm" % (solver, np.round(1e3 * np.array(errs), 2)))
-        assert max(errs) < 0.02
+        # what this sensor model resolves (profiles/r03_noise_floor_study.json: 2.1 mm median with NO range noise -- the
+        # 15 mm beam footprint greys the square edges out -- 2.7 mm at 10 mm): measured 2.4-6.9 mm (grid), 1.9-5.3 mm (reference mode)
+        assert max(errs) <= 0.008, errs
 
 
 def _dense_low_noise_fixture_frames():
@@ -292,7 +297,7 @@ def test_ambiguous_frames_are_flagged_not_silently_returned(ob):
     p.ambiguity_eps = 0.0
     e.set_params(p)
     r0 = e.extract(cut[None], click[None])[0]
-    assert r0.status == N.OK and r0.flags == 0
+    assert r0.status == N.OK and r0.flags == N.FLAG_LOW_COVERAGE      # (the middle-rows-only board is under-sampled too)
     p.refine_max_rounds = 2          # the pattern search is cut off long before its stride reaches the lattice: flagged
     e.set_params(p)
     r2 = e.extract(cut[None], click[None])[0]
@@ -310,6 +315,52 @@ def test_ambiguous_frames_are_flagged_not_silently_returned(ob):
     m.accept_ambiguous = True
     assert m.get_corners(corners) is True and len(corners) == 35
     m.close()
+
+
+def test_low_coverage_flag_and_accept_rule(ob):
+    """The second confidence signal: cells_hit / n_oob equal the oracle's; a board whose far
+    end is cut off by the ROI leaves squares empty -> ILCC_FLAG_LOW_COVERAGE, and the class mirror's get_corners
+    rejects the scan unless accept_ambiguous is set; min_cell_coverage <= 0 switches the flag off."""
+    board = synth.Board()
+    pose = synth.pose_from_fixture(0)
+    cloud = synth.make_frame(synth.vlp16(), board, pose, 0xC0FFEE)
+    click = synth.make_click(pose, 0xC0FFEE)
+    # full board: every square sampled
+    p = N.default_params()
+    e = LidarCornersBatch(1, len(cloud), p)
+    r = e.extract(cloud[None], click[None])[0]
+    o = ob.extract(cloud, click, _oparams(ob, N.SOLVER_GRID))
+    assert r.status == N.OK and (r.cells_hit, r.n_oob, r.flags) == (o.cells_hit, o.n_oob, o.flags)
+    assert r.cells_hit >= 46 and not (r.flags & N.FLAG_LOW_COVERAGE)
+    # the same frame with the upper third of the board's points removed before the call (an occluded board)
+    c0 = pose.centre
+    up = np.array(pose.v if abs(pose.v[2]) > abs(pose.u[2]) else pose.u)
+    up = up * np.sign(up[2])
+    keep = ((cloud[:, :3] - c0) @ up < 0.18) | (np.linalg.norm(cloud[:, :3] - c0, axis=1) > 1.0)
+    cut = np.ascontiguousarray(cloud[keep])
+    e2 = LidarCornersBatch(1, len(cut), p)
+    r2 = e2.extract(cut[None], click[None])[0]
+    o2 = ob.extract(cut, click, _oparams(ob, N.SOLVER_GRID))
+    assert r2.status == o2.status and (r2.cells_hit, r2.n_oob) == (o2.cells_hit, o2.n_oob)
+    assert (r2.flags & ~N.FLAG_TIE_OVERFLOW) == o2.flags
+    if r2.status in (N.OK, N.AMBIGUOUS):
+        assert r2.cells_hit < 0.9 * 48 and (r2.flags & N.FLAG_LOW_COVERAGE)
+        m = LidarCornersEst(device=0, max_points_per_frame=len(cut))
+        m.setROI(cut, click)
+        assert m.EuclideanCluster()
+        m.PCA()
+        got = []
+        assert m.get_corners(got) is False and got == []
+        m.accept_ambiguous = True
+        got = []
+        assert m.get_corners(got) is True and len(got) == 35
+        m.close()
+        p.min_cell_coverage = 0.0
+        e2.set_params(p)
+        r3 = e2.extract(cut[None], click[None])[0]
+        assert not (r3.flags & N.FLAG_LOW_COVERAGE) and r3.cells_hit == r2.cells_hit
+    e.close()
+    e2.close()
 
 
 def test_bad_frames_do_not_abort_the_batch(ob, est, frames):
@@ -441,7 +492,9 @@ def test_full_size_batch_properties():
     clouds, clicks, gts, _ = synth.make_batch(F, seed=0xC0FFEE)
     e = LidarCornersBatch(F, 28800, N.default_params())
     r1 = np.array([np.ctypeslib.as_array(r.corners)[:105].copy() for r in e.extract(clouds, clicks)])
-    s1 = [r.status for r in e.extract(clouds, clicks)]
+    full = e.extract(clouds, clicks)
+    s1 = [r.status for r in full]
+    low = [bool(r.flags & N.FLAG_LOW_COVERAGE) for r in full]
     r2 = np.array([np.ctypeslib.as_array(r.corners)[:105].copy() for r in e.extract(clouds, clicks)])
     assert np.array_equal(r1, r2)                                   # bitwise repeatable
     perm = np.random.default_rng(0).permutation(F)
@@ -450,9 +503,15 @@ def test_full_size_batch_properties():
     sub = np.array([np.ctypeslib.as_array(r.corners)[:105].copy() for r in e.extract(clouds[5:9], clicks[5:9])][:4])
     assert np.array_equal(sub, r1[5:9])
     ok = [f for f in range(F) if s1[f] == 0]
-    assert len(ok) >= 0.93 * F                                      # (ambiguous frames are flagged, not counted)
+    amb = [f for f in range(F) if s1[f] == N.AMBIGUOUS]
+    assert len(ok) + len(amb) >= 0.95 * F                           # corners delivered (OK or flagged ambiguous)
     err = np.array([synth.corner_error(r1[f].reshape(35, 3), gts[f], BOARD) for f in ok])
-    assert np.median(err) < 0.006
+    assert np.median(err) < 0.004                                   # 2.7-2.9 mm: the floor of this sensor model (profiles/r03_noise_floor_study.json)
+    # the recommended accept rule (include/ilcc_hip.h): status OK and the coverage flag clear -- no accepted frame is a
+    # square (150 mm) off, and the rule keeps >= 90 % of the batch
+    acc = [f for f in ok if not low[f]]
+    err_acc = np.array([synth.corner_error(r1[f].reshape(35, 3), gts[f], BOARD) for f in acc])
+    assert len(acc) >= 0.90 * F and err_acc.max() < 0.03, (len(acc), err_acc.max())
     # every result is an exact planar 0.15 m lattice (what the consumer relies on)
     for f in ok[:16]:
         g = r1[f].reshape(5, 7, 3)

@@ -53,7 +53,8 @@ def test_struct_layouts_match_the_library():
     assert p.tz_step == pytest.approx(0.0075) and p.tz_min == pytest.approx(-0.15)
     assert (p.refine_div, p.refine_max_rounds, p.refine_th_margin) == (16, 64, 32)
     assert p.ambiguity_eps == 1.0 and p.online_cluster_tol == 0.10     # LidarCornersEst.cpp:80
-    assert C.sizeof(N.Result) == 14 * 4 + 4 + 16 + 64 + 4 + 16 + 24 + 24 + 8 + 8 + 3 * 4 * 256  # no hidden padding surprises
+    assert p.min_cell_coverage == 0.9
+    assert C.sizeof(N.Result) == 14 * 4 + 4 + 16 + 64 + 4 + 16 + 24 + 24 + 8 + 8 + 8 + 3 * 4 * 256  # no hidden padding surprises
 
 
 def test_defaults_agree_with_the_oracle(ob):
@@ -61,7 +62,7 @@ def test_defaults_agree_with_the_oracle(ob):
     for f in ("cluster_tol", "cluster_min", "cluster_max", "ransac_thresh", "ransac_hyp", "ransac_seed",
               "hist_bins", "gray_rate", "huber_delta", "grid_length", "board_w", "board_h", "phase_mode",
               "n_th", "n_ty", "n_tz", "th_min", "th_step", "ty_min", "ty_step", "tz_min", "tz_step",
-              "refine_div", "refine_max_rounds", "refine_th_margin", "ambiguity_eps"):
+              "refine_div", "refine_max_rounds", "refine_th_margin", "ambiguity_eps", "min_cell_coverage"):
         assert getattr(p, f) == getattr(o, f), f
     assert tuple(p.roi_half) == tuple(o.roi_half)
 
