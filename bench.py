@@ -51,19 +51,40 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0                              # MI355X_MICROARCH.md: 8 TB/s spec
-# HBM bytes of the K6 stage (seed + refinement + full launch) per 128 config-2 frames, from the PMC
-# passes committed under profiles/ (see profiles/README.md)
-K6_HBM_TRAFFIC_BYTES_128 = 26937350   # profiles/r02i_pmc_summary.csv: 6332732 + 10078681 + 10525937
 # VALU issue peak: 256 CU x 4 SIMD x 32 lanes x 2.4 GHz = 78.6 T lane-instructions/s
 # (= the 157.3 TFLOP/s fp32 vector peak of MI355X_MICROARCH.md when every instruction is an FMA)
 VALU_ISSUE_PEAK_T = 78.6
-# VALU instructions of ONE (point, candidate) evaluation of k6_grid_cost (both colour phases), counted in the gfx950
-# ISA of the term itself (DESIGN.md "K6"): 26 for a border-class point (out-of-board logic included), 15 for an
-# interior-class point (it cannot leave the board under any translation of the grid).  Bound tests, tile prologues,
-# address arithmetic and staging are NOT credited (round 1's 27.5 was the one-class loop body including its share of the
-# bound test).  The library counts the executed evaluations of both classes.
-K6_VALU_OPS_BORDER = 26.0
+# VALU instructions of ONE (point, candidate) evaluation of k6_grid_cost (both colour phases), counted by
+# tools/k6_isa_count.sh in the gfx950 assembly of the term functions (probe kernels in csrc/k6_grid_cost.hip, the library's
+# compile flags): border-class point (out-of-board logic included) / interior-class point (it cannot leave the board under
+# any translation of the grid).  Bound tests, tile prologues, address arithmetic and staging are NOT credited.  The
+# committed output of the script is profiles/r03_k6_isa_count.json; tests/test_host_logic.py::test_k6_credit_matches_the_isa
+# re-runs the script and fails when these constants, that file and the current source disagree.
+K6_VALU_OPS_BORDER = 29.0
 K6_VALU_OPS_INTERIOR = 15.0
+# PMC passes of the K6 stage at the batch sizes this bench runs (tools/gpu_pmc.sh -> profiles/): per-launch counters of one
+# batch alone on the chip.  roofline.traffic and roofline.issued_vs_credited are computed from these files at run time.
+PMC_FILES = {(2, 256): "profiles/r03_pmc_cfg2_256f.csv", (5, 64): "profiles/r03_pmc_cfg5_64f.csv"}
+
+
+def k6_pmc(config, frames_per_batch):
+    """Counters of the three K6 launches (seed, refinement, full pass) of ONE batch from the committed PMC summary:
+    HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (MI355X_MICROARCH.md: FETCH_SIZE counts half the bytes of wide reads on
+    gfx950; separate passes), issued VALU wavefront-instructions, busy cycles.  None when no file matches this run."""
+    import csv
+    path = PMC_FILES.get((config, frames_per_batch))
+    if not path or not os.path.exists(os.path.join(ROOT, path)):
+        return None
+    rows = [r for r in csv.DictReader(open(os.path.join(ROOT, path))) if "k6_grid_cost" in r["kernel"]]
+    if len(rows) != 3:
+        return None
+    f = lambda r, k: float(r[k]) if r.get(k) not in (None, "") else 0.0
+    full = max(rows, key=lambda r: f(r, "SQ_INSTS_VALU"))
+    return {"file": path,
+            "traffic_bytes": int(sum((2.0 * f(r, "FETCH_SIZE") + f(r, "WRITE_SIZE")) * 1024.0 for r in rows)),
+            "valu_wave_instr": sum(f(r, "SQ_INSTS_VALU") for r in rows),
+            "full_pass": {"valu_wave_instr": f(full, "SQ_INSTS_VALU"), "gui_active_cycles_per_xcd": f(full, "GRBM_GUI_ACTIVE") / 8.0,
+                          "valu_busy_quad_cycles": f(full, "SQ_ACTIVE_INST_VALU")}}
 
 
 def _gen_chunk(args):
@@ -101,6 +122,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the H2D-inclusive / reference-mode legs (profiling runs)")
     ap.add_argument("--in-flight", type=int, default=4, help="batches in flight per GPU (1 = fully synchronous)")
+    ap.add_argument("--ref-n1", type=float, default=0.0,
+                    help="frames/s of the N=1 run: rank 0 then prints weak_scaling_efficiency = value / (N x ref)")
+    ap.add_argument("--no-noise-floor", action="store_true", help="skip the sensor-noise sweep (noise_floor_mm)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -122,6 +146,10 @@ def main():
     workers = int(os.environ.get("ILCC_BENCH_GEN_WORKERS", "0")) or max(1, min(16, cores // max(1, min(world, 8))))
     clouds, clicks, gts = generate(args.config, FS, 0xC0FFEE + rank * FS, workers)
     t_gen = time.perf_counter() - t_gen
+    # inputs of the sensor-noise sweep (noise_floor_mm): generated now, before anything touches the HIP runtime (forked workers)
+    noise_inputs = None
+    if world == 1 and args.config == 2 and not (args.no_extra_legs or args.no_noise_floor):
+        noise_inputs = gen_noise_variants(min(256, FS), workers)
 
     import torch
     import torch.distributed as dist
@@ -230,25 +258,36 @@ def main():
     dptrs = [t.data_ptr() for t in d_clouds]
 
     def warm(ptrs, w_steps):
-        """W steps, then until two consecutive step times agree within 3 % and >= 0.3 s have passed (<= 3 s)."""
+        """W steps, then blocks of 5 steps until the median step time of a block is within 2 % of the previous block's
+        median and >= 0.3 s have passed (cap: 3 s).  Returns (extra steps, seconds)."""
         t0 = time.perf_counter()
         run(max(1, w_steps), ptrs)
-        extra = 0
+        extra, prev = 0, None
         while True:
             ts = [time.perf_counter()]
-            run(3, ptrs, step_times=ts)
-            extra += 3
-            d = np.diff(ts)
+            run(5, ptrs, step_times=ts)
+            extra += 5
+            med = float(np.median(np.diff(ts)))
             now = time.perf_counter() - t0
-            done = (now >= 0.3 and abs(d[-1] - d[-2]) <= 0.03 * max(d[-1], d[-2])) or now >= 3.0
+            done = (prev is not None and now >= 0.3 and abs(med - prev) <= 0.02 * max(med, prev)) or now >= 3.0
+            prev = med
             if dist_on:   # every rank must issue the same number of steps (= gathers): stop only when all are steady
                 flag = torch.tensor([0.0 if done else 1.0], dtype=torch.float32, device=rec_dev)
                 dist.all_reduce(flag, op=dist.ReduceOp.MAX)
                 done = float(flag.item()) == 0.0
             if done:
-                return extra
+                return extra, time.perf_counter() - t0
 
-    extra_warm = warm(dptrs, args.warmup)
+    if dist_on:
+        # preflight: what the collective really spans (a SCALE log then proves N ranks on N devices)
+        info = torch.tensor([float(rank), float(torch.cuda.current_device()), float(FS * rec_w * 4)], dtype=torch.float64, device=rec_dev)
+        got = [torch.zeros_like(info) for _ in range(world)]
+        dist.all_gather(got, info)
+        if rank == 0:
+            print("bench preflight: backend %s, world %d; ranks %s on devices %s; gather of %d bytes per rank and step"
+                  % (dist.get_backend(), dist.get_world_size(), [int(g[0]) for g in got], [int(g[1]) for g in got], int(got[0][2])),
+                  file=sys.stderr, flush=True)
+    extra_warm, warm_s = warm(dptrs, args.warmup)
     est.reset_timing()
     torch.cuda.synchronize()
     if dist_on:
@@ -292,6 +331,11 @@ def main():
         valu_ops_per_eval = (K6_VALU_OPS_INTERIOR * evals_interior + K6_VALU_OPS_BORDER * (evals_per_launch - evals_interior)) \
             / max(1.0, evals_per_launch)
         valu_rate = evals_per_launch * valu_ops_per_eval / (k6_ms * 1e-3) / 1e12
+        pmc = k6_pmc(args.config, F)
+        credited_wave_instr = evals_per_launch * valu_ops_per_eval / 64.0
+        low = [bool(res[f].flags & N.FLAG_LOW_COVERAGE) for f in range(FS)]
+        acc = [f for f in ok if not low[f]]
+        err_acc = np.array([synth.corner_error(res[f].corners_array(), gts[f], board) for f in acc])
         out = {
             "metric": "chessboard-corner frames/sec + max corner error (mm), VLP-16 cloud",
             "value": fps,
@@ -328,6 +372,7 @@ def main():
                           "`value_h2d_inclusive` = the same pipeline with every batch starting in pinned host memory and "
                           "crossing PCIe inside the timed region -- that one is SURVEY.md 8(d)'s metric as written",
             "warmup_extra_steps_until_steady": extra_warm,
+            "warmup_s": round(warm_s, 3),
             "input_generation_s": round(t_gen, 2),
             "max_corner_error_mm_vs_ground_truth": 1e3 * float(err_ok.max()) if len(err_ok) else None,
             "median_corner_error_mm_vs_ground_truth": 1e3 * float(np.median(err_ok)) if len(err_ok) else None,
@@ -335,6 +380,11 @@ def main():
             "frames_ok": "%d/%d" % (len(ok), FS),
             "frames_flagged_ambiguous": len(amb),
             "max_corner_error_mm_incl_ambiguous": 1e3 * float(max(err_ok.max(initial=0.0), err_amb.max(initial=0.0))),
+            "accept_rule": {"rule": "status == ILCC_OK and not (flags & ILCC_FLAG_LOW_COVERAGE)  [include/ilcc_hip.h, 'accepting a frame']",
+                            "frames_accepted": "%d/%d" % (len(acc), FS),
+                            "max_corner_error_mm_accepted": 1e3 * float(err_acc.max()) if len(err_acc) else None,
+                            "median_corner_error_mm_accepted": 1e3 * float(np.median(err_acc)) if len(err_acc) else None,
+                            "frames_ok_but_low_coverage": int(sum(1 for f in ok if low[f]))},
             "labelled_points_per_frame": m_lab,
             "stage_ms_last_batch_overlapped": {k: round(getattr(tm, k), 4) for k in
                                                ("roi_crop", "cluster", "ransac_plane", "plane_frame_hist", "grid_cost",
@@ -346,10 +396,23 @@ def main():
                 "peak": VALU_ISSUE_PEAK_T,
                 "unit": "T lane-instr/s",
                 "frac": valu_rate / VALU_ISSUE_PEAK_T,
-                "traffic": K6_HBM_TRAFFIC_BYTES_128 * F // 128 if (F % 128 == 0 and args.config == 2) else None,
-                "traffic_note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (profiles/): "
-                                "(2 x FETCH_SIZE + WRITE_SIZE) x 1024 summed over the stage's three launches "
-                                "(seed, refinement, full pass), measured on a 128-frame batch and scaled to this batch size",
+                "traffic": pmc["traffic_bytes"] if pmc else None,
+                "traffic_note": "HBM bytes of the stage's three launches (seed, refinement, full pass) of one batch of THIS size alone "
+                                "on the chip: (2 x FETCH_SIZE + WRITE_SIZE) x 1024 from separate rocprofv3 --pmc passes, read at run time "
+                                "from %s (tools/gpu_pmc.sh); null when no committed file matches this config / batch size"
+                                % (pmc["file"] if pmc else "profiles/"),
+                "issued_vs_credited": {
+                    "issued_valu_wave_instr_per_launch": pmc["valu_wave_instr"],
+                    "credited_valu_wave_instr_per_launch": credited_wave_instr,
+                    "uncredited_share": 1.0 - credited_wave_instr / pmc["valu_wave_instr"],
+                    "what": "issued = SQ_INSTS_VALU of the three K6 launches of one batch (PMC file, batch alone on the chip); credited = this "
+                            "run's executed evaluations x the term's ISA count / 64 lanes.  The difference is bound tests, tile "
+                            "prologues, staging, address arithmetic, idle lanes of tail blocks",
+                    "full_pass_alone": dict(pmc["full_pass"],
+                                            ms_at_2p4GHz=pmc["full_pass"]["gui_active_cycles_per_xcd"] / 2.4e6,
+                                            valu_busy_share=pmc["full_pass"]["valu_busy_quad_cycles"] / max(1.0, pmc["full_pass"]["gui_active_cycles_per_xcd"] * 256.0),
+                                            issue_utilisation=2.0 * pmc["full_pass"]["valu_wave_instr"] / max(1.0, 1024.0 * pmc["full_pass"]["gui_active_cycles_per_xcd"])),
+                } if pmc else None,
                 "launch_ms": k6_ms,
                 "launches_timed": int(tm.grid_cost_launches),
                 "evals_executed_per_launch": evals_per_launch,
@@ -364,12 +427,15 @@ def main():
                         "whole_path_frac": fps / max(1, world) * bytes_per_frame / 1e9 / HBM_PEAK_GBPS},
                 "note": "k6_grid_cost is VALU-bound by construction (points staged once in LDS, ~1e8 nominal "
                         "point-candidate evaluations per frame, no MFMA): achieved = executed evaluations x their VALU "
-                        "instructions (26 border-class, 15 interior-class: the term only -- bound tests, prologues and address arithmetic are not credited) / launch duration.  launch = the K6 stage of one batch (seed + refinement + full "
+                        "instructions (%g border-class, %g interior-class, tools/k6_isa_count.sh: the term only -- bound tests, prologues and address arithmetic are not credited) / launch duration." % (K6_VALU_OPS_BORDER, K6_VALU_OPS_INTERIOR) + "  launch = the K6 stage of one batch (seed + refinement + full "
                         "launch), timed by HIP events on the library's stream (the wait for the previous batch's full pass "
                         "between the refinement and the full launch is excluded).  `hbm` holds the algorithmic-bytes "
                         "fraction of the 8 TB/s peak that BASELINE.json asks for",
             },
         }
+        if args.ref_n1 > 0:
+            out["weak_scaling_efficiency"] = fps / (world * args.ref_n1)
+            out["weak_scaling_reference_n1"] = args.ref_n1
         if world == 1 and not args.no_extra_legs:
             out["pcie_inclusive"] = pcie_inclusive_rate(torch, est, clouds, d_clicks, F, B, n_points, depth, args.steps, run, warm)
             out["value_h2d_inclusive"] = out["pcie_inclusive"]["value"]
@@ -379,6 +445,8 @@ def main():
             out["single_frame_latency_ms"] = single_frame_latency(N, params, clouds, clicks, n_points, local_rank)
             if args.config == 2:
                 out["half_resolution_grid_variant"] = half_grid_leg(N, est, params, dptrs, FS, run, warm, args.steps, synth, gts, board)
+            if noise_inputs is not None:
+                out["noise_floor_mm"] = noise_floor_leg(N, params, synth, board, n_points, local_rank, noise_inputs)
             if not args.no_cpu_baseline and args.config == 2:
                 out["cpu_baseline"] = cpu_baseline(clouds.reshape(FS, n_points, 4), clicks.reshape(FS, 3), gts, board,
                                                    args.cpu_seconds, gpu_ref)
@@ -435,6 +503,62 @@ def reference_mode_leg(N, est, params, dptrs, d_clicks, res_grid, F, B, FS, run,
         },
     }
     return blk, gpu_ref
+
+
+def _gen_noise(args):
+    from lidar_camera_calibration_amd import synth
+    lo, n, sigma_r, footprint = args
+    board, lidar = synth.Board(), synth.vlp16()
+    clouds, clicks, gts = [], [], []
+    for f in range(lo, lo + n):
+        s = 0xC0FFEE + f
+        prng = np.random.Generator(np.random.Philox(key=(s ^ 0x905E) & 0xFFFFFFFFFFFFFFFF))
+        pose = synth.random_pose(prng)
+        clouds.append(synth.make_frame(lidar, board, pose, s, sigma_r=sigma_r, footprint=footprint))
+        clicks.append(synth.make_click(pose, s))
+        gts.append(synth.true_corners(pose, board))
+    return np.stack(clouds), np.stack(clicks), np.stack(gts)
+
+
+NOISE_VARIANTS = ((0.0, 0.015), (0.001, 0.015), (0.003, 0.015), (0.010, 0.015), (0.0, 0.0))   # (sigma_r, beam footprint) in m
+
+
+def gen_noise_variants(n_frames, workers):
+    import multiprocessing as mp
+    chunk = max(1, n_frames // max(1, workers))
+    out = []
+    for sigma_r, footprint in NOISE_VARIANTS:
+        jobs = [(lo, min(chunk, n_frames - lo), sigma_r, footprint) for lo in range(0, n_frames, chunk)]
+        if workers > 1 and len(jobs) > 1:
+            with mp.get_context("fork").Pool(min(workers, len(jobs))) as pool:
+                parts = pool.map(_gen_noise, jobs)
+        else:
+            parts = [_gen_noise(j) for j in jobs]
+        out.append(tuple(np.concatenate([p[k] for p in parts]) for k in range(3)))
+    return out
+
+
+def noise_floor_leg(N, params, synth, board, n_points, device, inputs):
+    """Where the ~2.9 mm median comes from: the bench's first 256 board poses re-drawn with range noise
+    sigma_r in {0, 1, 3, 10} mm (15 mm beam footprint, the bench's model) and once with an ideal point beam, through the
+    SAME GPU path (ILCC_SOLVER_GRID; it equals the CPU oracle bit for bit, tests/).  The committed oracle study with more
+    variants is profiles/r03_noise_floor_study.json (tools/noise_floor_study.py)."""
+    from lidar_camera_calibration_amd import LidarCornersBatch
+    n_frames = len(inputs[0][0])
+    est = LidarCornersBatch(n_frames, n_points, params, device=device)
+    out = {"what": "corner error vs ground truth (mm, frames with status OK) of the GPU ILCC_SOLVER_GRID path on the bench's first %d board "
+                   "poses, sensor model varied: the median is set by the 15 mm beam footprint greying the square edges out and by "
+                   "what 16 rings sample of the pattern, not by the range noise and not by the solver" % n_frames,
+           "variants": []}
+    for (sigma_r, footprint), (clouds, clicks, gts) in zip(NOISE_VARIANTS, inputs):
+        res = est.extract(clouds, clicks)
+        ok = [f for f in range(n_frames) if res[f].status == N.OK]
+        e = np.array([1e3 * synth.corner_error(res[f].corners_array(), gts[f], board) for f in ok])
+        out["variants"].append({"sigma_r_mm": 1e3 * sigma_r, "footprint_mm": 1e3 * footprint, "frames_ok": "%d/%d" % (len(ok), n_frames),
+                                "median": float(np.median(e)) if len(e) else None, "p90": float(np.percentile(e, 90)) if len(e) else None,
+                                "max": float(e.max()) if len(e) else None})
+    est.close()
+    return out
 
 
 def single_frame_latency(N, params, clouds, clicks, n_points, device):

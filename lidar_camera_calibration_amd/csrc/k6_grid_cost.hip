@@ -660,6 +660,32 @@ __global__ __launch_bounds__(THREADS) void k6_grid_cost(Ctx c, float* volume) {
     grid_cost_body<OOB, VOLUME, false, PRUNE, THREADS>(c, volume, s_ij, s_hw, s_best, s_iters, s_cnt, s_ay, s_az);
 }
 
+// -DILCC_K6_ISA_PROBE (tools/k6_isa_count.sh): the two terms alone, N chained calls on N different points per kernel.  The
+// VALU instructions of ONE evaluation = (instructions of the N = 3 kernel - instructions of the N = 1 kernel) / 2 -- counted
+// by the script in the gfx950 assembly of THIS file with the library's own compiler flags, so bench.py's credit per executed
+// evaluation is regenerated, not asserted.
+#ifdef ILCC_K6_ISA_PROBE
+template <int N, bool BORDER>
+__global__ void k6_isa_probe(const float* __restrict__ pts, float ay, float az, float Wh, float Hh, float delta, float* out) {
+  float A0 = 0.f, A1 = 0.f;
+  const float lay = ay + (float)threadIdx.x, laz = az - (float)threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    const PointTerms p{pts[3 * k], pts[3 * k + 1], pts[3 * k + 2]};
+    if (BORDER)
+      accumulate<true>(p, lay, laz, Wh, Hh, delta, A0, A1);
+    else
+      accumulate_interior(p, lay, laz, delta, A0, A1);
+  }
+  out[2 * threadIdx.x] = A0;
+  out[2 * threadIdx.x + 1] = A1;
+}
+template __global__ void k6_isa_probe<1, true>(const float*, float, float, float, float, float, float*);
+template __global__ void k6_isa_probe<3, true>(const float*, float, float, float, float, float, float*);
+template __global__ void k6_isa_probe<1, false>(const float*, float, float, float, float, float, float*);
+template __global__ void k6_isa_probe<3, false>(const float*, float, float, float, float, float, float*);
+#endif
+
 #ifdef ILCC_K6_TIMING
 extern "C" int ilcc_debug_k6_profile(unsigned long long* out16, int clear) {
   static std::vector<unsigned long long> host((size_t)kProfWaves * kProfWords);

@@ -57,6 +57,26 @@ def test_struct_layouts_match_the_library():
     assert C.sizeof(N.Result) == 14 * 4 + 4 + 16 + 64 + 4 + 16 + 24 + 24 + 8 + 8 + 8 + 3 * 4 * 256  # no hidden padding surprises
 
 
+def test_k6_credit_matches_the_isa():
+    """bench.py credits each executed K6 evaluation with the VALU instruction count of the term: the constants there, the
+    committed profiles/r03_k6_isa_count.json and a fresh run of tools/k6_isa_count.sh on the current source (hipcc -S,
+    no GPU needed) must agree -- the credit is regenerated, not asserted."""
+    import json
+    import re
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    committed = json.load(open(os.path.join(root, "profiles", "r03_k6_isa_count.json")))
+    src = open(os.path.join(root, "bench.py")).read()
+    border = float(re.search(r"^K6_VALU_OPS_BORDER = ([0-9.]+)", src, re.M).group(1))
+    interior = float(re.search(r"^K6_VALU_OPS_INTERIOR = ([0-9.]+)", src, re.M).group(1))
+    assert (border, interior) == (committed["border_valu_per_eval"], committed["interior_valu_per_eval"])
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("no hipcc")
+    fresh = json.loads(subprocess.check_output([os.path.join(root, "tools", "k6_isa_count.sh")], text=True))
+    assert (fresh["border_valu_per_eval"], fresh["interior_valu_per_eval"]) == (border, interior), fresh
+
+
 def test_defaults_agree_with_the_oracle(ob):
     p, o = N.default_params(), ob.default_params()
     for f in ("cluster_tol", "cluster_min", "cluster_max", "ransac_thresh", "ransac_hyp", "ransac_seed",
