@@ -11,7 +11,8 @@
 //   reads                the first PointCloud2 on ~lidar_topic of <prefix><idx>.bag, idx = 1..bag_num
 //   writes               <ilcc2 package>/process_data/<camera_name>_lidar_<idx>.txt
 //
-// NOT compiled in this repository (ROS1, rosbag and PCL are absent from the build image); it is the
+// Not BUILT in this repository (ROS1, rosbag and PCL are absent from the image) but type-checked on every test run against
+// declaration-only headers (tests/ros_stub/, tests/test_host_logic.py::test_ros_node_source_type_checks); it is the
 // file a maintainer adds to the reference's catkin package, see INTEGRATION.md.  All computation is
 // one call chain into the C-ABI through ilcc_host::LidarCornersEst; the two PCL-viewer
 // confirmations of the reference are automatic.
@@ -25,6 +26,7 @@
 #include <rosbag/view.h>
 #include <sensor_msgs/PointCloud2.h>
 
+#include <array>
 #include <map>
 #include <string>
 #include <vector>

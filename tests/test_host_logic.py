@@ -57,6 +57,34 @@ def test_struct_layouts_match_the_library():
     assert C.sizeof(N.Result) == 14 * 4 + 4 + 16 + 64 + 4 + 16 + 24 + 24 + 8 + 8 + 8 + 3 * 4 * 256  # no hidden padding surprises
 
 
+def test_ros_node_source_type_checks(tmp_path):
+    """host/get_lidar_corners_node.cpp carries the reference node's external surface (node name, private
+    parameters, topics, bag reading, corner files) and needs ROS1 + PCL, which the image lacks.  It is type-checked
+    against declaration-only headers (tests/ros_stub/, `g++ -fsyntax-only`): a typo in that file fails here.  Not a build
+    of the reference, nothing links.  """
+    import shutil
+    import subprocess
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, "lidar_camera_calibration_amd", "host", "get_lidar_corners_node.cpp")
+    cmd = ["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(root, "tests", "ros_stub"),
+           "-I" + os.path.join(root, "include"), "-I" + os.path.join(root, "lidar_camera_calibration_amd", "host")]
+    r = subprocess.run(cmd + [src], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    # the surface the launch files and calib_lidar_cam.launch rely on is spelled in this file
+    text = open(src).read()
+    for token in ('"lidar_corners"', '"bag_path_prefix"', '"bag_num"', '"lidar_topic"', '"camera_name"', '"yaml_path"',
+                  '"/clicked_point"', '"/velodyne_points"', '"/ChessBoard"', '"/pca_cloud"', '"/Optim_cloud"', '"/lidar_corners"',
+                  '"/velodyne"', '"/process_data/"', '"_lidar_"'):
+        assert token in text, token
+    # and the check has teeth: a misspelt member of the estimator makes it fail
+    bad = tmp_path / "node_typo.cpp"
+    bad.write_text(text.replace("estimator_.EuclideanCluster()", "estimator_.EuclideanClusters()"))
+    r = subprocess.run(cmd + [str(bad)], capture_output=True, text=True)
+    assert r.returncode != 0 and "EuclideanClusters" in r.stderr
+
+
 def test_k6_credit_matches_the_isa():
     """bench.py credits each executed K6 evaluation with the VALU instruction count of the term: the constants there, the
     committed profiles/r03_k6_isa_count.json and a fresh run of tools/k6_isa_count.sh on the current source (hipcc -S,
