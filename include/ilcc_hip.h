@@ -229,6 +229,9 @@ int32_t ilcc_extract_batch_device(ilcc_handle* h, const float* d_xyzi, const uin
  * GPU_MAX_HW_QUEUES >= 5, HIP's default of 4 makes two of the streams share a hardware queue), so the short
  * latency-bound stages of one batch overlap with the grid search of another.  *ticket identifies the
  * batch; ilcc_wait blocks until it is complete and copies its records to out (n_frames entries).
+ * (When GPU_MAX_HW_QUEUES is not in the environment at the time the library is loaded, the library's constructor sets it
+ * to 8 -- never overriding a value of yours -- which takes effect only if the HIP runtime has not been initialised yet;
+ * the first use of the fourth slot prints a one-time note in that case.)
  * Tickets must be waited for in submission order once all slots are taken (ILCC_CAPACITY otherwise).
  * The inputs must stay valid and unchanged until the matching ilcc_wait returns. */
 int32_t ilcc_submit_batch_device(ilcc_handle* h, const float* d_xyzi, const uint64_t* offsets,

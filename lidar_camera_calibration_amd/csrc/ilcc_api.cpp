@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <mutex>
 #include <new>
 #include <sstream>
 #include <string>
@@ -80,6 +81,7 @@ struct ilcc_handle {
   uint32_t grid_lds_points = 1024;   // grows with the frames seen (finish()); frames above it take the global-memory path
   uint32_t cluster_lds_points = 2048;   // K2's LDS capacity in ROI points per frame: grows likewise (<= 4096); larger frames take the multi-workgroup path
   uint32_t big_grid = 1024;          // workgroups of K2's persistent kernels (4 x the device's CUs)
+  bool poisoned = false;             // a failed ilcc_set_params could not restore the device tables: every later call fails
   bool big_armed = false;            // K2's multi-workgroup kernels are launched: set once a frame above the LDS capacity was seen (finish()) or by ilcc_reserve
   ilcc_timing timing{};
   std::string err;
@@ -135,6 +137,13 @@ bool params_ok(const ilcc_params& p, std::string& why) {
   if (p.board_w * p.board_h > kCoverageCellsMax) return bad("board has more squares than the coverage mask holds");
   if ((uint64_t)p.n_th * p.n_ty * p.n_tz * 2ull >= 0xFFFFFFFFull) return bad("grid too large");
   if (!(p.th_step > 0) || !(p.ty_step > 0) || !(p.tz_step > 0)) return bad("grid steps must be > 0");
+  {
+    // K7r's basin check compares with the positions ONE SQUARE away: lround(g / (step / div)) lattice units.  A step so
+    // coarse that this rounds to 0 would compare the centre with itself (margin 0: every frame ILCC_AMBIGUOUS)
+    const double div = (double)(p.refine_div > 0 ? p.refine_div : 1);
+    if (std::lround(p.grid_length / (p.ty_step / div)) < 1 || std::lround(p.grid_length / (p.tz_step / div)) < 1)
+      return bad("ty_step / tz_step too coarse: one board square is less than half a refinement-lattice step");
+  }
   return true;
 }
 
@@ -240,19 +249,34 @@ void free_slot(Slot& sl) {
 // serialise: a fourth batch in flight only pays with >= 5 queues.  The variable is read when the runtime
 // initialises, so the library sets it (when unset) as soon as it is loaded, and says so when it finds a value that
 // is too small at the moment the fourth slot is first used.
-__attribute__((constructor)) void ilcc_default_hw_queues() { (void)setenv("GPU_MAX_HW_QUEUES", "8", /*overwrite=*/0); }
+// (setenv from a library constructor is a side effect on the host process: it only ever ADDS the variable, never
+// overrides a value the user chose, and is documented in include/ilcc_hip.h at ilcc_submit_batch_device.)
+bool g_hwq_set_by_user = false;   // GPU_MAX_HW_QUEUES was already in the environment when the library was loaded
+__attribute__((constructor)) void ilcc_default_hw_queues() {
+  g_hwq_set_by_user = std::getenv("GPU_MAX_HW_QUEUES") != nullptr;
+  (void)setenv("GPU_MAX_HW_QUEUES", "8", /*overwrite=*/0);
+}
 
 void warn_hw_queues_once(int slot_index) {
-  static bool warned = false;
-  if (slot_index < 3 || warned) return;
-  const char* v = std::getenv("GPU_MAX_HW_QUEUES");
-  if (v && std::atoi(v) >= 5) return;
-  warned = true;
-  std::fprintf(stderr,
-               "libilcc_hip: GPU_MAX_HW_QUEUES=%s: with fewer than 5 hardware queues the fourth batch in flight shares a "
-               "queue with another one and serialises; keep at most 3 tickets outstanding or export GPU_MAX_HW_QUEUES=8 "
-               "before the HIP runtime starts\n",
-               v ? v : "(unset)");
+  static std::once_flag once;   // handles of several threads (one per GPU) may reach this together
+  if (slot_index < 3) return;
+  std::call_once(once, [] {
+    const char* v = std::getenv("GPU_MAX_HW_QUEUES");
+    if (g_hwq_set_by_user && v && std::atoi(v) >= 5) return;   // the user's own, sufficient setting
+    if (g_hwq_set_by_user)
+      std::fprintf(stderr,
+                   "libilcc_hip: GPU_MAX_HW_QUEUES=%s: with fewer than 5 hardware queues the fourth batch in flight shares a "
+                   "queue with another one and serialises; keep at most 3 tickets outstanding or export GPU_MAX_HW_QUEUES=8 "
+                   "before the HIP runtime starts\n", v ? v : "(unset)");
+    else
+      // the library set the variable itself when it was loaded -- which only helps if the HIP runtime had not been
+      // initialised by then (e.g. by an earlier `import torch`): it cannot tell, so it says so once
+      std::fprintf(stderr,
+                   "libilcc_hip: GPU_MAX_HW_QUEUES was unset when the library was loaded; it has been set to 8, which takes effect "
+                   "only if the HIP runtime had not started yet.  If something initialised HIP earlier (e.g. torch), the runtime "
+                   "keeps 4 hardware queues and the fourth batch in flight serialises with another one: export "
+                   "GPU_MAX_HW_QUEUES=8 before starting the process\n");
+  });
 }
 
 int32_t alloc_slot(ilcc_handle* h, Slot& sl) {
@@ -387,9 +411,31 @@ int32_t check_offsets(ilcc_handle* h, const uint64_t* offsets, uint32_t n_frames
   return ILCC_OK;
 }
 
-// enqueue the whole path for one batch on the slot's stream (no host synchronisation)
+int32_t enqueue_impl(ilcc_handle* h, int si, const float4* d_xyzi, const uint64_t* offsets, uint32_t n_frames, const float* d_clicks,
+                     bool front_only, bool no_crop);
+
+// enqueue the whole path for one batch on the slot's stream (no host synchronisation).  On a mid-pipeline failure the
+// kernels already queued may still be running on the slot's buffers: wait for them before handing the error back, so
+// that the next submit can reuse the slot.
 int32_t enqueue(ilcc_handle* h, int si, const float4* d_xyzi, const uint64_t* offsets, uint32_t n_frames,
                 const float* d_clicks, bool front_only = false, bool no_crop = false) {
+  if (h->poisoned) {
+    h->err = "handle unusable: a failed ilcc_set_params could not restore the device tables";
+    return ILCC_HIP_ERROR;
+  }
+  const int32_t st = enqueue_impl(h, si, d_xyzi, offsets, n_frames, d_clicks, front_only, no_crop);
+  if (st != ILCC_OK && h->slots[si].stream) {
+    const std::string why = h->err;
+    (void)hipStreamSynchronize(h->slots[si].stream);
+    (void)hipGetLastError();
+    h->slots[si].busy = false;
+    h->err = why;
+  }
+  return st;
+}
+
+int32_t enqueue_impl(ilcc_handle* h, int si, const float4* d_xyzi, const uint64_t* offsets, uint32_t n_frames,
+                     const float* d_clicks, bool front_only, bool no_crop) {
   Slot& sl = h->slots[si];
   uint64_t max_n = 0;
   for (uint32_t f = 0; f < n_frames; ++f) max_n = std::max<uint64_t>(max_n, offsets[f + 1] - offsets[f]);
@@ -761,7 +807,14 @@ int32_t ilcc_set_params(ilcc_handle* h, const ilcc_params* p) {
   const ilcc_params old = h->p;
   h->p = *p;
   st = upload_tables(h);
-  if (st != ILCC_OK) h->p = old;
+  if (st != ILCC_OK) {
+    // the device tables may be partly overwritten: put the previous parameter set back on the device as well, and refuse
+    // further work if even that fails
+    const std::string why = h->err;
+    h->p = old;
+    if (upload_tables(h) != ILCC_OK) h->poisoned = true;
+    h->err = why;
+  }
   return st;
 }
 
@@ -1063,7 +1116,12 @@ int32_t ilcc_get_theta_t(ilcc_handle* h, const float* yz, const uint8_t* label, 
 
 int32_t ilcc_pattern_refine(ilcc_handle* h, const float* yz, const uint8_t* label, uint32_t m, int32_t lat[3],
                             int32_t* phase, int64_t* cost_q, int64_t* alt_cost_q, int32_t* rounds, int32_t* hops) {
-  if (!lat || !phase) return ILCC_BAD_ARGUMENT;
+  if (!h || !lat || !phase) return ILCC_BAD_ARGUMENT;
+  if (lat[0] < h->th_lat_lo || lat[0] > h->th_lat_hi || (*phase != 0 && *phase != 1)) {
+    // the kernel indexes its cos/sin table with lat[0] (the basin check reads it unguarded)
+    h->err = "ilcc_pattern_refine: theta lattice coordinate outside [th_min - refine_th_margin, th_max + refine_th_margin] steps";
+    return ILCC_BAD_ARGUMENT;
+  }
   int32_t st = stage_labelled(h, yz, label, m);
   if (st != ILCC_OK) return st;
   Slot& sl = h->slots[0];

@@ -15,7 +15,7 @@
 //      threads: no thread-0 section, no divergence.  A solve is a chain of ~100 dependent
 //      evaluations, so latency -- not throughput -- is what this layout minimises; frames and
 //      phases run concurrently on different CUs.
-// K7r pattern_refine (ILCC_SOLVER_GRID): one 1024-thread workgroup per frame.  Starts at the K6 grid argmin
+// K7r pattern_refine (ILCC_SOLVER_GRID): one 192-thread workgroup (three wavefronts, one per theta of the stencil) per frame.  Starts at the K6 grid argmin
 //      (near ties of the fp32 grid pass are first re-ordered on exact fixed-point costs), then a monotone
 //      pattern search on the pass-A cost and a check of the eight neighbouring basins -- the same
 //      specification as the oracle's orc_pattern_refine, bit for bit: every point's term is computed in
@@ -643,6 +643,11 @@ __global__ __launch_bounds__(kSolveThreads) void k7a_local_solve(Ctx c, SolveRec
 // ------------------------------------------------------------------ K7r pattern refine (ILCC_SOLVER_GRID)
 constexpr double kCostQOne = 1099511627776.0;   // 2^40: quantum of the fixed-point cost (oracle: ORC_COST_Q_ONE)
 constexpr int kRefineWaves = kRefineThreads / ILCC_WAVE;
+// the 3-theta stencil gives every theta kRefineWaves / 3 wavefronts: fewer than 3 wavefronts would leave a theta without
+// any (all 27 sums 0 -- a silently wrong refinement, not a build error), and the candidate lists are written by the first
+// kRefineList threads
+static_assert(kRefineThreads % ILCC_WAVE == 0 && kRefineWaves >= 3 && kRefineThreads >= kRefineList,
+              "ILCC_K7R_THREADS must be a multiple of 64, at least 192");
 constexpr int32_t kNoTheta = INT32_MIN;         // candidate whose theta lies outside the lattice table: never evaluated
 
 struct RCand {
@@ -744,7 +749,7 @@ __device__ __forceinline__ int stencil_sweep(const Ctx& c, const Board& bd, cons
   if (threadIdx.x < kRefineList) sh.acc[(sweep + 1) % 3][threadIdx.x] = 0ull;   // last read two sweeps ago
   __syncthreads();
   const int wid = __builtin_amdgcn_readfirstlane(wave_id());
-  const int waves_per_theta = kRefineWaves / n_th;          // 16 -> 5 per theta (one wavefront idles) or 16
+  const int waves_per_theta = kRefineWaves / n_th;          // 3 wavefronts: one per theta of the stencil, or all three on the basin check's single theta
   const int it = wid % n_th, grp = wid / n_th;
   const int32_t q0 = th[it];
   if (grp < waves_per_theta && q0 != kNoTheta) {

@@ -49,23 +49,6 @@ uint32_t record_check(const float* rec, uint32_t n_corners, uint32_t tag) {
   return (t ^ (t >> 24)) & 0xFFFFFFu;
 }
 
-#define CHECK_HIP(e)                                                            \
-  do {                                                                          \
-    hipError_t e_ = (e);                                                        \
-    if (e_ != hipSuccess) {                                                     \
-      std::fprintf(stderr, "%s: %s\n", #e, hipGetErrorString(e_));              \
-      return 1;                                                                 \
-    }                                                                           \
-  } while (0)
-#define CHECK_NCCL(e)                                                           \
-  do {                                                                          \
-    ncclResult_t e_ = (e);                                                      \
-    if (e_ != ncclSuccess) {                                                    \
-      std::fprintf(stderr, "%s: %s\n", #e, ncclGetErrorString(e_));             \
-      return 1;                                                                 \
-    }                                                                           \
-  } while (0)
-
 struct RankJob {
   int rank = 0, world = 1, device = 0;
   ncclComm_t comm = nullptr;
@@ -76,60 +59,101 @@ struct RankJob {
   int status = 0;
 };
 
+// One rank.  A rank NEVER returns before the collective: a failure of its local work (ilcc_create, a bad frame, an
+// out-of-memory) is remembered, its records keep the status -1 padding, and it still calls ncclGather -- otherwise the
+// other ranks' threads would wait in the collective for ever and main() would hang in join().  Only when a rank cannot
+// even set up its device buffers does it abort its communicator (which fails the peers' collective instead of hanging
+// it).  Every resource is released on every path.
 int run_rank(RankJob* j) {
-  CHECK_HIP(hipSetDevice(j->device));
+  int failed = 0;
+  auto hip_ok = [&](hipError_t e, const char* what) {
+    if (e == hipSuccess) return true;
+    std::fprintf(stderr, "rank %d: %s: %s\n", j->rank, what, hipGetErrorString(e));
+    failed = 1;
+    return false;
+  };
   const uint32_t F = (uint32_t)j->frames->size();
   const uint32_t lo = std::min(F, (uint32_t)j->rank * j->per), hi = std::min(F, lo + j->per);
   const uint32_t n_local = hi - lo;
-  hipStream_t stream;
-  CHECK_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-  float *d_rec = nullptr, *d_all = nullptr;
   const size_t rec_floats = (size_t)j->per * j->width;
-  CHECK_HIP(hipMalloc((void**)&d_rec, rec_floats * 4));
-  if (j->rank == 0) CHECK_HIP(hipMalloc((void**)&d_all, rec_floats * 4 * (size_t)j->world));
-  // shards are padded to `per` records; a padding record carries status -1
-  std::vector<float> pad(rec_floats, 0.f);
-  for (uint32_t f = 0; f < j->per; ++f) pad[(size_t)f * j->width] = -1.f;
-  CHECK_HIP(hipMemcpy(d_rec, pad.data(), rec_floats * 4, hipMemcpyHostToDevice));
-  if (n_local > 0) {
+  hipStream_t stream = nullptr;
+  float *d_rec = nullptr, *d_all = nullptr, *h_xyzi = nullptr, *h_click = nullptr;
+  ilcc_handle* h = nullptr;
+
+  // ---- buffers the collective needs
+  bool ready = hip_ok(hipSetDevice(j->device), "hipSetDevice") &&
+               hip_ok(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking), "hipStreamCreate") &&
+               hip_ok(hipMalloc((void**)&d_rec, rec_floats * 4), "hipMalloc(records)") &&
+               (j->rank != 0 || hip_ok(hipMalloc((void**)&d_all, rec_floats * 4 * (size_t)j->world), "hipMalloc(gathered)"));
+  if (ready) {
+    // shards are padded to `per` records; a padding record carries status -1
+    std::vector<float> pad(rec_floats, 0.f);
+    for (uint32_t f = 0; f < j->per; ++f) pad[(size_t)f * j->width] = -1.f;
+    ready = hip_ok(hipMemcpy(d_rec, pad.data(), rec_floats * 4, hipMemcpyHostToDevice), "hipMemcpy(padding)");
+  }
+
+  // test hook of THIS driver (never read by the library): make one rank's local work fail, to show that the process then
+  // exits with an error instead of hanging in the collective
+  const char* fail_rank = std::getenv("ILCC_MGPU_FAIL_RANK");
+  if (fail_rank && std::atoi(fail_rank) == j->rank) {
+    std::fprintf(stderr, "rank %d: local work failed (ILCC_MGPU_FAIL_RANK)\n", j->rank);
+    failed = 1;
+  }
+
+  // ---- this rank's shard: failures are recorded, never returned from
+  if (ready && !failed && n_local > 0) {
     std::vector<uint64_t> off(n_local + 1, 0);
     for (uint32_t f = 0; f < n_local; ++f) off[f + 1] = off[f] + (*j->frames)[lo + f].xyzi.size() / 4;
-    float *h_xyzi = nullptr, *h_click = nullptr;   // page-locked: the batch's H2D copy then runs as a DMA on its stream
-    CHECK_HIP(hipHostMalloc((void**)&h_xyzi, std::max<uint64_t>(off[n_local], 1) * 16, hipHostMallocDefault));
-    CHECK_HIP(hipHostMalloc((void**)&h_click, (size_t)n_local * 12, hipHostMallocDefault));
-    for (uint32_t f = 0; f < n_local; ++f) {
-      const Frame& fr = (*j->frames)[lo + f];
-      std::memcpy(h_xyzi + off[f] * 4, fr.xyzi.data(), fr.xyzi.size() * 4);
-      std::memcpy(h_click + 3 * f, fr.click, 12);
+    // page-locked: the batch's H2D copy then runs as a DMA on its stream
+    if (hip_ok(hipHostMalloc((void**)&h_xyzi, std::max<uint64_t>(off[n_local], 1) * 16, hipHostMallocDefault), "hipHostMalloc(cloud)") &&
+        hip_ok(hipHostMalloc((void**)&h_click, (size_t)n_local * 12, hipHostMallocDefault), "hipHostMalloc(clicks)")) {
+      for (uint32_t f = 0; f < n_local; ++f) {
+        const Frame& fr = (*j->frames)[lo + f];
+        std::memcpy(h_xyzi + off[f] * 4, fr.xyzi.data(), fr.xyzi.size() * 4);
+        std::memcpy(h_click + 3 * f, fr.click, 12);
+      }
+      h = ilcc_create(j->device, &j->params, n_local, std::max<uint64_t>(off[n_local], 1));
+      if (!h) {
+        std::fprintf(stderr, "rank %d: ilcc_create: %s\n", j->rank, ilcc_last_error(nullptr));
+        failed = 1;
+      } else {
+        std::vector<ilcc_result> res(n_local);
+        int32_t ticket = -1;
+        int32_t st = ilcc_submit_batch(h, h_xyzi, off.data(), n_local, h_click, &ticket);
+        if (st == ILCC_OK) st = ilcc_wait_records_device(h, ticket, res.data(), d_rec, j->n_corners, /*tag_base=*/lo);
+        if (st != ILCC_OK) {
+          std::fprintf(stderr, "rank %d: %s %s\n", j->rank, ilcc_strerror(st), ilcc_last_error(h));
+          failed = 1;
+        }
+      }
     }
-    ilcc_handle* h = ilcc_create(j->device, &j->params, n_local, std::max<uint64_t>(off[n_local], 1));
-    if (!h) {
-      std::fprintf(stderr, "rank %d: ilcc_create: %s\n", j->rank, ilcc_last_error(nullptr));
-      return 1;
-    }
-    std::vector<ilcc_result> res(n_local);
-    int32_t ticket = -1;
-    int32_t st = ilcc_submit_batch(h, h_xyzi, off.data(), n_local, h_click, &ticket);
-    if (st == ILCC_OK) st = ilcc_wait_records_device(h, ticket, res.data(), d_rec, j->n_corners, /*tag_base=*/lo);
-    if (st != ILCC_OK) {
-      std::fprintf(stderr, "rank %d: %s %s\n", j->rank, ilcc_strerror(st), ilcc_last_error(h));
-      return 1;
-    }
-    ilcc_destroy(h);
-    (void)hipHostFree(h_xyzi);
-    (void)hipHostFree(h_click);
   }
-  // the path's only collective
-  CHECK_NCCL(ncclGather(d_rec, d_all, rec_floats, ncclFloat, /*root=*/0, j->comm, stream));
-  CHECK_HIP(hipStreamSynchronize(stream));
-  if (j->rank == 0) {
-    j->gathered.resize(rec_floats * (size_t)j->world);
-    CHECK_HIP(hipMemcpy(j->gathered.data(), d_all, j->gathered.size() * 4, hipMemcpyDeviceToHost));
-    (void)hipFree(d_all);
+
+  // ---- the path's only collective: every rank that has its buffers takes part, failed or not
+  if (ready) {
+    const ncclResult_t e = ncclGather(d_rec, d_all, rec_floats, ncclFloat, /*root=*/0, j->comm, stream);
+    if (e != ncclSuccess) {
+      std::fprintf(stderr, "rank %d: ncclGather: %s\n", j->rank, ncclGetErrorString(e));
+      failed = 1;
+    }
+    (void)hip_ok(hipStreamSynchronize(stream), "hipStreamSynchronize");
+    if (j->rank == 0 && !failed) {
+      j->gathered.resize(rec_floats * (size_t)j->world);
+      (void)hip_ok(hipMemcpy(j->gathered.data(), d_all, j->gathered.size() * 4, hipMemcpyDeviceToHost), "hipMemcpy(gathered)");
+    }
+  } else {
+    // no buffers to gather from / into: fail the peers' collective instead of letting it wait for this rank
+    (void)ncclCommAbort(j->comm);
+    j->comm = nullptr;
   }
-  (void)hipFree(d_rec);
-  (void)hipStreamDestroy(stream);
-  return 0;
+
+  if (h) ilcc_destroy(h);
+  if (h_xyzi) (void)hipHostFree(h_xyzi);
+  if (h_click) (void)hipHostFree(h_click);
+  if (d_all) (void)hipFree(d_all);
+  if (d_rec) (void)hipFree(d_rec);
+  if (stream) (void)hipStreamDestroy(stream);
+  return failed;
 }
 
 }  // namespace
@@ -188,9 +212,15 @@ int main(int argc, char** argv) {
     threads.emplace_back([&j]() { j.status = run_rank(&j); });
   }
   for (std::thread& t : threads) t.join();
-  for (ncclComm_t c : comms) (void)ncclCommDestroy(c);
+  for (RankJob& j : jobs)
+    if (j.comm) (void)ncclCommDestroy(j.comm);   // (a rank that aborted its communicator has cleared the pointer)
+  int n_failed = 0;
   for (const RankJob& j : jobs)
-    if (j.status != 0) return 1;
+    if (j.status != 0) {
+      std::fprintf(stderr, "rank %d (device %d) failed\n", j.rank, j.device);
+      ++n_failed;
+    }
+  if (n_failed) return 1;
 
   // rank 0: every frame's record must sit at its own position (tag = global frame index) with intact contents
   const RankJob& root = jobs[0];

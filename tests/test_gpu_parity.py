@@ -828,12 +828,23 @@ def test_parameter_validation_and_second_handle():
     from lidar_camera_calibration_amd import IlccError
     e = LidarCornersBatch(2, 28800, N.default_params())
     for field, value in (("refine_div", 3), ("refine_div", 128), ("refine_max_rounds", -1), ("online_cluster_tol", 0.0),
-                         ("n_ty", 5000), ("grid_prune", 2), ("board_w", 9)):
+                         ("n_ty", 5000), ("grid_prune", 2), ("board_w", 9), ("min_cell_coverage", 1.5),
+                         ("ty_step", 10.0)):    # (ty_step = 10 m: one board square rounds to 0 refinement-lattice steps)
         p = N.default_params()
         setattr(p, field, value)
         with pytest.raises(IlccError):   # (n_ty = 5000: an axis is limited to 4096 candidates, so that n_ty + n_tz always fits the LDS
             # the grid kernel is allowed to ask for)
             e.set_params(p)
+    # the failed ilcc_set_params calls left the handle on its previous parameter set, tables included
+    # the K7r diagnostic entry refuses a theta lattice coordinate outside its cos/sin table
+    yz = np.zeros((8, 2), np.float32)
+    lab = np.zeros(8, np.uint8)
+    lib = N.lib()
+    for bad_th in (-10 ** 6, 10 ** 6):
+        lat = (C.c_int32 * 3)(bad_th, 0, 0)
+        ph = C.c_int32(0)
+        st = lib.ilcc_pattern_refine(e._h, N.fptr(yz), lab.ctypes.data_as(C.POINTER(C.c_uint8)), 8, lat, C.byref(ph), None, None, None, None)
+        assert st == N.BAD_ARGUMENT
     e2 = LidarCornersBatch(2, 28800, N.default_params())       # second handle, same device
     clouds, clicks, _, _ = synth.make_batch(2, fixture_poses=True)
     a = [r.corners_array() for r in e.extract(clouds, clicks)]

@@ -144,23 +144,32 @@ def test_cpp_mirror_runs_the_reference_node_loop(tmp_path, golden_dir, solver):
 def test_cpp_multi_gpu_driver_gathers_with_rccl(tmp_path, golden_dir):
     """ilcc_corners_mgpu: one thread + one ilcc_handle per GPU, contiguous shards, H2D on the batch's stream, records
     packed on the GPU and ONE ncclGather (RCCL, C++) to rank 0, which checks tag + content word of every record and
-    writes the files.  One GPU here (a 1-rank communicator); the files must be the Python mirror's byte for byte."""
+    writes the files.  Runs on EVERY device of the box (n_gpus = 0): a 1-rank communicator on the 1-GPU box, N ranks on
+    an N-GPU node, where each frame's record must come from rank f // ceil(F / N).  The files must be the Python
+    mirror's byte for byte."""
+    import torch
     mgpu = os.path.join(PKG, "ilcc_corners_mgpu")
     assert os.path.exists(mgpu)
+    ndev = torch.cuda.device_count()
     yaml = os.path.join(golden_dir, "pointgrey.yaml")
-    frames = _frames(3)
-    frames.insert(1, (frames[0][0], np.array([40.0, 40.0, 40.0], np.float32)))     # a frame without a board
-    argv = [mgpu, yaml, str(tmp_path / "pointgrey"), "1"]
+    base = _frames(3)
+    frames = [base[k % 3] for k in range(max(3, ndev + 1))]                         # more frames than GPUs: every rank works
+    frames.insert(1, (base[0][0], np.array([40.0, 40.0, 40.0], np.float32)))        # a frame without a board
+    F = len(frames)
+    per = -(-F // ndev)
+    argv = [mgpu, yaml, str(tmp_path / "pointgrey"), "0"]
     for k, (cloud, click) in enumerate(frames):
         raw = tmp_path / ("f%d.bin" % k)
         cloud.tofile(raw)
         argv += [str(raw), *("%.9g" % v for v in click)]
     r = subprocess.run(argv, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "gathered 4 records from 1 GPU(s) with one ncclGather; 3 files written" in r.stdout
+    assert "gathered %d records from %d GPU(s) with one ncclGather; %d files written" % (F, ndev, F - 1) in r.stdout
     lines = [ln.split() for ln in r.stdout.splitlines() if ln.startswith("frame ")]
+    assert len(lines) == F
     for k, (cloud, click) in enumerate(frames):
         f = dict(zip(lines[k][2::2], lines[k][3::2]))
+        assert int(f["rank"]) == k // per                                           # whose record sits where
         if k == 1:
             assert int(f["status"]) == N.NO_ROI_POINTS and f["file"] == "-"
             continue
@@ -168,6 +177,11 @@ def test_cpp_multi_gpu_driver_gathers_with_rccl(tmp_path, golden_dir):
         ok, st, _ = _python_mirror_file(cloud, click, yaml, str(py), N.SOLVER_GRID)
         assert ok and int(f["status"]) == st == N.OK
         assert open(f["file"], "rb").read() == py.read_bytes()
+    # a rank whose local work fails still joins the collective: the driver exits with an error, it does not hang
+    # (round-2 advisor finding); the LAST rank fails, so that on an N-GPU node the other ranks really wait for it
+    env = dict(os.environ, ILCC_MGPU_FAIL_RANK=str(ndev - 1))
+    r = subprocess.run(argv, capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 1 and "rank %d (device %d) failed" % (ndev - 1, ndev - 1) in r.stderr, r.stdout + r.stderr
 
 
 def _bench(env_extra, args, launcher=None, timeout=300):
