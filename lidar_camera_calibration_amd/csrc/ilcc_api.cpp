@@ -41,9 +41,9 @@ struct Slot {
   uint32_t *d_nlab = nullptr, *d_walk = nullptr, *d_counts = nullptr, *d_parent = nullptr, *d_count = nullptr;
   unsigned long long* d_masks = nullptr;
   uint32_t *d_hash_head = nullptr, *d_hash_next = nullptr, *d_big = nullptr;   // d_big: [0] count, [1..] listed frames
-  GridPartial *d_partial = nullptr, *d_partial2 = nullptr, *d_partial3 = nullptr;
+  GridPartial *d_partial = nullptr, *d_partial2 = nullptr, *d_partial3 = nullptr, *d_partial4 = nullptr;
   SolveRec* d_solverec = nullptr;
-  uint32_t* d_bound = nullptr;
+  uint32_t *d_bound = nullptr, *d_bound_sub = nullptr;
   uint32_t* d_tie_count = nullptr;
   GridPartial* d_tie_list = nullptr;
   unsigned long long* d_iters = nullptr;
@@ -232,8 +232,8 @@ int32_t upload_tables(ilcc_handle* h) {
 
 void free_slot(Slot& sl) {
   void* bufs[] = {sl.d_xyzi, sl.d_clicks, sl.d_off, sl.d_res, sl.d_roi, sl.d_cluster, sl.d_board, sl.d_pca, sl.d_optim,
-                  sl.d_yz, sl.d_lab, sl.d_cls, sl.d_nlab, sl.d_walk, sl.d_counts, sl.d_parent, sl.d_count, sl.d_hash_head, sl.d_hash_next, sl.d_big, sl.d_partial, sl.d_partial2, sl.d_partial3, sl.d_masks,
-                  sl.d_solverec, sl.d_bound, sl.d_iters, sl.d_tie_count, sl.d_tie_list};
+                  sl.d_yz, sl.d_lab, sl.d_cls, sl.d_nlab, sl.d_walk, sl.d_counts, sl.d_parent, sl.d_count, sl.d_hash_head, sl.d_hash_next, sl.d_big, sl.d_partial, sl.d_partial2, sl.d_partial3, sl.d_partial4, sl.d_masks,
+                  sl.d_solverec, sl.d_bound, sl.d_bound_sub, sl.d_iters, sl.d_tie_count, sl.d_tie_list};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (sl.h_res) (void)hipHostFree(sl.h_res);
@@ -312,8 +312,10 @@ int32_t alloc_slot(ilcc_handle* h, Slot& sl) {
   ALLOC(sl.d_partial, sizeof(GridPartial) * (size_t)mf * h->max_theta);
   ALLOC(sl.d_partial2, sizeof(GridPartial) * (size_t)mf * h->max_theta);
   ALLOC(sl.d_partial3, sizeof(GridPartial) * (size_t)mf * h->max_theta);
+  ALLOC(sl.d_partial4, sizeof(GridPartial) * (size_t)mf * 4);
   ALLOC(sl.d_solverec, sizeof(SolveRec) * 2 * (size_t)mf);
   ALLOC(sl.d_bound, sizeof(uint32_t) * mf);
+  ALLOC(sl.d_bound_sub, sizeof(uint32_t) * mf);
   ALLOC(sl.d_tie_count, sizeof(uint32_t) * mf);
   ALLOC(sl.d_tie_list, sizeof(GridPartial) * (size_t)mf * kTieCap);
   ALLOC(sl.d_iters, sizeof(unsigned long long) * 2 * kIterSlots);
@@ -359,6 +361,9 @@ Ctx make_ctx(ilcc_handle* h, Slot& sl, const float4* d_xyzi, const float* d_clic
   c.grid_blocks = (uint32_t)h->p.n_th;
   c.grid_lds_points = h->grid_lds_points;
   c.grid_bound = sl.d_bound;
+  c.grid_bound_sub = sl.d_bound_sub;
+  c.walk_limit = 0;
+  c.seed_k_from_flat = 0;
   c.tie_count = nullptr;   // only the full pass of K6 collects; K7a gets the pointers below
   c.tie_count_all = sl.d_tie_count;
   c.tie_list = sl.d_tie_list;
@@ -472,8 +477,15 @@ int32_t enqueue_impl(ilcc_handle* h, int si, const float4* d_xyzi, const uint64_
     // (grid_prune = 0 keeps the two small passes: they only initialise the frame's bound, which the cut-free full
     // pass still needs to recognise near ties; it never cuts a tile)
     if (h->n_th2 > 0 && h->p.n_th >= 8 && h->p.n_ty >= 8 && h->p.n_tz >= 8) {
-      // seeding pass: a decimated subset of the SAME candidates, fully evaluated (with pruning
-      // among themselves) -> per-frame bound + where to start the full pass
+      // All three small launches below only have to LOCATE the minimum.  The first two therefore look at a prefix of the
+      // point walk (an eighth of the frame's labelled points, at least ILCC_SEED_POINTS = 128 positions: a uniform sample of
+      // the board) and keep their own bound word; the anchor launch evaluates what they found -- 3 thetas x 8 x 8 translations
+      // around the refinement's argmin -- on EVERY point and publishes the frame's real bound.  (Round 2 ran seed and
+      // refinement on all points: 16 % of the path's VALU instructions.)
+#ifndef ILCC_SEED_POINTS
+#define ILCC_SEED_POINTS 128
+#endif
+      const uint32_t sub = (uint32_t)ILCC_SEED_POINTS;
       Ctx seed = c;
       seed.cth = h->d_cth2;
       seed.sth = h->d_sth2;
@@ -484,21 +496,53 @@ int32_t enqueue_impl(ilcc_handle* h, int si, const float4* d_xyzi, const uint64_
       seed.p.n_tz = h->n_tz2;
       seed.grid_blocks = (uint32_t)h->n_th2;
       seed.partial = sl.d_partial2;
+      seed.walk_limit = sub;
+      if (sub) seed.grid_bound = sl.d_bound_sub;
       launch_grid_cost(seed, s, /*use_oob=*/1, nullptr, true);
-      full.seed_partial = sl.d_partial2;
-      full.seed_blocks = (uint32_t)h->n_th2;
-      full.seed_n_ty = h->n_ty2;
-      full.seed_n_tz = h->n_tz2;
-      full.seed_stride_t = h->seed_stride_t;
-      full.seed_stride_th = h->seed_stride_th;
-      full.seed_off_th = h->seed_stride_th / 2;
-      {
-        // refinement pass: all candidates around the seed argmin (theta +- half a seed stride, 8 x 8 translations)
-        Ctx refine = full;
-        refine.refine_radius_th = std::max(1, h->seed_stride_th / ILCC_REFINE_RADIUS_DIV);
-        refine.grid_blocks = std::min((uint32_t)(2 * refine.refine_radius_th + 1), h->max_theta);
-        refine.partial = sl.d_partial3;
-        launch_grid_cost(refine, s, /*use_oob=*/1, nullptr, true);
+      Ctx refine = c;
+      refine.seed_partial = sl.d_partial2;
+      refine.seed_blocks = (uint32_t)h->n_th2;
+      refine.seed_n_ty = h->n_ty2;
+      refine.seed_n_tz = h->n_tz2;
+      refine.seed_stride_t = h->seed_stride_t;
+      refine.seed_stride_th = h->seed_stride_th;
+      refine.seed_off_th = h->seed_stride_th / 2;
+      // refinement pass: all candidates around the seed argmin (theta +- a third of a seed stride, 8 x 8 translations)
+      refine.refine_radius_th = std::max(1, h->seed_stride_th / ILCC_REFINE_RADIUS_DIV);
+      refine.grid_blocks = std::min((uint32_t)(2 * refine.refine_radius_th + 1), h->max_theta);
+      refine.partial = sl.d_partial3;
+      refine.walk_limit = sub;
+      if (sub) refine.grid_bound = sl.d_bound_sub;
+      launch_grid_cost(refine, s, /*use_oob=*/1, nullptr, true);
+      if (sub) {
+        Ctx anchor = c;
+        anchor.seed_partial = sl.d_partial3;
+        anchor.seed_blocks = refine.grid_blocks;
+        anchor.seed_n_ty = h->p.n_ty;
+        anchor.seed_n_tz = h->p.n_tz;
+        anchor.seed_stride_t = 1;
+        anchor.seed_stride_th = 1;
+        anchor.seed_off_th = 0;
+        anchor.seed_k_from_flat = 1;
+        anchor.refine_radius_th = 1;
+        anchor.grid_blocks = 3;
+        anchor.partial = sl.d_partial4;
+        launch_grid_cost(anchor, s, /*use_oob=*/1, nullptr, true);
+        full.seed_partial = sl.d_partial4;
+        full.seed_blocks = 3;
+        full.seed_n_ty = h->p.n_ty;
+        full.seed_n_tz = h->p.n_tz;
+        full.seed_stride_t = 1;
+        full.seed_stride_th = 1;
+        full.seed_off_th = 0;
+      } else {
+        full.seed_partial = sl.d_partial2;
+        full.seed_blocks = (uint32_t)h->n_th2;
+        full.seed_n_ty = h->n_ty2;
+        full.seed_n_tz = h->n_tz2;
+        full.seed_stride_t = h->seed_stride_t;
+        full.seed_stride_th = h->seed_stride_th;
+        full.seed_off_th = h->seed_stride_th / 2;
       }
     }
     // The FULL passes of different slots are chained so that they never share the chip (their HIP-event

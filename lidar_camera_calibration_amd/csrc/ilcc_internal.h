@@ -125,6 +125,9 @@ struct Ctx {
   uint32_t grid_blocks;      // K6 workgroups per frame
   uint32_t grid_lds_points;  // K6 points staged in LDS per workgroup (multiple of 64)
   uint32_t* grid_bound;      // per frame: float bits of the best complete candidate cost so far (K6 pruning)
+  uint32_t* grid_bound_sub;  // the same for the subsampled seed / refinement launches (costs over a prefix of the walk: never a valid bound for complete costs)
+  uint32_t walk_limit;       // K6: 0 = every labelled point; else only the first walk_limit positions of the walk (a uniform sample of the board)
+  uint32_t seed_k_from_flat; // K6: the seed records come from a launch over the FULL tables: theta index = flat / (2 n_ty n_tz), not the record's position
   // near ties: candidates of the full pass whose fp32 cost is within kTieEps of the bound at the time they
   // complete; K7r recounts them on the oracle's fixed-point cost so that the argmin is the oracle's even when fp32 cannot order them
   uint32_t* tie_count;       // per frame (nullptr: this launch does not collect)

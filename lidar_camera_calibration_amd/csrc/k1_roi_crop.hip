@@ -70,6 +70,7 @@ __global__ __launch_bounds__(kCropThreads) void k1_roi_count(Ctx c) {
     r->theta_t[0] = r->theta_t[1] = r->theta_t[2] = 0.0;
     c.n_lab[f] = 0;
     c.grid_bound[f] = 0x7f800000u;   // +inf
+    c.grid_bound_sub[f] = 0x7f800000u;
     if (f == 0) *c.big_count = 0u;   // K2's list of frames above its LDS capacity
   }
   const uint64_t cbeg = (uint64_t)s * kCropChunk;

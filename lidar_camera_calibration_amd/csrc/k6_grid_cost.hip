@@ -50,6 +50,9 @@ __device__ unsigned long long k6_prof[kProfWaves * kProfWords];   // one record 
 #else
 #define K6_NOW() 0ull
 #endif
+#ifndef ILCC_SEED_SHIFT
+#define ILCC_SEED_SHIFT 3   // subsampled launches walk M >> ILCC_SEED_SHIFT positions (at least Ctx::walk_limit)
+#endif
 #ifndef ILCC_K6_BOUND_REFRESH
 #define ILCC_K6_BOUND_REFRESH 256
 #endif
@@ -145,7 +148,7 @@ __device__ __forceinline__ Best seed_argmin(const Ctx& c, uint32_t f, uint32_t& 
     const GridPartial g = sp[q];
     if (better(g.cost, g.d2, g.flat, sb)) {
       sb = Best{g.cost, g.d2, g.flat};
-      k2 = q;
+      k2 = q;       // seed launch: workgroup q = seed theta q
       ab = g.pad;   // (a << 16) | b of the record's candidate in ITS launch's tables
     }
   }
@@ -172,7 +175,11 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
     }
     return;
   }
-  const uint32_t M = c.n_lab[f];
+  // walk_limit: the seed and refinement launches only look at a PREFIX of the walk -- the golden-ratio order makes it a
+  // uniform sample of the board -- to find WHERE the minimum is; their sums are not costs of complete candidates and go to
+  // a bound word of their own.  The anchor launch then evaluates the found neighbourhood on every point: that is the bound.
+  const uint32_t Mfull = c.n_lab[f];
+  const uint32_t M = c.walk_limit ? min(Mfull, max(c.walk_limit, Mfull >> ILCC_SEED_SHIFT)) : Mfull;   // an eighth of the points (measured: 1/2: 323 k, 1/4: 331 k, 1/8: 335 k, 1/16: 329 k frames/s), at least walk_limit
   const uint64_t beg = c.off[f];
   const float2* __restrict__ gyz = c.yz + beg;
   const uint8_t* __restrict__ glab = c.lab + beg;
@@ -185,7 +192,9 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
     const Best sb = seed_argmin(c, f, k2u, ab);
     if (sb.flat != 0xFFFFFFFFu) {
       const int a2 = __builtin_amdgcn_readfirstlane((int)(ab >> 16)), b2 = __builtin_amdgcn_readfirstlane((int)(ab & 0xFFFFu));
-      const int k2 = __builtin_amdgcn_readfirstlane((int)k2u);
+      // (records of a launch over the full tables carry the theta index in their flat index: one division per wavefront of
+      // the small anchor launch)
+      const int k2 = __builtin_amdgcn_readfirstlane(c.seed_k_from_flat ? (int)((sb.flat >> 1) / (uint32_t)(n_ty * n_tz)) : (int)k2u);
       const int sa = min(a2 * c.seed_stride_t, n_ty - 1), sbb = min(b2 * c.seed_stride_t, n_tz - 1);
       if (c.refine_radius_th > 0) {
         // refinement pass: every candidate within +-radius theta steps and the 8 x 8 (ty, tz) window
@@ -208,7 +217,7 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
   // Point order: slot s holds point (s * S) mod M with S ~ 0.618 M coprime to M, so that EVERY prefix
   // of the walk is a sample spread over the whole board (ring order would spend the first points on
   // one scan line, which says little about a candidate): the bound test cuts tiles sooner.
-  const uint32_t S = M ? c.walk_stride[f] : 1u;   // walk_stride(M), computed where n_lab is written
+  const uint32_t S = Mfull ? c.walk_stride[f] : 1u;   // walk_stride(Mfull), computed where n_lab is written
   // Staged points come in two classes.  INTERIOR: in the board under EVERY translation of the tables (checked with
   // accumulate<>'s own fp32 expressions at the four extreme translations; |i - W/2| - W/2 is V-shaped in i and every
   // operation is monotone, so the extremes decide for all values in between) -> accumulate_interior.  BORDER: the rest.
@@ -220,8 +229,8 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
     const float ay_lo = c.ay[0], ay_hi = c.ay[c.p.n_ty - 1], az_lo = c.az[0], az_hi = c.az[c.p.n_tz - 1];
     uint32_t base_in = 0, base_out = 0;
     // slot sl <- point (sl * S) mod M, advanced chunk by chunk (M <= 8192 here: the products fit 32 bits)
-    uint32_t pidx = M ? (threadIdx.x * S) % M : 0u;
-    const uint32_t pstep = M ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(((uint32_t)THREADS * S) % M)) : 0u;
+    uint32_t pidx = Mfull ? (threadIdx.x * S) % Mfull : 0u;
+    const uint32_t pstep = Mfull ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(((uint32_t)THREADS * S) % Mfull)) : 0u;
     for (uint32_t c0 = 0; c0 < M; c0 += THREADS) {
       const uint32_t sl = c0 + threadIdx.x;
       const bool valid = sl < M;
@@ -230,7 +239,7 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
       bool interior = false;
       const uint32_t i = pidx;
       pidx += pstep;
-      if (pidx >= M) pidx -= M;
+      if (pidx >= Mfull) pidx -= Mfull;
       if (valid) {
         const float2 v = gyz[i];
         // Rx(theta) on (0,y,z), already divided by g (Optimization.h:37-46)
@@ -346,8 +355,8 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
     if (PRUNE) gb_bits = __hip_atomic_load(bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // lane's points: walk positions my_s, my_s + 4, ...  (LDS_POINTS = false: point index (pos * S) mod M)
     // (M == 0: no point is ever fetched, every candidate costs 0; keep the modulo defined)
-    uint32_t idx = M ? (uint32_t)(((uint64_t)my_s * S) % M) : 0u;
-    const uint32_t idx_step = M ? (uint32_t)(((uint64_t)kSlices * S) % M) : 0u;
+    uint32_t idx = Mfull ? (uint32_t)(((uint64_t)my_s * S) % Mfull) : 0u;
+    const uint32_t idx_step = Mfull ? (uint32_t)(((uint64_t)kSlices * S) % Mfull) : 0u;
     uint32_t pos = 0;
     auto fetch = [&](uint32_t at) -> PointTerms {   // at = walk position of THIS lane's point
       if (LDS_POINTS) {
@@ -357,7 +366,7 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
         const float2 v = gyz[idx];
         const PointTerms t{fmaf(-sth, v.y, cth * v.x), fmaf(cth, v.y, sth * v.x), glab[idx] ? 0.5f : 0.f};
         idx += idx_step;
-        if (idx >= M) idx -= M;
+        if (idx >= Mfull) idx -= Mfull;
         return t;
       }
     };
@@ -490,7 +499,7 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
         }
       }
       if (!(PRUNE && pruned)) {
-        if (!LDS_POINTS && M) idx = (uint32_t)(((uint64_t)(pos + my_s) * S) % M);
+        if (!LDS_POINTS && Mfull) idx = (uint32_t)(((uint64_t)(pos + my_s) * S) % Mfull);
         for (; pos < M; pos += kSlices) {   // tail (< 12 points): one point per lane and trip, lanes past the end idle
           const uint32_t at = pos + my_s;
           if (at < M) {
@@ -653,7 +662,8 @@ __global__ __launch_bounds__(THREADS) void k6_grid_cost(Ctx c, float* volume) {
   float* s_hw = reinterpret_cast<float*>(smem + sizeof(float2) * (size_t)c.grid_lds_points);
   float* s_ay = s_hw + c.grid_lds_points;   // n_ty floats
   float* s_az = s_ay + c.p.n_ty;            // n_tz floats
-  const uint32_t M = c.n_lab[blockIdx.y];
+  const uint32_t Mall = c.n_lab[blockIdx.y];
+  const uint32_t M = c.walk_limit ? min(Mall, max(c.walk_limit, Mall >> ILCC_SEED_SHIFT)) : Mall;
   if (M <= c.grid_lds_points)
     grid_cost_body<OOB, VOLUME, true, PRUNE, THREADS>(c, volume, s_ij, s_hw, s_best, s_iters, s_cnt, s_ay, s_az);
   else
