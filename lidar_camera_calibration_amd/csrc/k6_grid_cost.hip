@@ -321,14 +321,26 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
   };
 
   // first block of each class in registers (see run_tile); needs a full block of both classes
-  const bool first_block = LDS_POINTS && Mi >= (uint32_t)kStep && M - Mi >= (uint32_t)kStep;
-  PointTerms first_in[kUnroll], first_bd[kUnroll];
+#ifndef ILCC_K6_FIRST_IN
+#define ILCC_K6_FIRST_IN 0   // interior- / border-class points per lane in the first (register-resident) block
+#endif
+#ifndef ILCC_K6_FIRST_BD
+#define ILCC_K6_FIRST_BD 4   // border-class points say more about a wrong candidate (they also feel the outline): measured first block in+bd 2+2: 335 k, 1+3: 344 k, 0+4: 345 k frames/s
+#endif
+  constexpr int kFirstIn = ILCC_K6_FIRST_IN, kFirstBd = ILCC_K6_FIRST_BD;
+  const bool first_block = LDS_POINTS && Mi >= (uint32_t)(kFirstIn * kSlices) && M - Mi >= (uint32_t)(kFirstBd * kSlices);
+  PointTerms first_in[kFirstIn > 0 ? kFirstIn : 1], first_bd[kFirstBd > 0 ? kFirstBd : 1];
   if (LDS_POINTS && first_block) {
 #pragma unroll
-    for (int u = 0; u < kUnroll; ++u) {
-      const uint32_t ai = (uint32_t)(u * kSlices + my_s), ab = Mi + ai;
-      const float2 vi = s_ij[ai], vb = s_ij[ab];
+    for (int u = 0; u < kFirstIn; ++u) {
+      const uint32_t ai = (uint32_t)(u * kSlices + my_s);
+      const float2 vi = s_ij[ai];
       first_in[u] = PointTerms{vi.x, vi.y, s_hw[ai]};
+    }
+#pragma unroll
+    for (int u = 0; u < kFirstBd; ++u) {
+      const uint32_t ab = Mi + (uint32_t)(u * kSlices + my_s);
+      const float2 vb = s_ij[ab];
       first_bd[u] = PointTerms{vb.x, vb.y, s_hw[ab]};
     }
   }
@@ -392,11 +404,11 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
       // the rejection path of a tile touches LDS only for its (ty, tz) pair and never prefetches a block it will not use
       if (first_block) {
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) accumulate_interior(first_in[u], ay, az, delta2, A0, A1);
+        for (int u = 0; u < kFirstIn; ++u) accumulate_interior(first_in[u], ay, az, delta2, A0, A1);
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) accumulate<OOB>(first_bd[u], ay, az, Wh, Hh, delta2, A0, A1);
-        pin = kStep;
-        pbd = Mi + kStep;
+        for (int u = 0; u < kFirstBd; ++u) accumulate<OOB>(first_bd[u], ay, az, Wh, Hh, delta2, A0, A1);
+        pin = kFirstIn * kSlices;
+        pbd = Mi + kFirstBd * kSlices;
         if (PRUNE) {
           if (beaten())
             pruned = true;
@@ -410,19 +422,29 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
       // other wavefronts, and the registers of a second block in flight cost a wavefront of occupancy (measured with two
       // named register sets: 83 VGPRs, 267 k instead of 281 k frames/s).
       if (!(PRUNE && pruned)) {
-        uint32_t both = (uint32_t)__builtin_amdgcn_readfirstlane((int)min((Mi - min(pin, Mi)) / (uint32_t)kStep, (M - pbd) / (uint32_t)kStep));
+#ifndef ILCC_K6_LOOP_IN
+#define ILCC_K6_LOOP_IN 1   // interior- / border-class points per lane and trip of this loop
+#endif
+#ifndef ILCC_K6_LOOP_BD
+#define ILCC_K6_LOOP_BD 3   // (with the 0+4 first block) loop 2+2: 345 k, 1+3: 350 k, 0+4: 347 k frames/s
+#endif
+        constexpr int kLoopIn = ILCC_K6_LOOP_IN, kLoopBd = ILCC_K6_LOOP_BD;
+        constexpr uint32_t kStepIn = kLoopIn * kSlices, kStepBd = kLoopBd * kSlices;
+        uint32_t both = (uint32_t)__builtin_amdgcn_readfirstlane(
+            (int)min(kLoopIn ? (Mi - min(pin, Mi)) / (kLoopIn ? kStepIn : 1u) : 0x7FFFFFFFu, kLoopBd ? (M - pbd) / (kLoopBd ? kStepBd : 1u) : 0x7FFFFFFFu));
         for (; both; --both) {
-          PointTerms bi[kUnroll], bb[kUnroll];
+          PointTerms bi[kLoopIn > 0 ? kLoopIn : 1], bb[kLoopBd > 0 ? kLoopBd : 1];
 #pragma unroll
-          for (int u = 0; u < kUnroll; ++u) bi[u] = fetch(pin + u * kSlices + my_s);
+          for (int u = 0; u < kLoopIn; ++u) bi[u] = fetch(pin + u * kSlices + my_s);
 #pragma unroll
-          for (int u = 0; u < kUnroll; ++u) bb[u] = fetch(pbd + u * kSlices + my_s);
+          for (int u = 0; u < kLoopBd; ++u) bb[u] = fetch(pbd + u * kSlices + my_s);
 #pragma unroll
-          for (int u = 0; u < kUnroll; ++u) accumulate_interior(bi[u], ay, az, delta2, A0, A1);
+          for (int u = 0; u < kLoopIn; ++u) accumulate_interior(bi[u], ay, az, delta2, A0, A1);
 #pragma unroll
-          for (int u = 0; u < kUnroll; ++u) accumulate<OOB>(bb[u], ay, az, Wh, Hh, delta2, A0, A1);
-          pin += kStep;
-          pbd += kStep;
+          for (int u = 0; u < kLoopBd; ++u) accumulate<OOB>(bb[u], ay, az, Wh, Hh, delta2, A0, A1);
+          pin += kStepIn;
+          pbd += kStepBd;
+          since_refresh += kStepIn + kStepBd - kStep;   // (refresh() adds kStep)
           if (PRUNE) {
             if (beaten()) {
               pruned = true;
