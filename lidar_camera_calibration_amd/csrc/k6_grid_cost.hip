@@ -229,56 +229,106 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
     const float ay_lo = c.ay[0], ay_hi = c.ay[c.p.n_ty - 1], az_lo = c.az[0], az_hi = c.az[c.p.n_tz - 1];
     uint32_t base_in = 0, base_out = 0;
     // slot sl <- point (sl * S) mod M, advanced chunk by chunk (M <= 8192 here: the products fit 32 bits)
-    uint32_t pidx = Mfull ? (threadIdx.x * S) % Mfull : 0u;
+#ifndef ILCC_K6_RIM
+#define ILCC_K6_RIM 300   // border-class points within this many thousandths of a square of the outline (at zero translation) are walked FIRST: rim 0: 350 k, 150: 355 k, 300: 357 k, 500: 351 k frames/s (first block 0+4); with a 0+2 first block 200: 385 k, 300: 388 k, 400: 384 k
+#endif
+    const float ay_c = c.ay[c.c_ty], az_c = c.az[c.c_tz];
+    const float rim_thr = -(float)ILCC_K6_RIM * 1e-3f;
     const uint32_t pstep = Mfull ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(((uint32_t)THREADS * S) % Mfull)) : 0u;
+    // class: 0 interior, 1 border, 2 rim (border and close to the outline at zero translation)
+    auto classify = [&](uint32_t i, float2& ij, float& hw) -> int {
+      const float2 v = gyz[i];
+      // Rx(theta) on (0,y,z), already divided by g (Optimization.h:37-46)
+      ij = make_float2(fmaf(-sth, v.y, cth * v.x), fmaf(cth, v.y, sth * v.x));
+      hw = glab[i] ? 0.5f : 0.f;
+      if (!ILCC_K6_SPLIT) return 1;
+      const float u0 = fabsf((ij.x + ay_lo) - Wh_) - Wh_, u1 = fabsf((ij.x + ay_hi) - Wh_) - Wh_;
+      const float w0 = fabsf((ij.y + az_lo) - Hh_) - Hh_, w1 = fabsf((ij.y + az_hi) - Hh_) - Hh_;
+      if (fmaxf(fmaxf(u0, u1), fmaxf(w0, w1)) < 0.f) return 0;
+      if (ILCC_K6_RIM) {
+        const float uc = fabsf((ij.x + ay_c) - Wh_) - Wh_, wc = fabsf((ij.y + az_c) - Hh_) - Hh_;
+        if (fmaxf(uc, wc) > rim_thr) return 2;
+      }
+      return 1;
+    };
+    uint32_t n_rim = 0;
+    if (ILCC_K6_RIM) {   // counting pass: the rim points' region [Mi, Mi + n_rim) needs both totals before anything is placed
+      uint32_t pidx0 = Mfull ? (threadIdx.x * S) % Mfull : 0u;
+      uint32_t cnt_in = 0, cnt_rim = 0;
+      for (uint32_t c0 = 0; c0 < M; c0 += THREADS) {
+        const uint32_t i = pidx0;
+        pidx0 += pstep;
+        if (pidx0 >= Mfull) pidx0 -= Mfull;
+        if (c0 + threadIdx.x < M) {
+          float2 ij;
+          float hw;
+          const int cl = classify(i, ij, hw);
+          cnt_in += cl == 0;
+          cnt_rim += cl == 2;
+        }
+      }
+      cnt_in = wave_sum(cnt_in);
+      cnt_rim = wave_sum(cnt_rim);
+      if (lane == 0) {
+        s_iters[wid] = cnt_in;
+        s_cnt[wid] = cnt_rim;
+      }
+      __syncthreads();
+      uint32_t ti = 0, tr = 0;
+      for (int w = 0; w < THREADS / ILCC_WAVE; ++w) {
+        ti += s_iters[w];
+        tr += s_cnt[w];
+      }
+      __syncthreads();
+      Mi = ti;
+      n_rim = tr;
+    }
+    uint32_t pidx = Mfull ? (threadIdx.x * S) % Mfull : 0u;
+    uint32_t base_rim = 0;
     for (uint32_t c0 = 0; c0 < M; c0 += THREADS) {
       const uint32_t sl = c0 + threadIdx.x;
       const bool valid = sl < M;
       float2 ij = make_float2(0.f, 0.f);
       float hw = 0.f;
-      bool interior = false;
+      int cl = -1;
       const uint32_t i = pidx;
       pidx += pstep;
       if (pidx >= Mfull) pidx -= Mfull;
-      if (valid) {
-        const float2 v = gyz[i];
-        // Rx(theta) on (0,y,z), already divided by g (Optimization.h:37-46)
-        ij = make_float2(fmaf(-sth, v.y, cth * v.x), fmaf(cth, v.y, sth * v.x));
-        hw = glab[i] ? 0.5f : 0.f;
-        if (ILCC_K6_SPLIT) {
-          const float u0 = fabsf((ij.x + ay_lo) - Wh_) - Wh_, u1 = fabsf((ij.x + ay_hi) - Wh_) - Wh_;
-          const float w0 = fabsf((ij.y + az_lo) - Hh_) - Hh_, w1 = fabsf((ij.y + az_hi) - Hh_) - Hh_;
-          interior = fmaxf(fmaxf(u0, u1), fmaxf(w0, w1)) < 0.f;
-        }
-      }
-      const unsigned long long m_in = __ballot(valid && interior), m_out = __ballot(valid && !interior);
+      if (valid) cl = classify(i, ij, hw);
+      const bool interior = cl == 0, rim = cl == 2;
+      const unsigned long long m_in = __ballot(interior), m_out = __ballot(cl == 1), m_rim = __ballot(rim);
       const unsigned long long below = (1ull << lane) - 1ull;
       if (lane == 0) {
-        s_iters[wid] = (uint32_t)__popcll(m_in);          // (s_iters / s_cnt are free until the epilogue)
+        s_iters[wid] = (uint32_t)__popcll(m_in) | ((uint32_t)__popcll(m_rim) << 16);          // (s_iters / s_cnt are free until the epilogue)
         s_cnt[wid] = (uint32_t)__popcll(m_out);
       }
       __syncthreads();
-      uint32_t pre_in = 0, pre_out = 0, tot_in = 0, tot_out = 0;
+      uint32_t pre_in = 0, pre_out = 0, pre_rim = 0, tot_in = 0, tot_out = 0, tot_rim = 0;
 #pragma unroll
       for (int w = 0; w < THREADS / ILCC_WAVE; ++w) {
-        const uint32_t a = s_iters[w], b = s_cnt[w];
+        const uint32_t a = s_iters[w] & 0xFFFFu, r = s_iters[w] >> 16, b = s_cnt[w];
         if (w < wid) {
           pre_in += a;
           pre_out += b;
+          pre_rim += r;
         }
         tot_in += a;
         tot_out += b;
+        tot_rim += r;
       }
       if (valid) {
         const uint32_t at = interior ? base_in + pre_in + (uint32_t)__popcll(m_in & below)
+                            : rim    ? Mi + base_rim + pre_rim + (uint32_t)__popcll(m_rim & below)
                                      : M - 1u - (base_out + pre_out + (uint32_t)__popcll(m_out & below));
         s_ij[at] = ij;
         s_hw[at] = hw;
       }
       base_in += tot_in;
       base_out += tot_out;
+      base_rim += tot_rim;
       __syncthreads();
     }
+    (void)n_rim;
     Mi = (uint32_t)__builtin_amdgcn_readfirstlane((int)base_in);
   }
   // (ty, tz) tables in LDS: a cut-short tile lasts about as long as one L2 round trip, so its
@@ -325,7 +375,7 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
 #define ILCC_K6_FIRST_IN 0   // interior- / border-class points per lane in the first (register-resident) block
 #endif
 #ifndef ILCC_K6_FIRST_BD
-#define ILCC_K6_FIRST_BD 4   // border-class points say more about a wrong candidate (they also feel the outline): measured first block in+bd 2+2: 335 k, 1+3: 344 k, 0+4: 345 k frames/s
+#define ILCC_K6_FIRST_BD 2   // border-class (rim-first) points per lane before the first test: 1: 369 k, 2: 379 k, 3: 379 k, 4: 357 k frames/s (loop 1+3)
 #endif
   constexpr int kFirstIn = ILCC_K6_FIRST_IN, kFirstBd = ILCC_K6_FIRST_BD;
   const bool first_block = LDS_POINTS && Mi >= (uint32_t)(kFirstIn * kSlices) && M - Mi >= (uint32_t)(kFirstBd * kSlices);
@@ -423,10 +473,10 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
       // named register sets: 83 VGPRs, 267 k instead of 281 k frames/s).
       if (!(PRUNE && pruned)) {
 #ifndef ILCC_K6_LOOP_IN
-#define ILCC_K6_LOOP_IN 1   // interior- / border-class points per lane and trip of this loop
+#define ILCC_K6_LOOP_IN 0   // interior- / border-class points per lane and trip of this loop
 #endif
 #ifndef ILCC_K6_LOOP_BD
-#define ILCC_K6_LOOP_BD 3   // (with the 0+4 first block) loop 2+2: 345 k, 1+3: 350 k, 0+4: 347 k frames/s
+#define ILCC_K6_LOOP_BD 2   // (rim-first, 0+2 first block) loop in+bd 0+2: 388 k, 1+2: 383 k, 0+3: 383 k frames/s
 #endif
         constexpr int kLoopIn = ILCC_K6_LOOP_IN, kLoopBd = ILCC_K6_LOOP_BD;
         constexpr uint32_t kStepIn = kLoopIn * kSlices, kStepBd = kLoopBd * kSlices;
