@@ -395,13 +395,24 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
     }
   }
 
+  const bool whole_tiles = (n_ty % kTile) == 0 && (n_tz % kTile) == 0;   // (wave-uniform: a scalar branch per tile)
   // one 4 x 4 tile, quad-sliced (lane = candidate * 4 + slice), from walk positions (pin0, pbd0) on, sums starting at
   // (a0_init, a1_init)
   auto run_tile = [&](int tile_a, int tile_b, float a0_init, float a1_init, uint32_t pin0, uint32_t pbd0) {
     const int ia = a_org + tile_a * kTile + my_a, ib = b_org + tile_b * kTile + my_b;
-    const bool owner = ia < n_ty && ib < n_tz;
-    const unsigned long long owner_mask = __ballot(owner);   // an SGPR pair: the bound test is then ballot & mask, no VALU select
-    const float ay = s_ay[min(ia, n_ty - 1)], az = s_az[min(ib, n_tz - 1)];
+    // grids whose axes are multiples of the tile (the default 40 x 40) have no partial tiles: no clamps, no owner test
+    bool owner = true;
+    unsigned long long owner_mask = ~0ull;   // an SGPR pair: the bound test is then ballot & mask, no VALU select
+    float ay, az;
+    if (whole_tiles) {
+      ay = s_ay[ia];
+      az = s_az[ib];
+    } else {
+      owner = ia < n_ty && ib < n_tz;
+      owner_mask = __ballot(owner);
+      ay = s_ay[min(ia, n_ty - 1)];
+      az = s_az[min(ib, n_tz - 1)];
+    }
 
     // Branch and bound (PRUNE): costs are sums of non-negative terms, so a candidate whose partial
     // sum already exceeds the best COMPLETE cost known for this frame cannot be the argmin.
