@@ -68,7 +68,7 @@ PMC_FILES = {(2, 256): "profiles/r03_pmc_cfg2_256f.csv", (5, 64): "profiles/r03_
 
 
 def k6_pmc(config, frames_per_batch):
-    """Counters of the three K6 launches (seed, refinement, full pass) of ONE batch from the committed PMC summary:
+    """Counters of the K6 launches (seed, refinement, anchor, full pass) of ONE batch from the committed PMC summary:
     HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (MI355X_MICROARCH.md: FETCH_SIZE counts half the bytes of wide reads on
     gfx950; separate passes), issued VALU wavefront-instructions, busy cycles.  None when no file matches this run."""
     import csv
@@ -76,7 +76,7 @@ def k6_pmc(config, frames_per_batch):
     if not path or not os.path.exists(os.path.join(ROOT, path)):
         return None
     rows = [r for r in csv.DictReader(open(os.path.join(ROOT, path))) if "k6_grid_cost" in r["kernel"]]
-    if len(rows) != 3:
+    if len(rows) not in (3, 4):    # seed, refinement, (anchor,) full pass: one summary row per distinct launch size
         return None
     f = lambda r, k: float(r[k]) if r.get(k) not in (None, "") else 0.0
     full = max(rows, key=lambda r: f(r, "SQ_INSTS_VALU"))
@@ -397,7 +397,7 @@ def main():
                 "unit": "T lane-instr/s",
                 "frac": valu_rate / VALU_ISSUE_PEAK_T,
                 "traffic": pmc["traffic_bytes"] if pmc else None,
-                "traffic_note": "HBM bytes of the stage's three launches (seed, refinement, full pass) of one batch of THIS size alone "
+                "traffic_note": "HBM bytes of the stage's launches (seed, refinement, anchor, full pass) of one batch of THIS size alone "
                                 "on the chip: (2 x FETCH_SIZE + WRITE_SIZE) x 1024 from separate rocprofv3 --pmc passes, read at run time "
                                 "from %s (tools/gpu_pmc.sh); null when no committed file matches this config / batch size"
                                 % (pmc["file"] if pmc else "profiles/"),
@@ -405,7 +405,7 @@ def main():
                     "issued_valu_wave_instr_per_launch": pmc["valu_wave_instr"],
                     "credited_valu_wave_instr_per_launch": credited_wave_instr,
                     "uncredited_share": 1.0 - credited_wave_instr / pmc["valu_wave_instr"],
-                    "what": "issued = SQ_INSTS_VALU of the three K6 launches of one batch (PMC file, batch alone on the chip); credited = this "
+                    "what": "issued = SQ_INSTS_VALU of the K6 launches of one batch (PMC file, batch alone on the chip); credited = this "
                             "run's executed evaluations x the term's ISA count / 64 lanes.  The difference is bound tests, tile "
                             "prologues, staging, address arithmetic, idle lanes of tail blocks",
                     "full_pass_alone": dict(pmc["full_pass"],
@@ -427,7 +427,7 @@ def main():
                         "whole_path_frac": fps / max(1, world) * bytes_per_frame / 1e9 / HBM_PEAK_GBPS},
                 "note": "k6_grid_cost is VALU-bound by construction (points staged once in LDS, ~1e8 nominal "
                         "point-candidate evaluations per frame, no MFMA): achieved = executed evaluations x their VALU "
-                        "instructions (%g border-class, %g interior-class, tools/k6_isa_count.sh: the term only -- bound tests, prologues and address arithmetic are not credited) / launch duration." % (K6_VALU_OPS_BORDER, K6_VALU_OPS_INTERIOR) + "  launch = the K6 stage of one batch (seed + refinement + full "
+                        "instructions (%g border-class, %g interior-class, tools/k6_isa_count.sh: the term only -- bound tests, prologues and address arithmetic are not credited) / launch duration." % (K6_VALU_OPS_BORDER, K6_VALU_OPS_INTERIOR) + "  launch = the K6 stage of one batch (seed + refinement + anchor + full "
                         "launch), timed by HIP events on the library's stream (the wait for the previous batch's full pass "
                         "between the refinement and the full launch is excluded).  `hbm` holds the algorithmic-bytes "
                         "fraction of the 8 TB/s peak that BASELINE.json asks for",

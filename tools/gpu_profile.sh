@@ -1,22 +1,24 @@
-# kernel-level profile of the default bench (run through gpurun from the repo root): rocprofv3 kernel stats of the
-# timed pipeline only (no extra legs), the un-contended single-batch timeline, optional PMC passes
-TAG=${1:-r02}
+# kernel-level profile of the default bench (run through gpurun from the repo root): tools/gpu_profile.sh TAG [pmc]
+#   - un-contended single-batch timeline (HIP events), both solver modes
+#   - rocprofv3 --kernel-trace --stats of the default bench, timed pipeline only (4 batches in flight) -> <TAG>_kernel_stats_bench_20_5.csv
+#   - the same with --in-flight 1 (one batch alone on the chip: clean per-kernel durations) -> <TAG>_kernel_stats_bench_inflight1.csv
+#   - with `pmc`: PMC passes at the batch sizes the bench runs (tools/gpu_pmc.sh: config 2 / 256 frames, config 5 / 64 frames)
+TAG=${1:-r03}
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out
-python tools/dev_batch_timeline.py 1 30 2>/dev/null | tail -1
-python tools/dev_batch_timeline.py 0 30 2>/dev/null | tail -1
+python tools/dev_batch_timeline.py 1 30 2>/dev/null | tail -1 | tee $R/gpurun_out/${TAG}_timeline_grid.json
+python tools/dev_batch_timeline.py 0 30 2>/dev/null | tail -1 | tee $R/gpurun_out/${TAG}_timeline_reference.json
 cd /tmp && export TMPDIR=/tmp
-ILCC_BENCH_GEN_WORKERS=1 timeout 420 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_stats -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra-legs > $R/gpurun_out/prof_${TAG}_bench.json 2> /dev/null
+for MODE in "20_5:" "inflight1:--in-flight 1"; do
+  N=${MODE%%:*}; A=${MODE#*:}
+  ILCC_BENCH_GEN_WORKERS=1 timeout 420 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_stats_$N -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra-legs $A > $R/gpurun_out/prof_${TAG}_bench_$N.json 2> /dev/null
+  F=$(find $R/gpurun_out/prof_${TAG}_stats_$N -name "*kernel_stats.csv" | head -1)
+  cp $F $R/gpurun_out/${TAG}_kernel_stats_bench_$N.csv; cut -c1-150 $F | head -18
+  python -c "
+import json; d=json.load(open('$R/gpurun_out/prof_${TAG}_bench_$N.json')); print('BENCH under rocprof ($N)', round(d['value']), d['ms_per_step'], d['roofline']['launch_ms'])"
+done
 cd $R
-find gpurun_out/prof_${TAG}_stats -name "*kernel_stats.csv" | head -1 | xargs -I{} sh -c "cp {} gpurun_out/${TAG}_kernel_stats.csv; cut -c1-160 {} | head -16"
-python -c "
-import json; d=json.load(open('gpurun_out/prof_${TAG}_bench.json')); print('BENCH under rocprof', round(d['value']), d['ms_per_step'], d['roofline']['launch_ms'])"
 if [ "$2" = "pmc" ]; then
-  cd /tmp
-  for C in "SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_SALU" "FETCH_SIZE" "WRITE_SIZE"; do
-    N=$(echo $C | cut -d' ' -f1)
-    timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/gpurun_out/prof_${TAG}_pmc_$N -- python $R/tools/pmc_target.py > /dev/null 2>&1
-  done
-  cd $R
-  python tools/pmc_summary.py gpurun_out/prof_${TAG}_pmc_ > gpurun_out/${TAG}_pmc_summary.csv; cat gpurun_out/${TAG}_pmc_summary.csv
+  tools/gpu_pmc.sh $TAG 256 2 | tail -14 | cut -c1-220
+  tools/gpu_pmc.sh $TAG 64 5 | tail -16 | cut -c1-220
 fi
