@@ -5,13 +5,15 @@
 // for EVERY candidate of an exhaustive (theta, ty, tz) x colour-phase grid (the reference only
 // walks this surface locally with Ceres from (0,0,0)).
 //
-// Mapping (gfx950): workgroup = (frame, theta index), 4 wavefronts.  The frame's labelled points
-// are rotated by the workgroup's theta and staged ONCE into LDS.  A wavefront owns a tile of
+// Mapping (gfx950): workgroup = (frame, theta index), 4 wavefronts (8 on frames staged above 2048 points).  The frame's
+// labelled points are rotated by the workgroup's theta and staged ONCE into LDS.  A wavefront owns a tile of
 // 4 x 4 (ty, tz) candidates; lane = candidate * 4 + slice: the four lanes of a quad evaluate the SAME
 // candidate on four interleaved quarters of the point walk and keep private running sums (both
 // colour phases).  The branch-and-bound test therefore needs only a quad reduction -- four DPP adds --
-// and runs every 16 points (8 interior-class + 8 border-class, see the staging): a tile stops the moment each of its
-// candidates is provably beaten.
+// and runs every 8 positions of the walk (2 points per lane): a tile stops the moment each of its candidates is provably
+// beaten.  The walk starts with the border-class points closest to the board's outline (rim), then the other border-class
+// points, then the interior-class ones (see the staging): 86 % of the tiles are dropped at their first test, and that
+// first block lives in registers (DESIGN.md section 4 has the measurements behind every one of these choices).
 // History of this mapping, measured on the 128-frame batch:
 //  * lanes = points, 4 x 4 candidates in registers (round-1 first design): 14.5 VALU per evaluation
 //    thanks to separable i/j terms, but every test needed a ~130-instruction transposed reduction over
@@ -30,9 +32,10 @@
 //   1/2 rho(r^2) = q (r - q/2),  q = min(r, delta)                     (HuberLoss(0.1), :137)
 // The cell is white iff topleftWhite xor ((floor i + floor j) odd)  (:53-61), so a mismatch
 // under phase 0 is a match under phase 1: both phases come out of one pass.
-// A lane's sums carry cost / 2 (the colour weight is 0 or 1/2; powers of two, exact): 26 VALU
-// instructions per point and lane for a border-class point (out-of-board logic included), 15 for an interior-class
-// point (it is in the board under every translation of the grid: accumulate_interior).
+// A lane's sums carry cost / 2 (the colour weight is 0 or 1/2; powers of two, exact): 29 VALU
+// instructions per point and lane for a border-class point (out-of-board logic included; 26 inside the unrolled walk), 15
+// for an interior-class point (it is in the board under every translation of the grid: accumulate_interior) --
+// tools/k6_isa_count.sh counts them in the assembly of the probe kernels at the end of this file.
 #include "ilcc_internal.h"
 #ifdef ILCC_K6_TIMING
 #include <algorithm>
