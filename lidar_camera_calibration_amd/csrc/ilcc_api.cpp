@@ -375,6 +375,7 @@ Ctx make_ctx(ilcc_handle* h, Slot& sl, const float4* d_xyzi, const float* d_clic
   c.seed_stride_th = 1;
   c.seed_off_th = 0;
   c.refine_radius_th = 0;
+  c.refine_window = 0;
   c.cth = h->d_cth;
   c.sth = h->d_sth;
   c.ay = h->d_ay;
@@ -508,6 +509,7 @@ int32_t enqueue_impl(ilcc_handle* h, int si, const float4* d_xyzi, const uint64_
       refine.seed_stride_th = h->seed_stride_th;
       refine.seed_off_th = h->seed_stride_th / 2;
       // refinement pass: all candidates around the seed argmin (theta +- a third of a seed stride, 8 x 8 translations)
+      refine.refine_window = 1;
       refine.refine_radius_th = std::max(1, h->seed_stride_th / ILCC_REFINE_RADIUS_DIV);
       refine.grid_blocks = std::min((uint32_t)(2 * refine.refine_radius_th + 1), h->max_theta);
       refine.partial = sl.d_partial3;
@@ -524,12 +526,16 @@ int32_t enqueue_impl(ilcc_handle* h, int si, const float4* d_xyzi, const uint64_
         anchor.seed_stride_th = 1;
         anchor.seed_off_th = 0;
         anchor.seed_k_from_flat = 1;
-        anchor.refine_radius_th = 1;
-        anchor.grid_blocks = 3;
+#ifndef ILCC_ANCHOR_RADIUS
+#define ILCC_ANCHOR_RADIUS 1
+#endif
+        anchor.refine_window = 1;
+        anchor.refine_radius_th = ILCC_ANCHOR_RADIUS;
+        anchor.grid_blocks = 2 * ILCC_ANCHOR_RADIUS + 1;
         anchor.partial = sl.d_partial4;
         launch_grid_cost(anchor, s, /*use_oob=*/1, nullptr, true);
         full.seed_partial = sl.d_partial4;
-        full.seed_blocks = 3;
+        full.seed_blocks = 2 * ILCC_ANCHOR_RADIUS + 1;
         full.seed_n_ty = h->p.n_ty;
         full.seed_n_tz = h->p.n_tz;
         full.seed_stride_t = 1;

@@ -100,11 +100,22 @@ __device__ __forceinline__ void accumulate(const PointTerms& p, float ay, float 
   const float mf = __builtin_amdgcn_fractf(fmaf(0.5f, fi + fj, p.hw));   // 0.5 iff (floor i + floor j + white) odd
   const float nmf = 0.5f - mf;
   const float ui = fabsf(i - Wh) - Wh, uj = fabsf(j - Hh) - Hh; // < 0 inside; |.| = min(|i|, |i-W|)
-  const bool oob = fmaxf(ui, uj) >= 0.f;                         // not (0 < i < W and 0 < j < H)
-  // (forcing the compare into an SGPR pair instead of VCC for the three selects -- tools/ubench/valu_rate2.hip shows
-  // back-to-back v_cndmask on VCC at a fifth of the rate -- measured no difference here: 0.584 vs 0.578 ms per batch)
-  auto sel = [&](float if_oob, float otherwise) -> float { return oob ? if_oob : otherwise; };
+#ifndef ILCC_K6_ARITH_SELECT
+#define ILCC_K6_ARITH_SELECT 0   // measured: 385 k (arithmetic) vs 388-391 k (selects) frames/s -- fewer and "faster" instructions, no gain: kept off
+#endif
   float R, w0, w1;
+  if (OOB && ILCC_K6_ARITH_SELECT) {
+    // out-of-board as a 0 / 1 FACTOR instead of a compare and three selects (v_cmp and v_cndmask issue at half the rate of
+    // v_fma on this part, tools/ubench): t = clamp(m * 2^40 + 1) is 0 for every m < 0 a float of this size can hold
+    // (|m| >= 2^-22) and 1 for m >= 0 -- the in-board side (t = 0) stays bit-identical to accumulate_interior
+    const float m = fmaxf(ui, uj);                               // >= 0: not (0 < i < W and 0 < j < H)
+    const float t = __builtin_fminf(__builtin_fmaxf(fmaf(m, 0x1p40f, 1.f), 0.f), 1.f);
+    R = fmaf(t, (fabsf(ui) + fabsf(uj)) - Rin, Rin);
+    w0 = fmaf(t, nmf, mf);                                       // 0.5 when out of board
+    w1 = fmaf(t, mf, nmf);
+  } else {
+  const bool oob = fmaxf(ui, uj) >= 0.f;                         // not (0 < i < W and 0 < j < H)
+  auto sel = [&](float if_oob, float otherwise) -> float { return oob ? if_oob : otherwise; };
   if (OOB) {
     R = sel(fabsf(ui) + fabsf(uj), Rin);
     w0 = sel(0.5f, mf);
@@ -113,6 +124,7 @@ __device__ __forceinline__ void accumulate(const PointTerms& p, float ay, float 
     R = sel(0.f, Rin);
     w0 = mf;
     w1 = nmf;
+  }
   }
   const float Q = fminf(R, delta);
   const float T = Q * fmaf(-0.5f, Q, R);    // q (r - q/2) = 1/2 rho(r^2)
@@ -199,7 +211,7 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
       // the small anchor launch)
       const int k2 = __builtin_amdgcn_readfirstlane(c.seed_k_from_flat ? (int)((sb.flat >> 1) / (uint32_t)(n_ty * n_tz)) : (int)k2u);
       const int sa = min(a2 * c.seed_stride_t, n_ty - 1), sbb = min(b2 * c.seed_stride_t, n_tz - 1);
-      if (c.refine_radius_th > 0) {
+      if (c.refine_window) {
         // refinement pass: every candidate within +-radius theta steps and the 8 x 8 (ty, tz) window
         // around the seed argmin -> the frame's bound is (nearly always) the true minimum before the
         // full pass starts, which is what lets the full pass cut almost every tile after 8 points

@@ -37,14 +37,18 @@ same_idx = sum(int(res[f].grid_index == ref[f].grid_index) for f in both)
 same_theta = sum(int(tuple(res[f].theta_t) == tuple(ref[f].theta_t) and res[f].sel_cost == ref[f].sel_cost
                      and res[f].basin_margin == ref[f].basin_margin) for f in both) if mode == "grid" else -1
 flagged = sum(int(res[f].status == 11) for f in range(F))
-overflow = sum(int(res[f].flags != 0) for f in range(F))
+overflow = sum(int(res[f].flags & N.FLAG_TIE_OVERFLOW != 0) for f in range(F))
+same_conf = sum(int((res[f].cells_hit, res[f].n_oob, res[f].flags & ~N.FLAG_TIE_OVERFLOW) == (ref[f].cells_hit, ref[f].n_oob, ref[f].flags))
+                for f in both)
+low_cov = sum(int(res[f].flags & N.FLAG_LOW_COVERAGE != 0) for f in both)
 dev = [float(np.abs(res[f].corners_array() - ob.result_corners(ref[f])).max()) for f in both]
 it = sum(int(res[f].iters_a == ref[f].iters_a and res[f].iters_b == ref[f].iters_b) for f in both)
 print("mode", mode)
 print("frames %d  status agree %d  both with corners %d  grid argmin identical %d  rounds/hops (iterations) identical %d  "
       "theta_t+cost+margin bit-identical %d  flagged ambiguous %d  tie-list overflows %d  max corner deviation %.3g m  "
-      "frames above 1e-6 m: %d" % (F, same_status, len(both), same_idx, it, same_theta, flagged, overflow,
-                                   max(dev) if dev else 0.0, sum(d > 1e-6 for d in dev)))
+      "frames above 1e-6 m: %d  cells_hit/n_oob/flags identical %d  flagged low coverage %d"
+      % (F, same_status, len(both), same_idx, it, same_theta, flagged, overflow, max(dev) if dev else 0.0, sum(d > 1e-6 for d in dev),
+         same_conf, low_cov))
 for f in both:
     if res[f].grid_index != ref[f].grid_index:
         print("  frame", f, "gpu", res[f].grid_index, res[f].grid_cost, "oracle", ref[f].grid_index, ref[f].grid_cost)
