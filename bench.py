@@ -445,6 +445,8 @@ def main():
             out["single_frame_latency_ms"] = single_frame_latency(N, params, clouds, clicks, n_points, local_rank)
             if args.config == 2:
                 out["half_resolution_grid_variant"] = half_grid_leg(N, est, params, dptrs, FS, run, warm, args.steps, synth, gts, board)
+            if args.config == 2:
+                out["online_caller"] = online_caller_leg(N, params, clouds.reshape(FS, n_points, 4), gts, n_points, local_rank)
             if noise_inputs is not None:
                 out["noise_floor_mm"] = noise_floor_leg(N, params, synth, board, n_points, local_rank, noise_inputs)
             if not args.no_cpu_baseline and args.config == 2:
@@ -518,6 +520,34 @@ def _gen_noise(args):
         clicks.append(synth.make_click(pose, s))
         gts.append(synth.true_corners(pose, board))
     return np.stack(clouds), np.stack(clicks), np.stack(gts)
+
+
+def online_caller_leg(N, params, clouds, gts, n_points, device):
+    """SURVEY.md 8(f2): LidarCornersEst::get_chessboard_by_point as the online node calls it (lidar_chessboard_online.cpp:91-101)
+    -- NO ROI crop, the whole 28 800-point cloud clustered at tolerance 0.10, the cluster around the predicted board centre,
+    getPlane, gray zone -- through ilcc_chessboard_by_point_batch (host buffers in, records out, synchronous), 128 frames per
+    call.  The whole-cloud clustering is K2's multi-workgroup path (28 800 points per frame > the LDS capacity)."""
+    from lidar_camera_calibration_amd import LidarCornersBatch
+    F = min(128, len(clouds))
+    est = LidarCornersBatch(F, n_points, params, device=device)
+    est.reserve(2048, n_points)                      # arms the multi-workgroup clustering up front
+    pts = np.ascontiguousarray(gts[:F].mean(axis=1), dtype=np.float32)   # the tracker's prediction: the board centre
+    c = np.ascontiguousarray(clouds[:F])
+    for _ in range(3):
+        res = est.chessboard_by_point(c, pts)
+    ts = []
+    for _ in range(10):
+        t0 = time.perf_counter()
+        res = est.chessboard_by_point(c, pts)
+        ts.append(time.perf_counter() - t0)
+    tm = est.timing()
+    found = sum(1 for r in res if r.status == N.OK)
+    est.close()
+    dt = float(np.median(ts))
+    return {"value": F / dt, "unit": "frames/s", "frames_per_call": F, "ms_per_call": 1e3 * dt, "boards_found": "%d/%d" % (found, F),
+            "cluster_ms_per_call": round(tm.cluster, 4),
+            "what": "ilcc_chessboard_by_point_batch, host in / host out (the 59 MB H2D copy of a call is inside), median of 10 calls; "
+                    "the reference's online node runs this at the sensor's 10 Hz"}
 
 
 NOISE_VARIANTS = ((0.0, 0.015), (0.001, 0.015), (0.003, 0.015), (0.010, 0.015), (0.0, 0.0))   # (sigma_r, beam footprint) in m
