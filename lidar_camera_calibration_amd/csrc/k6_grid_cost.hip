@@ -829,7 +829,11 @@ hipError_t set_kernel_attributes_k6() {
 
 void launch_grid_cost(const Ctx& c, hipStream_t s, int32_t use_oob, float* cost_volume, bool prune) {
   const dim3 grid(c.grid_blocks, c.n_frames), block(kGridThreads);
-  const size_t lds = (sizeof(float2) + sizeof(float)) * (size_t)c.grid_lds_points + sizeof(float) * (size_t)(c.p.n_ty + c.p.n_tz);
+#ifndef ILCC_K6_LDS_PAD
+#define ILCC_K6_LDS_PAD 0   // experiment: extra dynamic LDS per workgroup of the FULL pass, to cap its workgroups per CU and leave room for the per-frame kernels of other batches
+#endif
+  const size_t lds = (sizeof(float2) + sizeof(float)) * (size_t)c.grid_lds_points + sizeof(float) * (size_t)(c.p.n_ty + c.p.n_tz) +
+                     (c.tie_count != nullptr ? (size_t)ILCC_K6_LDS_PAD : 0);
   // the diagnostic volume is always a complete evaluation (no pruning)
   if (cost_volume) {
     if (use_oob)
