@@ -25,6 +25,11 @@ constexpr int kFrameThreads = ILCC_K2_THREADS;    // K2: one workgroup per frame
 #define ILCC_K45_THREADS 1024
 #endif
 constexpr int kPlaneThreads = ILCC_K3_THREADS;    // K3: one workgroup per frame
+constexpr int kPlaneThreadsSmallBatch = 1024;     // K3 in batches of <= kSmallBatchFrames frames (latency, not CU footprint, matters)
+#ifndef ILCC_SMALL_BATCH
+#define ILCC_SMALL_BATCH 64
+#endif
+constexpr int kSmallBatchFrames = ILCC_SMALL_BATCH;   // batches this small cannot fill 256 CUs with one workgroup per frame: the per-frame kernels go wide
 constexpr int kHistThreads = ILCC_K45_THREADS;    // K4/K5: one workgroup per frame
 #ifndef ILCC_K6_THREADS
 #define ILCC_K6_THREADS 256
@@ -54,6 +59,7 @@ constexpr int kSolveThreads = ILCC_K7_THREADS;     // K7: wavefronts x 64 per (f
                                // (the kernel's latency is set by the few frames that walk 30+ rounds; small workgroups leave the CUs to K6)
 #endif
 constexpr int kRefineThreads = ILCC_K7R_THREADS;   // K7r: one workgroup per frame
+constexpr int kRefineThreadsSmallBatch = 768;      // K7r in batches of <= kSmallBatchFrames frames: 4 wavefronts per theta of the stencil
 constexpr int kRefineList = 32;        // K7r: candidates evaluated per sweep over the points
 constexpr int kTieCap = 256;           // K6 -> K7a: near-tie candidates kept per frame for the fp64 recount
 constexpr float kTieEps = 2e-5f;       // relative cost window of a near-tie (fp32 sums of ~1e3 terms agree to ~1e-6)

@@ -62,7 +62,12 @@ __device__ __forceinline__ float plane_dist(const float pl[4], const float4 q) {
 
 constexpr int kRansacLdsPoints = 2048;   // cluster points staged in LDS (32 KiB); larger clusters are read through L2
 
-__global__ __launch_bounds__(kPlaneThreads) void k3_ransac_plane(Ctx c) {
+// Launched with kPlaneThreads (256) per frame in large batches -- the kernel then runs BESIDE another batch's K6 and small
+// workgroups leave it the CUs -- and with kPlaneThreadsSmallBatch (1024) when the batch has too few frames to fill the
+// chip anyway (one click of the reference's node; config 5's 64 dense frames): 16 instead of 4 wavefronts share the 128
+// hypotheses.  Results do not depend on the width (hypotheses are ranked by (inliers, index), sums are block sums).
+__global__ __launch_bounds__(kPlaneThreadsSmallBatch) void k3_ransac_plane(Ctx c) {
+  const uint32_t kThreads = blockDim.x;
   __shared__ float4 s_P[kRansacLdsPoints];
   __shared__ uint32_t sc[64];
   __shared__ double scd[16 * 6 + 8];
@@ -83,14 +88,14 @@ __global__ __launch_bounds__(kPlaneThreads) void k3_ransac_plane(Ctx c) {
   // every hypothesis re-reads the whole cluster (128 x M points): from LDS, not from L2, when it fits
   const float4* P = G;
   if (M <= (uint32_t)kRansacLdsPoints) {
-    for (uint32_t i = tid; i < M; i += kPlaneThreads) s_P[i] = G[i];
+    for (uint32_t i = tid; i < M; i += kThreads) s_P[i] = G[i];
     __syncthreads();
     P = s_P;
   }
 
   // ---- score hypotheses, one per wavefront pass
   uint32_t best_cnt = 0, best_h = 0xFFFFFFFFu;
-  for (uint32_t h = (uint32_t)wid; h < (uint32_t)c.p.ransac_hyp; h += kPlaneThreads / ILCC_WAVE) {
+  for (uint32_t h = (uint32_t)wid; h < (uint32_t)c.p.ransac_hyp; h += kThreads / ILCC_WAVE) {
     const uint32_t i0 = sample_index(c.p.ransac_seed, h, 0, M);
     const uint32_t i1 = sample_index(c.p.ransac_seed, h, 1, M);
     const uint32_t i2 = sample_index(c.p.ransac_seed, h, 2, M);
@@ -115,7 +120,7 @@ __global__ __launch_bounds__(kPlaneThreads) void k3_ransac_plane(Ctx c) {
   __syncthreads();
   if (tid == 0) {
     uint32_t bc = 0, bh = 0xFFFFFFFFu;
-    for (int w = 0; w < kPlaneThreads / ILCC_WAVE; ++w)
+    for (int w = 0; w < (int)(kThreads / ILCC_WAVE); ++w)
       if (sc[w] > bc || (sc[w] == bc && sc[w] > 0 && sc[16 + w] < bh)) {
         bc = sc[w];
         bh = sc[16 + w];
@@ -140,7 +145,7 @@ __global__ __launch_bounds__(kPlaneThreads) void k3_ransac_plane(Ctx c) {
   // ---- optimizeModelCoefficients: PCA plane of the inliers (needs > 3 of them)
   if (bc > 3) {
     double sx = 0, sy = 0, sz = 0;
-    for (uint32_t i = tid; i < M; i += kPlaneThreads) {
+    for (uint32_t i = tid; i < M; i += kThreads) {
       const float4 q = P[i];
       if (plane_dist(pl, q) < thr) {
         sx += q.x;
@@ -152,7 +157,7 @@ __global__ __launch_bounds__(kPlaneThreads) void k3_ransac_plane(Ctx c) {
     block_sum_n<3>(sums3, scd);
     const double cx = sums3[0] / bc, cy = sums3[1] / bc, cz = sums3[2] / bc;
     double cv[6] = {0, 0, 0, 0, 0, 0};
-    for (uint32_t i = tid; i < M; i += kPlaneThreads) {
+    for (uint32_t i = tid; i < M; i += kThreads) {
       const float4 q = P[i];
       if (plane_dist(pl, q) < thr) {
         const double dx = q.x - cx, dy = q.y - cy, dz = q.z - cz;
@@ -190,7 +195,7 @@ __global__ __launch_bounds__(kPlaneThreads) void k3_ransac_plane(Ctx c) {
   // ---- re-select inliers with the refined plane, stable order
   float4* __restrict__ dst = c.board + beg;
   uint32_t running = 0;
-  for (uint32_t base = 0; base < M; base += kPlaneThreads) {
+  for (uint32_t base = 0; base < M; base += kThreads) {
     const uint32_t i = base + tid;
     float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
     bool keep = false;
@@ -211,7 +216,8 @@ __global__ __launch_bounds__(kPlaneThreads) void k3_ransac_plane(Ctx c) {
 }
 
 void launch_ransac_plane(const Ctx& c, hipStream_t s) {
-  hipLaunchKernelGGL(k3_ransac_plane, dim3(c.n_frames), dim3(kPlaneThreads), 0, s, c);
+  const int threads = c.n_frames <= (uint32_t)kSmallBatchFrames ? kPlaneThreadsSmallBatch : kPlaneThreads;
+  hipLaunchKernelGGL(k3_ransac_plane, dim3(c.n_frames), dim3(threads), 0, s, c);
 }
 
 }  // namespace ilcc

@@ -642,11 +642,14 @@ __global__ __launch_bounds__(kSolveThreads) void k7a_local_solve(Ctx c, SolveRec
 
 // ------------------------------------------------------------------ K7r pattern refine (ILCC_SOLVER_GRID)
 constexpr double kCostQOne = 1099511627776.0;   // 2^40: quantum of the fixed-point cost (oracle: ORC_COST_Q_ONE)
-constexpr int kRefineWaves = kRefineThreads / ILCC_WAVE;
+// wavefronts of the K7r workgroup: kRefineThreads / 64 in large batches, kRefineThreadsSmallBatch / 64 in small ones (the
+// sums are integers: the split of the points over wavefronts cannot change a total)
+#define kRefineWaves ((int)(blockDim.x >> 6))
 // the 3-theta stencil gives every theta kRefineWaves / 3 wavefronts: fewer than 3 wavefronts would leave a theta without
 // any (all 27 sums 0 -- a silently wrong refinement, not a build error), and the candidate lists are written by the first
 // kRefineList threads
-static_assert(kRefineThreads % ILCC_WAVE == 0 && kRefineWaves >= 3 && kRefineThreads >= kRefineList,
+static_assert(kRefineThreads % ILCC_WAVE == 0 && kRefineThreads / ILCC_WAVE >= 3 && kRefineThreads >= kRefineList &&
+              kRefineThreadsSmallBatch % (3 * ILCC_WAVE) == 0,
               "ILCC_K7R_THREADS must be a multiple of 64, at least 192");
 constexpr int32_t kNoTheta = INT32_MIN;         // candidate whose theta lies outside the lattice table: never evaluated
 
@@ -1003,7 +1006,7 @@ __device__ void refine_frame(const Ctx& c, SolveRec* rec, float2* s_yz, uint8_t*
   }
 }
 
-__global__ __launch_bounds__(kRefineThreads) void k7r_pattern_refine(Ctx c, SolveRec* rec) {
+__global__ __launch_bounds__(kRefineThreadsSmallBatch) void k7r_pattern_refine(Ctx c, SolveRec* rec) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ RefineShared sh;
   const uint32_t f = blockIdx.x;
@@ -1203,7 +1206,8 @@ hipError_t set_kernel_attributes_k7() {
 
 void launch_pattern_refine_corners(const Ctx& c, hipStream_t s) {
   const size_t lds = (sizeof(float2) + 1) * (size_t)c.grid_lds_points;
-  hipLaunchKernelGGL(k7r_pattern_refine, dim3(c.n_frames), dim3(kRefineThreads), lds, s, c, c.solve_rec);
+  const int threads = c.n_frames <= (uint32_t)kSmallBatchFrames ? kRefineThreadsSmallBatch : kRefineThreads;
+  hipLaunchKernelGGL(k7r_pattern_refine, dim3(c.n_frames), dim3(threads), lds, s, c, c.solve_rec);
   hipLaunchKernelGGL(k7b_corners, dim3(c.n_frames), dim3(kSolveThreads), 0, s, c, c.solve_rec, 1);
 }
 
