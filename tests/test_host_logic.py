@@ -85,6 +85,23 @@ def test_ros_node_source_type_checks(tmp_path):
     assert r.returncode != 0 and "EuclideanClusters" in r.stderr
 
 
+def test_bench_reads_its_roofline_inputs_from_committed_profiles():
+    """roofline.traffic / issued_vs_credited are derived at run time from the PMC summaries committed under profiles/
+    (no scaled constants): the parser finds the K6 launches of the batch sizes the bench runs."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for (config, frames), path in bench.PMC_FILES.items():
+        assert os.path.exists(os.path.join(root, path)), path
+        pmc = bench.k6_pmc(config, frames)
+        assert pmc is not None and pmc["file"] == path
+        assert pmc["traffic_bytes"] > 1e6 and pmc["valu_wave_instr"] > pmc["full_pass"]["valu_wave_instr"] > 1e7
+        assert 0.3 < pmc["full_pass"]["valu_busy_quad_cycles"] / (pmc["full_pass"]["gui_active_cycles_per_xcd"] * 256.0) < 1.2
+    assert bench.k6_pmc(2, 100) is None          # no file for that batch size: traffic is null, never a scaled guess
+
+
 def test_k6_credit_matches_the_isa():
     """bench.py credits each executed K6 evaluation with the VALU instruction count of the term: the constants there, the
     committed profiles/r03_k6_isa_count.json and a fresh run of tools/k6_isa_count.sh on the current source (hipcc -S,
