@@ -683,10 +683,12 @@ __device__ __forceinline__ AxisTerms axis_terms(double v, double n) {
   AxisTerms t;
   t.inside = v > 0 && v < n;
   const double fl = floor(v);
-  t.odd = fl != floor(fl / 2.0) * 2.0;
+  // (floor(v) is odd) from the integer: the same truth value as `fl != floor(fl / 2) * 2` for every |v| < 2^31 -- board
+  // coordinates are a few units -- at a quarter of the fp64 operations
+  t.odd = (((int)fl) & 1) != 0;
   const double fr = v - fl;
   t.in_dist = (fr > 0.5) ? (fl + 1.0) - v : fr;
-  t.out_dist = (fabs(v) < fabs(v - n)) ? fabs(v) : fabs(v - n);
+  t.out_dist = fmin(fabs(v), fabs(v - n));   // == (|v| < |v - n|) ? |v| : |v - n| for finite v
   return t;
 }
 // rint(1/2 rho * 2^40) as a double (an integer < 2^53: sums of a few of them are exact in double, too)
