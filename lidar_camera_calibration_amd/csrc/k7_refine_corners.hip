@@ -693,8 +693,17 @@ __device__ __forceinline__ AxisTerms axis_terms(double v, double n) {
 }
 // rint(1/2 rho * 2^40) as a double (an integer < 2^53: sums of a few of them are exact in double, too)
 __device__ __forceinline__ double term_q(const AxisTerms& ai, const AxisTerms& aj, bool tlw, bool laser_white, double delta) {
+#ifndef ILCC_K7R_BRANCHFREE
+#define ILCC_K7R_BRANCHFREE 0   // measured: K7r alone 0.274 -> 0.233 ms per 128 frames, pipelined bench 392 -> 383 k frames/s (both sums are always computed): off
+#endif
   double res = 0.0;
-  if (ai.inside && aj.inside) {
+  if (ILCC_K7R_BRANCHFREE) {
+    // the same sums as the branches below, selected instead of jumped to: nine of these per point and theta run with less
+    // than one wavefront per SIMD, where every taken branch is a bubble nothing else fills
+    const bool white = tlw != (ai.odd != aj.odd);           // both even or both odd -> topleftWhite (:53-61)
+    const double in_sum = ai.in_dist + aj.in_dist, out_sum = ai.out_dist + aj.out_dist;
+    res = (ai.inside && aj.inside) ? ((laser_white != white) ? in_sum : 0.0) : out_sum;
+  } else if (ai.inside && aj.inside) {
     const bool white = (ai.odd == aj.odd) ? tlw : !tlw;     // both even or both odd -> topleftWhite (:53-61)
     if (laser_white != white) res = ai.in_dist + aj.in_dist;
   } else {
