@@ -497,6 +497,11 @@ int32_t enqueue_impl(ilcc_handle* h, int si, const float4* d_xyzi, const uint64_
       seed.p.n_tz = h->n_tz2;
       seed.grid_blocks = (uint32_t)h->n_th2;
       seed.partial = sl.d_partial2;
+      // the "nearest to zero" indices of the decimated tables (the kernel reads ay[c_ty] / az[c_tz] for its rim test and
+      // uses all three for the tie-break distance: they must index THIS launch's tables, not the full ones)
+      seed.c_th = std::min(std::max((c.c_th - h->seed_stride_th / 2 + h->seed_stride_th / 2) / std::max(1, h->seed_stride_th), 0), h->n_th2 - 1);
+      seed.c_ty = std::min(c.c_ty / std::max(1, h->seed_stride_t), h->n_ty2 - 1);
+      seed.c_tz = std::min(c.c_tz / std::max(1, h->seed_stride_t), h->n_tz2 - 1);
       seed.walk_limit = sub;
       if (sub) seed.grid_bound = sl.d_bound_sub;
       launch_grid_cost(seed, s, /*use_oob=*/1, nullptr, true);
