@@ -236,8 +236,11 @@ __device__ void cluster_frame(const Ctx& c, uint32_t f, uint32_t* lds_parent, fl
       const int cy = rem / gnx, cx = rem - cy * gnx;
       const uint32_t cbeg = cell ? cur16[cell - 1] : 0u, clen = cur16[cell] - cbeg;
       // lanes 0..26: run (start, length) of neighbour cell r = lane; inclusive scan of the lengths over the lanes
+      // Only the cell itself (r = 13) and its 13 FORWARD neighbours (r = 14..26: offsets after (0,0,0) in (dz,dy,dx) order)
+      // are searched: a pair of points in two adjacent cells is met exactly once, from the cell that comes first -- the
+      // full 27-cell search met every such pair from both sides and threw one of the two distance tests away (j < i).
       uint32_t rst = 0, rln = 0;
-      if (lane < 27) {
+      if (lane >= 13 && lane < 27) {
         const int dz = lane / 9 - 1, dy = (lane / 3) % 3 - 1, dx = lane % 3 - 1;
         const int nx = cx + dx, ny = cy + dy, nz = cz + dz;
         if (nx >= 0 && nx < gnx && ny >= 0 && ny < gny && nz >= 0 && nz < gnz) {
@@ -293,7 +296,7 @@ __device__ void cluster_frame(const Ctx& c, uint32_t f, uint32_t* lds_parent, fl
             float d2 = ex * ex;
             d2 = d2 + ey * ey;
             d2 = d2 + ez * ez;
-            const bool need = valid && j < i && d2 < tol2 && qi != pj;   // each pair once; equal parents = same set for good
+            const bool need = valid && (r != 13 || j < i) && d2 < tol2 && qi != pj;   // own cell: each pair once; equal parents = same set for good
 #ifdef ILCC_K2_TIMING
             ++n_iter;
 #endif
@@ -750,12 +753,14 @@ __device__ __forceinline__ void big_search_point(const Ctx& c, uint32_t f, uint3
   const float4 pi = P[i];
   int cx, cy, cz;
   big_cell(c, pi, cx, cy, cz);
-  for (int dz = -1; dz <= 1; ++dz)
-    for (int dy = -1; dy <= 1; ++dy)
-      for (int dx = -1; dx <= 1; ++dx) {
+  // the point's own cell (pairs once: j < i) and its 13 forward neighbours (every pair of adjacent cells is met once, from
+  // the cell that comes first in (dz, dy, dx) order); two cells sharing a bucket only add distance tests that fail or repeat
+  for (int r = 13; r < 27; ++r) {
+      {
+        const int dz = r / 9 - 1, dy = (r / 3) % 3 - 1, dx = r % 3 - 1;
         uint32_t j = __hip_atomic_load(&head[cell_hash(cx + dx, cy + dy, cz + dz)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         while (j != 0xFFFFFFFFu) {
-          if (j < i) {   // each pair once
+          if (r != 13 ? j != i : j < i) {
             const float4 q = P[j];
             const float ex = q.x - pi.x, ey = q.y - pi.y, ez = q.z - pi.z;
             float d2 = ex * ex;
@@ -770,6 +775,7 @@ __device__ __forceinline__ void big_search_point(const Ctx& c, uint32_t f, uint3
           j = next[j];
         }
       }
+  }
 }
 
 __global__ __launch_bounds__(kBigChunk) void k2l_insert(Ctx c) {
