@@ -665,6 +665,7 @@ struct RefineShared {
 struct RefineState {
   int32_t lat[3];
   int32_t phase, rounds, hops, capped;
+  int32_t skip_first;   // the start is the exhaustive grid's argmin with all 26 grid neighbours inside the grid (see pattern_refine)
   long long cost, alt;
 };
 
@@ -830,6 +831,11 @@ __device__ void pattern_refine(const Ctx& c, const Board& bd, const float2* yz, 
   st.alt = 0;
   for (;;) {
     int stride = div, r = 0;
+    if (st.skip_first && refine && div >= 2 && c.p.refine_max_rounds >= 1) {   // (first search only: a hop restarts in full)
+      stride = div >> 1;
+      r = 1;
+    }
+    st.skip_first = 0;
     while (refine && stride >= 1 && r < c.p.refine_max_rounds) {
       int32_t th[3], ty[3], tz[3];
 #pragma unroll
@@ -999,6 +1005,19 @@ __device__ void refine_frame(const Ctx& c, SolveRec* rec, float2* s_yz, uint8_t*
   st.lat[1] = (int32_t)((cell / n_tz) % n_ty) * div;
   st.lat[2] = (int32_t)(cell % n_tz) * div;
   st.phase = (int)(b.flat & 1u);
+#ifndef ILCC_K7R_SKIP_FIRST
+#define ILCC_K7R_SKIP_FIRST 1
+#endif
+  {
+    // The first round of the first search looks at the 26 neighbours one GRID step away.  When they are all grid candidates,
+    // K6 has already ranked them: pruned ones cost more than (1 + 2e-5) x the minimum, completed ones within that window were
+    // re-ordered on exact costs above -- none can be STRICTLY cheaper than the argmin, the round cannot move and is not
+    // evaluated (it still counts as a round: `rounds` stays the oracle's number).  Not when the near-tie list overflowed
+    // (the argmin is then the fp32 one).
+    const int gk = (int)(cell / (n_tz * n_ty)), ga = (int)((cell / n_tz) % n_ty), gb = (int)(cell % n_tz);
+    st.skip_first = ILCC_K7R_SKIP_FIRST && !(flags & ILCC_FLAG_TIE_OVERFLOW) && gk > 0 && gk < c.p.n_th - 1 && ga > 0 &&
+                    ga < (int)n_ty - 1 && gb > 0 && gb < (int)n_tz - 1;
+  }
   pattern_refine(c, bd, yz, lab, n, sh, sweep, st);
   if (tid == 0) {
     const double dv = (double)div;
@@ -1044,6 +1063,7 @@ __global__ __launch_bounds__(kRefineThreads) void k7r_pattern_refine_test(Ctx c,
   st.lat[1] = io->lat[1];
   st.lat[2] = io->lat[2];
   st.phase = io->phase;
+  st.skip_first = 0;   // an arbitrary start: nothing is known about its grid neighbours
   int sweep = 0;
   __syncthreads();
   pattern_refine(c, bd, c.yz, c.lab, c.n_lab[0], sh, sweep, st);
