@@ -183,6 +183,8 @@ typedef struct ilcc_timing {
   uint64_t grid_cost_evals_nominal_sum; /* evaluations an unpruned exhaustive pass needs */
   uint64_t grid_cost_evals_interior_sum; /* part of grid_cost_evals_sum spent on points that cannot leave the board under any
                                             translation of the grid (cheaper term: no out-of-board logic) */
+  uint64_t grid_cost_box_evals_sum; /* (point, 16-candidate tile) evaluations of the box pre-pass: a lower bound for a whole
+                                       tile at once (not part of grid_cost_evals_sum) */
 } ilcc_timing;
 
 int32_t ilcc_abi_version(void);

@@ -104,6 +104,7 @@ class Timing(C.Structure):
         ("grid_cost_evals_sum", C.c_uint64),
         ("grid_cost_evals_nominal_sum", C.c_uint64),
         ("grid_cost_evals_interior_sum", C.c_uint64),
+        ("grid_cost_box_evals_sum", C.c_uint64),
     ]
 
 

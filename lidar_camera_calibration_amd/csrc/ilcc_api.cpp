@@ -318,10 +318,10 @@ int32_t alloc_slot(ilcc_handle* h, Slot& sl) {
   ALLOC(sl.d_bound_sub, sizeof(uint32_t) * mf);
   ALLOC(sl.d_tie_count, sizeof(uint32_t) * mf);
   ALLOC(sl.d_tie_list, sizeof(GridPartial) * (size_t)mf * kTieCap);
-  ALLOC(sl.d_iters, sizeof(unsigned long long) * 2 * kIterSlots);
+  ALLOC(sl.d_iters, sizeof(unsigned long long) * 3 * kIterSlots);
 #undef ALLOC
   HIP_TRY(h, hipHostMalloc((void**)&sl.h_res, sizeof(ilcc_result) * mf, hipHostMallocDefault));
-  HIP_TRY(h, hipHostMalloc((void**)&sl.h_iters, sizeof(unsigned long long) * 2 * kIterSlots, hipHostMallocDefault));
+  HIP_TRY(h, hipHostMalloc((void**)&sl.h_iters, sizeof(unsigned long long) * 3 * kIterSlots, hipHostMallocDefault));
   sl.allocated = true;
   return ILCC_OK;
 }
@@ -567,6 +567,11 @@ int32_t enqueue_impl(ilcc_handle* h, int si, const float4* d_xyzi, const uint64_
       HIP_TRY(h, hipStreamWaitEvent(s, h->slots[h->k6_last].k6_done, 0));
     HIP_TRY(h, hipEventRecord(sl.ev[8], s));
     full.tie_count = sl.d_tie_count;
+#ifndef ILCC_BOX_POINTS
+#define ILCC_BOX_POINTS 32
+#endif
+    // box pre-pass (k6_grid_cost.hip): its monotonicity argument needs a tile's box narrower than one square on both axes
+    full.box_points = (prune && 3.0 * h->p.ty_step < 0.9 * h->p.grid_length && 3.0 * h->p.tz_step < 0.9 * h->p.grid_length) ? (uint32_t)ILCC_BOX_POINTS : 0u;
     launch_grid_cost(full, s, /*use_oob=*/1, nullptr, prune);
     HIP_TRY(h, hipEventRecord(sl.k6_done, s));
     h->k6_last = si;
@@ -584,7 +589,7 @@ int32_t enqueue_impl(ilcc_handle* h, int si, const float4* d_xyzi, const uint64_
   HIP_TRY(h, hipEventRecord(sl.ev[6], s));
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipMemcpyAsync(sl.h_res, sl.d_res, sizeof(ilcc_result) * n_frames, hipMemcpyDeviceToHost, s));
-  HIP_TRY(h, hipMemcpyAsync(sl.h_iters, sl.d_iters, sizeof(unsigned long long) * 2 * kIterSlots, hipMemcpyDeviceToHost, s));
+  HIP_TRY(h, hipMemcpyAsync(sl.h_iters, sl.d_iters, sizeof(unsigned long long) * 3 * kIterSlots, hipMemcpyDeviceToHost, s));
   sl.busy = true;
   return ILCC_OK;
 }
@@ -637,6 +642,7 @@ int32_t finish(ilcc_handle* h, int si, ilcc_result* out, float* d_records = null
     for (int k = 0; k < kIterSlots; ++k) {
       iters += sl.h_iters[k];
       iters_in += sl.h_iters[kIterSlots + k];
+      t.grid_cost_box_evals_sum += sl.h_iters[2 * kIterSlots + k];
     }
     t.grid_cost_evals_sum += (uint64_t)iters * grid_cost_evals_per_count();
     t.grid_cost_evals_interior_sum += (uint64_t)iters_in * grid_cost_evals_per_count();

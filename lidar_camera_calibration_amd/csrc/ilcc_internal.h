@@ -64,7 +64,7 @@ constexpr int kRefineList = 32;        // K7r: candidates evaluated per sweep ov
 constexpr int kTieCap = 256;           // K6 -> K7a: near-tie candidates kept per frame for the fp64 recount
 constexpr float kTieEps = 2e-5f;       // relative cost window of a near-tie (fp32 sums of ~1e3 terms agree to ~1e-6)
 constexpr int kCoverageCellsMax = 1024;   // K7b: board squares tracked by the coverage mask (board_w x board_h)
-constexpr int kIterSlots = 64;         // K6 executed-iteration counters (spread to avoid one hot atomic); [0,64): all points, [64,128): interior-class points
+constexpr int kIterSlots = 64;         // K6 executed-iteration counters (spread to avoid one hot atomic); [0,64): all points, [64,128): interior-class points, [128,192): (point, tile) evaluations of the box pre-pass
 #ifndef ILCC_K2_ALLPAIRS_MAX
 #define ILCC_K2_ALLPAIRS_MAX 256
 #endif
@@ -140,6 +140,7 @@ struct Ctx {
   uint32_t* tie_count_all;   // the same array, always set: K1 resets it
   GridPartial* tie_list;     // n_frames x kTieCap: cost (fp32), d2, flat
   unsigned long long* grid_iters;  // executed K6 work in counts of grid_cost_evals_per_count() evaluations, for the VALU rate
+  uint32_t box_points;             // K6 full pass: border-class walk positions the box pre-pass looks at per tile (0: no pre-pass)
   // seeding pass of the branch-and-bound (a decimated subset of the same grid, evaluated first)
   const GridPartial* seed_partial; // n_frames x seed_blocks, nullptr when this launch is the seed pass / unused
   uint32_t seed_blocks;

@@ -47,7 +47,7 @@ namespace ilcc {
 // -DILCC_K6_TIMING: per-wavefront cycle budget of the FULL pass (s_memtime around the phases of a workgroup's life), summed
 // into k6_prof[] and read back through ilcc_debug_k6_profile (tools/dev_k6_timing.py).  Costs ~10 % of the kernel's time.
 #ifdef ILCC_K6_TIMING
-constexpr int kProfWaves = 1 << 17, kProfWords = 12;
+constexpr int kProfWaves = 1 << 17, kProfWords = 16;
 __device__ unsigned long long k6_prof[kProfWaves * kProfWords];   // one record per wavefront: plain stores, no atomics
 #define K6_NOW() __builtin_readcyclecounter()
 #else
@@ -67,6 +67,8 @@ constexpr int kSlices = 4;        // lanes (one quad) sharing a candidate, each 
 constexpr int kUnroll = ILCC_K6_UNROLL;        // points per lane and block (round 1, one class of points: 2: 179 k, 3: 181 k, 4: 178 k, 6: 167 k
                                                // frames/s; round 2, two classes, test after every border block only: 2: 245.6 k, 3: 238 k, 4: 227 k)
 constexpr int kStep = kSlices * kUnroll;
+constexpr int kBoxTilesMax = 4096;                 // box pre-pass: tiles per workgroup its LDS bit mask holds
+constexpr float kBoxSafety = 1.f - 0x1p-12f;
 constexpr int kBoundRefresh = ILCC_K6_BOUND_REFRESH; // points between reloads of the frame's shared bound
 
 // sum over the 4 lanes of a quad (every lane gets the total): two DPP adds
@@ -172,11 +174,12 @@ __device__ __forceinline__ Best seed_argmin(const Ctx& c, uint32_t f, uint32_t& 
 
 template <bool OOB, bool VOLUME, bool LDS_POINTS, bool PRUNE, int THREADS>
 __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, float2* s_ij, float* s_hw, Best* s_best,
-                                               uint32_t* s_iters, uint32_t* s_cnt, float* s_ay, float* s_az) {
+                                               uint32_t* s_iters, uint32_t* s_cnt, float* s_ay, float* s_az, uint32_t* s_dead) {
   const uint32_t f = blockIdx.y;
   uint32_t k = blockIdx.x;   // theta index (refinement pass: set from the seed below)
   [[maybe_unused]] const unsigned long long t_entry = K6_NOW();
   [[maybe_unused]] unsigned long long t_rej = 0, t_surv = 0, n_rej = 0, n_surv = 0, n_done = 0, p_surv = 0;
+  [[maybe_unused]] unsigned long long n_tests = 0, alive_sum = 0, alive_le4 = 0, alive_le2 = 0;   // bound tests after the first one
   const ilcc_result* r = &c.res[f];
   const int lane = lane_id();
   const int wid = __builtin_amdgcn_readfirstlane(wave_id());
@@ -363,6 +366,58 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
   float shared_bound = __builtin_inff();   // what this wavefront last published
   uint32_t gb_bits = PRUNE ? __hip_atomic_load(bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0x7f800000u;
   uint32_t pts_done = 0, pts_in = 0;   // walk positions executed by this wavefront (all / interior class)
+
+  // BOX PRE-PASS (full pass of the pipeline): a lower bound for all 16 candidates of a tile at once, at the price of ONE
+  // evaluation per point.  A border-class point that is out of the board under EVERY translation of the tile's 4 x 4 box costs
+  // each of them at least T(r_box), r_box = (smallest |u_i| over the box) + (smallest |u_j| over the box): u = |x - W/2| - W/2
+  // is evaluated with accumulate<>'s own fp32 expressions at the two extreme translations of each axis, every operation in
+  // it is monotone (floating-point rounding included) and a box is narrower than one square (the host checks), so the
+  // extremes bound everything in between; T is non-decreasing in r, and both colour phases pay an out-of-board point.  Points
+  // that are in the board somewhere in the box count 0.  lane = (tile, half of the points): 2 x box_points evaluations per
+  // tile instead of the 16 x 8 of a first block -- and the rim points, which the walk puts first, are exactly the ones that
+  // leave the board when the translation is wrong.  A tile whose bound already exceeds the frame's bound is never started.
+  // kBoxSafety: the bound is a sum in another order than the candidates' own fp32 sums (<= 2^12 terms per lane).
+  bool use_box = false;
+  if constexpr (PRUNE && LDS_POINTS && OOB) {
+    use_box = c.box_points != 0u && n_tiles <= kBoxTilesMax && M > Mi;
+    if (use_box) {
+      for (int w = threadIdx.x; w < (n_tiles + 31) / 32; w += THREADS) s_dead[w] = 0u;
+      __syncthreads();
+      const uint32_t n_pre = min(c.box_points, M - Mi);
+      const float lim_box = 0.5f * (1.f + kTieEps) * __uint_as_float(gb_bits);
+      const int half = (int)(threadIdx.x & 1u);
+      for (int q0 = 0; q0 < n_tiles; q0 += THREADS / 2) {
+        const int q = q0 + (int)(threadIdx.x >> 1);
+        const int qc = min(q, n_tiles - 1);
+        const int qa = qc / ntb, qb = qc - qa * ntb;
+        float alo = __builtin_inff(), ahi = -__builtin_inff(), zlo = __builtin_inff(), zhi = -__builtin_inff();
+#pragma unroll
+        for (int d = 0; d < kTile; ++d) {
+          const float va = s_ay[min(a_org + qa * kTile + d, n_ty - 1)], vz = s_az[min(b_org + qb * kTile + d, n_tz - 1)];
+          alo = fminf(alo, va);
+          ahi = fmaxf(ahi, va);
+          zlo = fminf(zlo, vz);
+          zhi = fmaxf(zhi, vz);
+        }
+        float lb = 0.f;
+        for (uint32_t u = (uint32_t)half; u < n_pre; u += 2u) {
+          const float2 v = s_ij[Mi + u];
+          const float i_lo = v.x + alo, i_hi = v.x + ahi, j_lo = v.y + zlo, j_hi = v.y + zhi;
+          const float ui_lo = fabsf(i_lo - Wh) - Wh, ui_hi = fabsf(i_hi - Wh) - Wh;
+          const float uj_lo = fabsf(j_lo - Hh) - Hh, uj_hi = fabsf(j_hi - Hh) - Hh;
+          const bool out_all = fmaxf(fminf(ui_lo, ui_hi), fminf(uj_lo, uj_hi)) >= 0.f;
+          // |u| closest to zero over the box: the end value nearer to zero, 0 when the ends differ in sign
+          const float R = fabsf(__builtin_amdgcn_fmed3f(ui_lo, ui_hi, 0.f)) + fabsf(__builtin_amdgcn_fmed3f(uj_lo, uj_hi, 0.f));
+          const float Q = fminf(R, delta2);
+          const float T = Q * fmaf(-0.5f, Q, R);
+          lb = out_all ? fmaf(T, 0.5f, lb) : lb;
+        }
+        lb += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(lb), 0xB1 /*quad_perm [1,0,3,2]*/, 0xf, 0xf, false));
+        if (half == 0 && q < n_tiles && lb * kBoxSafety > lim_box) atomicOr(&s_dead[q >> 5], 1u << (q & 31));
+      }
+      __syncthreads();
+    }
+  }
   float* vol = VOLUME ? volume + (uint64_t)f * (uint64_t)c.p.n_th * n_ty * n_tz * 2u : nullptr;
   const int my_s = lane & (kSlices - 1), my_c = lane >> 2;
   const int my_a = my_c >> 2, my_b = my_c & 3;
@@ -465,6 +520,17 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
       uint32_t since_refresh = 0;
       auto beaten = [&]() -> bool {          // every candidate of the tile provably loses
         const float part = fminf(quad_sum(A0), quad_sum(A1));
+#ifdef ILCC_K6_TIMING
+        {
+          const uint32_t alive = (uint32_t)__popcll(__ballot(!(part > lim2)) & owner_mask) >> 2;
+          if (pin + (pbd - Mi) > (uint32_t)((kFirstIn + kFirstBd) * kSlices) && alive) {
+            ++n_tests;
+            alive_sum += alive;
+            alive_le4 += alive <= 4u;
+            alive_le2 += alive <= 2u;
+          }
+        }
+#endif
         return (__ballot(!(part > lim2)) & owner_mask) == 0ull;
       };
       auto refresh = [&]() {
@@ -660,6 +726,10 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
   for (int tt = wid; tt < n_tiles; tt += THREADS / ILCC_WAVE) {
     const int tile_a = ta, tile_b = tb;
     advance();
+    if (use_box) {
+      const int q = tile_a * ntb + tile_b;
+      if ((__builtin_amdgcn_readfirstlane((int)s_dead[q >> 5]) >> (q & 31)) & 1) continue;
+    }
 #ifdef ILCC_K6_TIMING
     const unsigned long long tt0 = K6_NOW();
     const uint32_t pd0 = pts_done;
@@ -710,6 +780,7 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
     }
     atomicAdd(c.grid_iters + (f & (kIterSlots - 1)), (unsigned long long)it_sum);   // spread over 64 words
     atomicAdd(c.grid_iters + kIterSlots + (f & (kIterSlots - 1)), (unsigned long long)in_sum);
+    if (use_box) atomicAdd(c.grid_iters + 2 * kIterSlots + (f & (kIterSlots - 1)), (unsigned long long)n_tiles * min(c.box_points, M - Mi));
     Best b = s_best[0];
     for (int w = 1; w < THREADS / ILCC_WAVE; ++w)
       if (better(s_best[w].cost, s_best[w].d2, s_best[w].flat, b)) b = s_best[w];
@@ -741,6 +812,10 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
     o[9] = t_end - t_tiles;
     o[10] = (unsigned long long)M;
     o[11] = (unsigned long long)Mi;
+    o[12] = n_tests;
+    o[13] = alive_sum;
+    o[14] = alive_le4;
+    o[15] = alive_le2;
   }
 #endif
 }
@@ -756,6 +831,7 @@ __global__ __launch_bounds__(THREADS) void k6_grid_cost(Ctx c, float* volume) {
   __shared__ Best s_best[THREADS / ILCC_WAVE];
   __shared__ uint32_t s_iters[THREADS / ILCC_WAVE];
   __shared__ uint32_t s_cnt[THREADS / ILCC_WAVE];
+  __shared__ uint32_t s_dead[kBoxTilesMax / 32];   // box pre-pass: one bit per tile of the workgroup
   float2* s_ij = reinterpret_cast<float2*>(smem);
   float* s_hw = reinterpret_cast<float*>(smem + sizeof(float2) * (size_t)c.grid_lds_points);
   float* s_ay = s_hw + c.grid_lds_points;   // n_ty floats
@@ -763,9 +839,9 @@ __global__ __launch_bounds__(THREADS) void k6_grid_cost(Ctx c, float* volume) {
   const uint32_t Mall = c.n_lab[blockIdx.y];
   const uint32_t M = c.walk_limit ? min(Mall, max(c.walk_limit, Mall >> ILCC_SEED_SHIFT)) : Mall;
   if (M <= c.grid_lds_points)
-    grid_cost_body<OOB, VOLUME, true, PRUNE, THREADS>(c, volume, s_ij, s_hw, s_best, s_iters, s_cnt, s_ay, s_az);
+    grid_cost_body<OOB, VOLUME, true, PRUNE, THREADS>(c, volume, s_ij, s_hw, s_best, s_iters, s_cnt, s_ay, s_az, s_dead);
   else
-    grid_cost_body<OOB, VOLUME, false, PRUNE, THREADS>(c, volume, s_ij, s_hw, s_best, s_iters, s_cnt, s_ay, s_az);
+    grid_cost_body<OOB, VOLUME, false, PRUNE, THREADS>(c, volume, s_ij, s_hw, s_best, s_iters, s_cnt, s_ay, s_az, s_dead);
 }
 
 // -DILCC_K6_ISA_PROBE (tools/k6_isa_count.sh): the two terms alone, N chained calls on N different points per kernel.  The

@@ -31,3 +31,6 @@ print("share of wavefront cycles: staging %.1f %%, rejected tiles %.1f %%, survi
       % (100 * p[2] / tot, 100 * p[4] / tot, 100 * p[6] / tot, 100 * p[9] / tot, 100 * (tot - p[2] - p[4] - p[6] - p[9]) / tot))
 print("tiles per wavefront: %.1f rejected at the first test (%.0f cycles each), %.2f survive it (%.0f cycles and %.0f walk positions each; "
       "%.3f run to the end)" % (p[3] / waves, p[4] / max(p[3], 1), p[5] / waves, p[6] / max(p[5], 1), p[7] / max(p[5], 1), p[8] / waves))
+if p[12]:
+    print("bound tests that let a tile walk on (after the first): %.1f per wavefront; candidates still alive at them: mean %.2f of 16; "
+          "<= 4 alive at %.1f %%, <= 2 alive at %.1f %% of these tests" % (p[12] / waves, p[13] / p[12], 100 * p[14] / p[12], 100 * p[15] / p[12]))
