@@ -36,7 +36,9 @@ struct Slot {
   uint64_t* d_off = nullptr;
   ilcc_result* d_res = nullptr;
   float4 *d_roi = nullptr, *d_cluster = nullptr, *d_board = nullptr, *d_pca = nullptr, *d_optim = nullptr;
-  float2* d_yz = nullptr;
+  float2 *d_yz = nullptr, *d_walk_yz = nullptr;
+  uint8_t* d_walk_lab = nullptr;
+  uint32_t *d_walk_mi = nullptr, *d_walk_nrim = nullptr;
   uint8_t *d_lab = nullptr, *d_cls = nullptr;
   uint32_t *d_nlab = nullptr, *d_walk = nullptr, *d_counts = nullptr, *d_parent = nullptr, *d_count = nullptr;
   unsigned long long* d_masks = nullptr;
@@ -232,7 +234,7 @@ int32_t upload_tables(ilcc_handle* h) {
 
 void free_slot(Slot& sl) {
   void* bufs[] = {sl.d_xyzi, sl.d_clicks, sl.d_off, sl.d_res, sl.d_roi, sl.d_cluster, sl.d_board, sl.d_pca, sl.d_optim,
-                  sl.d_yz, sl.d_lab, sl.d_cls, sl.d_nlab, sl.d_walk, sl.d_counts, sl.d_parent, sl.d_count, sl.d_hash_head, sl.d_hash_next, sl.d_big, sl.d_partial, sl.d_partial2, sl.d_partial3, sl.d_partial4, sl.d_masks,
+                  sl.d_yz, sl.d_walk_yz, sl.d_walk_lab, sl.d_walk_mi, sl.d_walk_nrim, sl.d_lab, sl.d_cls, sl.d_nlab, sl.d_walk, sl.d_counts, sl.d_parent, sl.d_count, sl.d_hash_head, sl.d_hash_next, sl.d_big, sl.d_partial, sl.d_partial2, sl.d_partial3, sl.d_partial4, sl.d_masks,
                   sl.d_solverec, sl.d_bound, sl.d_bound_sub, sl.d_iters, sl.d_tie_count, sl.d_tie_list};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -298,6 +300,10 @@ int32_t alloc_slot(ilcc_handle* h, Slot& sl) {
   ALLOC(sl.d_pca, sizeof(float4) * np);
   ALLOC(sl.d_optim, sizeof(float4) * np);
   ALLOC(sl.d_yz, sizeof(float2) * np);
+  ALLOC(sl.d_walk_yz, sizeof(float2) * np);
+  ALLOC(sl.d_walk_lab, np);
+  ALLOC(sl.d_walk_mi, sizeof(uint32_t) * mf);
+  ALLOC(sl.d_walk_nrim, sizeof(uint32_t) * mf);
   ALLOC(sl.d_lab, np);
   ALLOC(sl.d_cls, np);
   ALLOC(sl.d_nlab, sizeof(uint32_t) * mf);
@@ -345,6 +351,10 @@ Ctx make_ctx(ilcc_handle* h, Slot& sl, const float4* d_xyzi, const float* d_clic
   c.cls = sl.d_cls;
   c.n_lab = sl.d_nlab;
   c.walk_stride = sl.d_walk;
+  c.walk_yz = sl.d_walk_yz;
+  c.walk_lab = sl.d_walk_lab;
+  c.walk_mi = sl.d_walk_mi;
+  c.walk_nrim = sl.d_walk_nrim;
   c.crop_counts = sl.d_counts;
   c.crop_masks = sl.d_masks;
   c.uf_parent = sl.d_parent;
@@ -474,6 +484,7 @@ int32_t enqueue_impl(ilcc_handle* h, int si, const float4* d_xyzi, const uint64_
   HIP_TRY(h, hipEventRecord(sl.ev[4], s));
   if (sl.grid) {
     const bool prune = h->p.grid_prune != 0;
+    launch_walk_order(c, s);   // K5w: the labelled points in K6's walk layout, once per frame
     Ctx full = c;
     // (grid_prune = 0 keeps the two small passes: they only initialise the frame's bound, which the cut-free full
     // pass still needs to recognise near ties; it never cuts a tile)
@@ -1132,6 +1143,7 @@ int32_t ilcc_grid_cost(ilcc_handle* h, const float* yz, const uint8_t* label, ui
   h->grid_lds_points = saved;
   const uint32_t inf_bits = 0x7f800000u;
   HIP_TRY(h, hipMemcpyAsync(sl.d_bound, &inf_bits, sizeof(inf_bits), hipMemcpyHostToDevice, s));
+  launch_walk_order(c, s);
   // full evaluation when the volume is wanted, the pipeline's branch-and-bound variant otherwise
   launch_grid_cost(c, s, use_oob, d_vol, /*prune=*/d_vol == nullptr && h->p.grid_prune != 0);
   std::vector<GridPartial> part(c.grid_blocks);

@@ -114,6 +114,10 @@ struct Ctx {
   uint8_t* lab;              // 0 black, 1 white
   uint32_t* n_lab;           // per frame
   uint32_t* walk_stride;     // per frame: K6's point-walk stride, walk_stride(n_lab) -- written with n_lab (K4/K5, stage_labelled)
+  // K5w: the labelled points in K6's walk layout [interior | rim | other border] (frames of at most kGridLdsPointsMax points)
+  float2* walk_yz;
+  uint8_t* walk_lab;
+  uint32_t *walk_mi, *walk_nrim;   // per frame: interior-class points, rim points
   uint8_t* cls;              // color_by_gray_zone class of every plane point: 0 black, 1 gray, 2 white
   uint32_t* crop_counts;     // n_frames x crop_chunks
   unsigned long long* crop_masks;  // n_frames x crop_chunks x (kCropChunk / 64) keep-bits of the count pass
@@ -258,6 +262,7 @@ void launch_roi_crop(const Ctx& c, hipStream_t s);
 void launch_cluster(const Ctx& c, hipStream_t s);
 void launch_ransac_plane(const Ctx& c, hipStream_t s);
 void launch_plane_frame_hist(const Ctx& c, hipStream_t s);
+void launch_walk_order(const Ctx& c, hipStream_t s);   // K5w (k6_grid_cost.hip): before any launch_grid_cost on the frames
 void launch_grid_cost(const Ctx& c, hipStream_t s, int32_t use_oob, float* cost_volume /*nullable*/,
                       bool prune);
 uint32_t grid_cost_evals_per_count();   // (point, candidate) evaluations behind one count of Ctx::grid_iters

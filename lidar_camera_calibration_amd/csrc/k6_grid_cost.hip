@@ -232,122 +232,34 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
   }
   const float cth = c.cth[k], sth = c.sth[k];
 
-  // Point order: slot s holds point (s * S) mod M with S ~ 0.618 M coprime to M, so that EVERY prefix
-  // of the walk is a sample spread over the whole board (ring order would spend the first points on
-  // one scan line, which says little about a candidate): the bound test cuts tiles sooner.
-  const uint32_t S = Mfull ? c.walk_stride[f] : 1u;   // walk_stride(Mfull), computed where n_lab is written
-  // Staged points come in two classes.  INTERIOR: in the board under EVERY translation of the tables (checked with
-  // accumulate<>'s own fp32 expressions at the four extreme translations; |i - W/2| - W/2 is V-shaped in i and every
-  // operation is monotone, so the extremes decide for all values in between) -> accumulate_interior.  BORDER: the rest.
-  // Interior points fill [0, Mi) in walk order, border points fill [Mi, M) in reverse walk order (a stable partition by
-  // ballot ranks, chunk by chunk: deterministic, so are the fp32 sums).
+  // Point order: k5w_walk_order (below) has written the frame's labelled points in WALK layout, once per frame instead of once
+  // per workgroup: [interior class | rim | other border-class points], each part in golden-ratio order (slot s of the walk
+  // holds point (s * S) mod M with S ~ 0.618 M coprime to M, so that every prefix of a part is a sample spread over the whole
+  // board: the bound test cuts tiles sooner than ring order would).  INTERIOR: in the board under EVERY rotation and
+  // translation of the tables -> accumulate_interior.  Staging is then a rotation of M points by this workgroup's theta.
+  // A subsampled launch (walk_limit) stages a prefix of each part, in proportion.
+  const uint32_t S = Mfull ? c.walk_stride[f] : 1u;   // (the walk through global memory of frames too large for LDS)
   uint32_t Mi = 0;
   if (LDS_POINTS) {
-    const float Wh_ = 0.5f * (float)c.p.board_w, Hh_ = 0.5f * (float)c.p.board_h;
-    const float ay_lo = c.ay[0], ay_hi = c.ay[c.p.n_ty - 1], az_lo = c.az[0], az_hi = c.az[c.p.n_tz - 1];
-    uint32_t base_in = 0, base_out = 0;
-    // slot sl <- point (sl * S) mod M, advanced chunk by chunk (M <= 8192 here: the products fit 32 bits)
-#ifndef ILCC_K6_RIM
-#define ILCC_K6_RIM 300   // border-class points within this many thousandths of a square of the outline (at zero translation) are walked FIRST: rim 0: 350 k, 150: 355 k, 300: 357 k, 500: 351 k frames/s (first block 0+4); with a 0+2 first block 200: 385 k, 300: 388 k, 400: 384 k
-#endif
-    const float ay_c = c.ay[c.c_ty], az_c = c.az[c.c_tz];
-    const float rim_thr = -(float)ILCC_K6_RIM * 1e-3f;
-    const uint32_t pstep = Mfull ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(((uint32_t)THREADS * S) % Mfull)) : 0u;
-    // class: 0 interior, 1 border, 2 rim (border and close to the outline at zero translation)
-    auto classify = [&](uint32_t i, float2& ij, float& hw) -> int {
-      const float2 v = gyz[i];
+    const float2* __restrict__ wyz = c.walk_yz + beg;
+    const uint8_t* __restrict__ wlab = c.walk_lab + beg;
+    const uint32_t Mi_all = c.walk_mi[f], n_rim_all = c.walk_nrim[f];
+    uint32_t n_in = Mi_all, n_rm = n_rim_all;
+    if (M < Mfull) {
+      n_in = (uint32_t)(((uint64_t)Mi_all * M) / Mfull);
+      n_rm = (uint32_t)(((uint64_t)n_rim_all * M) / Mfull);
+    }
+    // (parts are prefixes: n_in <= Mi_all, n_rm <= n_rim_all, and the rest M - n_in - n_rm <= the other border points + 2:
+    // floor() twice; the source index below is clamped for that)
+    for (uint32_t sl = threadIdx.x; sl < M; sl += THREADS) {
+      uint32_t src = sl < n_in ? sl : sl < n_in + n_rm ? Mi_all + (sl - n_in) : Mi_all + n_rim_all + (sl - n_in - n_rm);
+      src = min(src, Mfull - 1u);
+      const float2 v = wyz[src];
       // Rx(theta) on (0,y,z), already divided by g (Optimization.h:37-46)
-      ij = make_float2(fmaf(-sth, v.y, cth * v.x), fmaf(cth, v.y, sth * v.x));
-      hw = glab[i] ? 0.5f : 0.f;
-      if (!ILCC_K6_SPLIT) return 1;
-      const float u0 = fabsf((ij.x + ay_lo) - Wh_) - Wh_, u1 = fabsf((ij.x + ay_hi) - Wh_) - Wh_;
-      const float w0 = fabsf((ij.y + az_lo) - Hh_) - Hh_, w1 = fabsf((ij.y + az_hi) - Hh_) - Hh_;
-      if (fmaxf(fmaxf(u0, u1), fmaxf(w0, w1)) < 0.f) return 0;
-      if (ILCC_K6_RIM) {
-        const float uc = fabsf((ij.x + ay_c) - Wh_) - Wh_, wc = fabsf((ij.y + az_c) - Hh_) - Hh_;
-        if (fmaxf(uc, wc) > rim_thr) return 2;
-      }
-      return 1;
-    };
-    uint32_t n_rim = 0;
-    if (ILCC_K6_RIM) {   // counting pass: the rim points' region [Mi, Mi + n_rim) needs both totals before anything is placed
-      uint32_t pidx0 = Mfull ? (threadIdx.x * S) % Mfull : 0u;
-      uint32_t cnt_in = 0, cnt_rim = 0;
-      for (uint32_t c0 = 0; c0 < M; c0 += THREADS) {
-        const uint32_t i = pidx0;
-        pidx0 += pstep;
-        if (pidx0 >= Mfull) pidx0 -= Mfull;
-        if (c0 + threadIdx.x < M) {
-          float2 ij;
-          float hw;
-          const int cl = classify(i, ij, hw);
-          cnt_in += cl == 0;
-          cnt_rim += cl == 2;
-        }
-      }
-      cnt_in = wave_sum(cnt_in);
-      cnt_rim = wave_sum(cnt_rim);
-      if (lane == 0) {
-        s_iters[wid] = cnt_in;
-        s_cnt[wid] = cnt_rim;
-      }
-      __syncthreads();
-      uint32_t ti = 0, tr = 0;
-      for (int w = 0; w < THREADS / ILCC_WAVE; ++w) {
-        ti += s_iters[w];
-        tr += s_cnt[w];
-      }
-      __syncthreads();
-      Mi = ti;
-      n_rim = tr;
+      s_ij[sl] = make_float2(fmaf(-sth, v.y, cth * v.x), fmaf(cth, v.y, sth * v.x));
+      s_hw[sl] = wlab[src] ? 0.5f : 0.f;
     }
-    uint32_t pidx = Mfull ? (threadIdx.x * S) % Mfull : 0u;
-    uint32_t base_rim = 0;
-    for (uint32_t c0 = 0; c0 < M; c0 += THREADS) {
-      const uint32_t sl = c0 + threadIdx.x;
-      const bool valid = sl < M;
-      float2 ij = make_float2(0.f, 0.f);
-      float hw = 0.f;
-      int cl = -1;
-      const uint32_t i = pidx;
-      pidx += pstep;
-      if (pidx >= Mfull) pidx -= Mfull;
-      if (valid) cl = classify(i, ij, hw);
-      const bool interior = cl == 0, rim = cl == 2;
-      const unsigned long long m_in = __ballot(interior), m_out = __ballot(cl == 1), m_rim = __ballot(rim);
-      const unsigned long long below = (1ull << lane) - 1ull;
-      if (lane == 0) {
-        s_iters[wid] = (uint32_t)__popcll(m_in) | ((uint32_t)__popcll(m_rim) << 16);          // (s_iters / s_cnt are free until the epilogue)
-        s_cnt[wid] = (uint32_t)__popcll(m_out);
-      }
-      __syncthreads();
-      uint32_t pre_in = 0, pre_out = 0, pre_rim = 0, tot_in = 0, tot_out = 0, tot_rim = 0;
-#pragma unroll
-      for (int w = 0; w < THREADS / ILCC_WAVE; ++w) {
-        const uint32_t a = s_iters[w] & 0xFFFFu, r = s_iters[w] >> 16, b = s_cnt[w];
-        if (w < wid) {
-          pre_in += a;
-          pre_out += b;
-          pre_rim += r;
-        }
-        tot_in += a;
-        tot_out += b;
-        tot_rim += r;
-      }
-      if (valid) {
-        const uint32_t at = interior ? base_in + pre_in + (uint32_t)__popcll(m_in & below)
-                            : rim    ? Mi + base_rim + pre_rim + (uint32_t)__popcll(m_rim & below)
-                                     : M - 1u - (base_out + pre_out + (uint32_t)__popcll(m_out & below));
-        s_ij[at] = ij;
-        s_hw[at] = hw;
-      }
-      base_in += tot_in;
-      base_out += tot_out;
-      base_rim += tot_rim;
-      __syncthreads();
-    }
-    (void)n_rim;
-    Mi = (uint32_t)__builtin_amdgcn_readfirstlane((int)base_in);
+    Mi = n_in;
   }
   // (ty, tz) tables in LDS: a cut-short tile lasts about as long as one L2 round trip, so its
   // prologue must not wait for global loads
@@ -838,10 +750,134 @@ __global__ __launch_bounds__(THREADS) void k6_grid_cost(Ctx c, float* volume) {
   float* s_az = s_ay + c.p.n_ty;            // n_tz floats
   const uint32_t Mall = c.n_lab[blockIdx.y];
   const uint32_t M = c.walk_limit ? min(Mall, max(c.walk_limit, Mall >> ILCC_SEED_SHIFT)) : Mall;
-  if (M <= c.grid_lds_points)
+  (void)M;
+  if (Mall <= c.grid_lds_points)   // (k5w_walk_order has laid out every frame of at most kGridLdsPointsMax points)
     grid_cost_body<OOB, VOLUME, true, PRUNE, THREADS>(c, volume, s_ij, s_hw, s_best, s_iters, s_cnt, s_ay, s_az, s_dead);
   else
     grid_cost_body<OOB, VOLUME, false, PRUNE, THREADS>(c, volume, s_ij, s_hw, s_best, s_iters, s_cnt, s_ay, s_az, s_dead);
+}
+
+// K5w walk order: the frame's labelled points in the layout k6_grid_cost stages -- [interior | rim | other border], each part
+// in golden-ratio walk order -- written ONCE per frame (round 3 until here: every one of a frame's ~80 K6 workgroups
+// classified and partitioned the points again, 20 % of the full pass's VALU instructions).
+//   interior: in the board under every rotation of the theta table and every translation of the (ty, tz) tables, decided
+//             with accumulate<>'s own fp32 expressions at the four extreme translations (|i - W/2| - W/2 is V-shaped in i and
+//             every operation is monotone, so the extremes decide for all values in between; the decimated tables of the
+//             seed launch are subsets of the full ones) -> accumulate_interior is exact for these points in every launch;
+//   rim:      border-class and within ILCC_K6_RIM thousandths of a square of the outline at the grid's centre candidate:
+//             walked first, they are the points that leave the board when the translation is wrong (ordering only).
+#ifndef ILCC_K6_RIM
+#define ILCC_K6_RIM 300   // rim 0: 350 k, 150: 355 k, 300: 357 k, 500: 351 k frames/s (first block 0+4); with a 0+2 first block 200: 385 k, 300: 388 k, 400: 384 k
+#endif
+constexpr int kWalkThreads = 1024;
+__global__ __launch_bounds__(kWalkThreads) void k5w_walk_order(Ctx c) {
+  __shared__ uint8_t s_cls[kGridLdsPointsMax];
+  __shared__ uint32_t s_in[kWalkThreads / ILCC_WAVE], s_rim[kWalkThreads / ILCC_WAVE], s_oth[kWalkThreads / ILCC_WAVE];
+  const uint32_t f = blockIdx.x;
+  if (c.res[f].status != ILCC_OK) return;
+  const uint32_t M = c.n_lab[f];
+  if (M == 0u || M > (uint32_t)kGridLdsPointsMax) {   // K6 walks such a frame through global memory in golden-ratio order
+    if (threadIdx.x == 0) {
+      c.walk_mi[f] = 0u;
+      c.walk_nrim[f] = 0u;
+    }
+    return;
+  }
+  const int lane = lane_id();
+  const int wid = wave_id();
+  const uint64_t beg = c.off[f];
+  const float2* __restrict__ gyz = c.yz + beg;
+  const uint8_t* __restrict__ glab = c.lab + beg;
+  const uint32_t S = c.walk_stride[f];
+  const float Wh = 0.5f * (float)c.p.board_w, Hh = 0.5f * (float)c.p.board_h;
+  const float ay_lo = c.ay[0], ay_hi = c.ay[c.p.n_ty - 1], az_lo = c.az[0], az_hi = c.az[c.p.n_tz - 1];
+  const float ay_c = c.ay[c.c_ty], az_c = c.az[c.c_tz];
+  const float rim_thr = -(float)ILCC_K6_RIM * 1e-3f;
+  const int n_th = c.p.n_th;
+  // class of every walk slot: 0 interior, 1 other border, 2 rim
+  uint32_t cnt_in = 0, cnt_rim = 0;
+  for (uint32_t sl = threadIdx.x; sl < M; sl += kWalkThreads) {
+    const float2 v = gyz[(uint32_t)(((uint64_t)sl * S) % M)];
+    float worst = -__builtin_inff();
+    for (int k = 0; k < n_th; ++k) {
+      const float cth = c.cth[k], sth = c.sth[k];
+      const float pi = fmaf(-sth, v.y, cth * v.x), pj = fmaf(cth, v.y, sth * v.x);
+      const float u0 = fabsf((pi + ay_lo) - Wh) - Wh, u1 = fabsf((pi + ay_hi) - Wh) - Wh;
+      const float w0 = fabsf((pj + az_lo) - Hh) - Hh, w1 = fabsf((pj + az_hi) - Hh) - Hh;
+      worst = fmaxf(worst, fmaxf(fmaxf(u0, u1), fmaxf(w0, w1)));
+    }
+    int cl = 0;
+    if (!(worst < 0.f) || !ILCC_K6_SPLIT) {
+      const float cth = c.cth[c.c_th], sth = c.sth[c.c_th];
+      const float pi = fmaf(-sth, v.y, cth * v.x), pj = fmaf(cth, v.y, sth * v.x);
+      const float uc = fabsf((pi + ay_c) - Wh) - Wh, wc = fabsf((pj + az_c) - Hh) - Hh;
+      cl = (ILCC_K6_RIM && fmaxf(uc, wc) > rim_thr) ? 2 : 1;
+    }
+    s_cls[sl] = (uint8_t)cl;
+    cnt_in += cl == 0;
+    cnt_rim += cl == 2;
+  }
+  cnt_in = wave_sum(cnt_in);
+  cnt_rim = wave_sum(cnt_rim);
+  if (lane == 0) {
+    s_in[wid] = cnt_in;
+    s_rim[wid] = cnt_rim;
+  }
+  __syncthreads();
+  uint32_t Mi = 0, n_rim = 0;
+  for (int w = 0; w < kWalkThreads / ILCC_WAVE; ++w) {
+    Mi += s_in[w];
+    n_rim += s_rim[w];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    c.walk_mi[f] = Mi;
+    c.walk_nrim[f] = n_rim;
+  }
+  // stable partition, chunk by chunk (ballot ranks inside a wavefront, counts of the wavefronts in LDS): deterministic
+  float2* __restrict__ wyz = c.walk_yz + beg;
+  uint8_t* __restrict__ wlab = c.walk_lab + beg;
+  uint32_t base_in = 0, base_rim = Mi, base_oth = Mi + n_rim;
+  for (uint32_t c0 = 0; c0 < M; c0 += kWalkThreads) {
+    const uint32_t sl = c0 + threadIdx.x;
+    const int cl = sl < M ? (int)s_cls[sl] : -1;
+    const unsigned long long m_in = __ballot(cl == 0), m_oth = __ballot(cl == 1), m_rim = __ballot(cl == 2);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (lane == 0) {
+      s_in[wid] = (uint32_t)__popcll(m_in);
+      s_rim[wid] = (uint32_t)__popcll(m_rim);
+      s_oth[wid] = (uint32_t)__popcll(m_oth);
+    }
+    __syncthreads();
+    uint32_t pre_in = 0, pre_rim = 0, pre_oth = 0, tot_in = 0, tot_rim = 0, tot_oth = 0;
+    for (int w = 0; w < kWalkThreads / ILCC_WAVE; ++w) {
+      const uint32_t a = s_in[w], r = s_rim[w], o = s_oth[w];
+      if (w < wid) {
+        pre_in += a;
+        pre_rim += r;
+        pre_oth += o;
+      }
+      tot_in += a;
+      tot_rim += r;
+      tot_oth += o;
+    }
+    if (cl >= 0) {
+      const uint32_t at = cl == 0   ? base_in + pre_in + (uint32_t)__popcll(m_in & below)
+                          : cl == 2 ? base_rim + pre_rim + (uint32_t)__popcll(m_rim & below)
+                                    : base_oth + pre_oth + (uint32_t)__popcll(m_oth & below);
+      const uint32_t i = (uint32_t)(((uint64_t)sl * S) % M);
+      wyz[at] = gyz[i];
+      wlab[at] = glab[i];
+    }
+    base_in += tot_in;
+    base_rim += tot_rim;
+    base_oth += tot_oth;
+    __syncthreads();
+  }
+}
+
+void launch_walk_order(const Ctx& c, hipStream_t s) {
+  hipLaunchKernelGGL(k5w_walk_order, dim3(c.n_frames), dim3(kWalkThreads), 0, s, c);
 }
 
 // -DILCC_K6_ISA_PROBE (tools/k6_isa_count.sh): the two terms alone, N chained calls on N different points per kernel.  The
