@@ -480,7 +480,7 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
 #define ILCC_K6_LOOP_IN 0   // interior- / border-class points per lane and trip of this loop
 #endif
 #ifndef ILCC_K6_LOOP_BD
-#define ILCC_K6_LOOP_BD 2   // (rim-first, 0+2 first block) loop in+bd 0+2: 388 k, 1+2: 383 k, 0+3: 383 k frames/s
+#define ILCC_K6_LOOP_BD 3   // (rim-first, 0+2 first block) loop in+bd 0+2: 388 k, 1+2: 383 k, 0+3: 383 k frames/s; with the box pre-pass 0+1: 501 k, 0+2: 513 k, 0+3: 523 k, 1+2: 508 k
 #endif
         constexpr int kLoopIn = ILCC_K6_LOOP_IN, kLoopBd = ILCC_K6_LOOP_BD;
         constexpr uint32_t kStepIn = kLoopIn * kSlices, kStepBd = kLoopBd * kSlices;
