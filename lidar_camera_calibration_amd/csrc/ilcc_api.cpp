@@ -52,6 +52,7 @@ struct Slot {
   // pinned host staging
   ilcc_result* h_res = nullptr;
   unsigned long long* h_iters = nullptr;
+  uint64_t* h_off = nullptr;   // pinned copy of `off`: the upload at the head of a batch must not stage through pageable memory
   // state of the batch in flight / last completed
   std::vector<uint64_t> off;
   uint32_t n_frames = 0;
@@ -240,6 +241,7 @@ void free_slot(Slot& sl) {
     if (b) (void)hipFree(b);
   if (sl.h_res) (void)hipHostFree(sl.h_res);
   if (sl.h_iters) (void)hipHostFree(sl.h_iters);
+  if (sl.h_off) (void)hipHostFree(sl.h_off);
   for (auto& ev : sl.ev)
     if (ev) (void)hipEventDestroy(ev);
   if (sl.k6_done) (void)hipEventDestroy(sl.k6_done);
@@ -328,6 +330,7 @@ int32_t alloc_slot(ilcc_handle* h, Slot& sl) {
 #undef ALLOC
   HIP_TRY(h, hipHostMalloc((void**)&sl.h_res, sizeof(ilcc_result) * mf, hipHostMallocDefault));
   HIP_TRY(h, hipHostMalloc((void**)&sl.h_iters, sizeof(unsigned long long) * 3 * kIterSlots, hipHostMallocDefault));
+  HIP_TRY(h, hipHostMalloc((void**)&sl.h_off, sizeof(uint64_t) * (mf + 1), hipHostMallocDefault));
   sl.allocated = true;
   return ILCC_OK;
 }
@@ -464,7 +467,8 @@ int32_t enqueue_impl(ilcc_handle* h, int si, const float4* d_xyzi, const uint64_
   sl.off.assign(offsets, offsets + n_frames + 1);
   sl.n_frames = n_frames;
   hipStream_t s = sl.stream;
-  HIP_TRY(h, hipMemcpyAsync(sl.d_off, sl.off.data(), sizeof(uint64_t) * (n_frames + 1), hipMemcpyHostToDevice, s));
+  std::memcpy(sl.h_off, sl.off.data(), sizeof(uint64_t) * (n_frames + 1));
+  HIP_TRY(h, hipMemcpyAsync(sl.d_off, sl.h_off, sizeof(uint64_t) * (n_frames + 1), hipMemcpyHostToDevice, s));
   // (result records, component counters, K6 counters and near-tie counters are reset inside K1 / K2)
   Ctx c = make_ctx(h, sl, d_xyzi, d_clicks, n_frames, chunks);
   if (no_crop) {   // get_chessboard_by_point clusters the whole cloud: an unbounded box only drops non-finite points

@@ -22,7 +22,7 @@ constexpr int kFrameThreads = ILCC_K2_THREADS;    // K2: one workgroup per frame
 #define ILCC_K3_THREADS 256    // measured in the pipelined bench: 1024: 229.6 k, 512: 230.4 k, 256: 235.2 k frames/s
 #endif
 #ifndef ILCC_K45_THREADS
-#define ILCC_K45_THREADS 1024
+#define ILCC_K45_THREADS 256   // measured in the pipelined bench (box pre-pass in place): 1024: 519 k, 512: 530 k, 256: 543 k frames/s -- a 1024-thread workgroup needs 16 free wave slots on ONE CU while another batch's K6 full pass keeps refilling them
 #endif
 constexpr int kPlaneThreads = ILCC_K3_THREADS;    // K3: one workgroup per frame
 constexpr int kPlaneThreadsSmallBatch = 1024;     // K3 in batches of <= kSmallBatchFrames frames (latency, not CU footprint, matters)

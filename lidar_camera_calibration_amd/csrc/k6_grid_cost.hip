@@ -769,7 +769,10 @@ __global__ __launch_bounds__(THREADS) void k6_grid_cost(Ctx c, float* volume) {
 #ifndef ILCC_K6_RIM
 #define ILCC_K6_RIM 300   // rim 0: 350 k, 150: 355 k, 300: 357 k, 500: 351 k frames/s (first block 0+4); with a 0+2 first block 200: 385 k, 300: 388 k, 400: 384 k
 #endif
-constexpr int kWalkThreads = 1024;
+#ifndef ILCC_K5W_THREADS
+#define ILCC_K5W_THREADS 1024
+#endif
+constexpr int kWalkThreads = ILCC_K5W_THREADS;
 __global__ __launch_bounds__(kWalkThreads) void k5w_walk_order(Ctx c) {
   __shared__ uint8_t s_cls[kGridLdsPointsMax];
   __shared__ uint32_t s_in[kWalkThreads / ILCC_WAVE], s_rim[kWalkThreads / ILCC_WAVE], s_oth[kWalkThreads / ILCC_WAVE];
