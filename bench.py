@@ -62,6 +62,8 @@ VALU_ISSUE_PEAK_T = 78.6
 # re-runs the script and fails when these constants, that file and the current source disagree.
 K6_VALU_OPS_BORDER = 29.0
 K6_VALU_OPS_INTERIOR = 15.0
+# ... and of ONE (point, 16-candidate tile) evaluation of the full pass's box pre-pass (box_term: a lower bound for the whole tile)
+K6_VALU_OPS_BOX = 24.0
 # PMC passes of the K6 stage at the batch sizes this bench runs (tools/gpu_pmc.sh -> profiles/): per-launch counters of one
 # batch alone on the chip.  roofline.traffic and roofline.issued_vs_credited are computed from these files at run time.
 PMC_FILES = {(2, 256): "profiles/r03_pmc_cfg2_256f.csv", (5, 64): "profiles/r03_pmc_cfg5_64f.csv"}
@@ -330,9 +332,11 @@ def main():
         evals_interior = tm.grid_cost_evals_interior_sum / launches
         valu_ops_per_eval = (K6_VALU_OPS_INTERIOR * evals_interior + K6_VALU_OPS_BORDER * (evals_per_launch - evals_interior)) \
             / max(1.0, evals_per_launch)
-        valu_rate = evals_per_launch * valu_ops_per_eval / (k6_ms * 1e-3) / 1e12
+        box_evals = tm.grid_cost_box_evals_sum / launches               # (point, tile) evaluations of the box pre-pass
+        credited_lane_instr = evals_per_launch * valu_ops_per_eval + box_evals * K6_VALU_OPS_BOX
+        valu_rate = credited_lane_instr / (k6_ms * 1e-3) / 1e12
         pmc = k6_pmc(args.config, F)
-        credited_wave_instr = evals_per_launch * valu_ops_per_eval / 64.0
+        credited_wave_instr = credited_lane_instr / 64.0
         low = [bool(res[f].flags & N.FLAG_LOW_COVERAGE) for f in range(FS)]
         acc = [f for f in ok if not low[f]]
         err_acc = np.array([synth.corner_error(res[f].corners_array(), gts[f], board) for f in acc])
@@ -419,6 +423,8 @@ def main():
                 "evals_nominal_per_launch": evals_nominal,
                 "executed_fraction": evals_per_launch / evals_nominal if evals_nominal else None,
                 "valu_instr_per_eval": valu_ops_per_eval,
+                "box_evals_per_launch": box_evals,
+                "valu_instr_per_box_eval": K6_VALU_OPS_BOX,
                 "evals_executed_per_s": evals_per_launch / (k6_ms * 1e-3),
                 "interior_class_fraction_of_executed_evals": evals_interior / max(1.0, evals_per_launch),
                 "hbm": {"algorithmic_bytes_per_launch": k6_bytes, "achieved_GBps": achieved, "peak_GBps": HBM_PEAK_GBPS,
@@ -426,8 +432,8 @@ def main():
                         "whole_path_GBps": fps / max(1, world) * bytes_per_frame / 1e9,
                         "whole_path_frac": fps / max(1, world) * bytes_per_frame / 1e9 / HBM_PEAK_GBPS},
                 "note": "k6_grid_cost is VALU-bound by construction (points staged once in LDS, ~1e8 nominal "
-                        "point-candidate evaluations per frame, no MFMA): achieved = executed evaluations x their VALU "
-                        "instructions (%g border-class, %g interior-class, tools/k6_isa_count.sh: the term only -- bound tests, prologues and address arithmetic are not credited) / launch duration." % (K6_VALU_OPS_BORDER, K6_VALU_OPS_INTERIOR) + "  launch = the K6 stage of one batch (seed + refinement + anchor + full "
+                        "point-candidate evaluations per frame, no MFMA): achieved = (executed evaluations x their VALU "
+                        "instructions (%g border-class, %g interior-class) + the box pre-pass's (point, tile) evaluations x %g; tools/k6_isa_count.sh: the terms only -- bound tests, prologues and address arithmetic are not credited) / launch duration.  The box pre-pass (round 3) rejects a 16-candidate tile with 32 x %g instructions instead of 16 x 8 x %g: executed_fraction and this rate fall while frames/s rise" % (K6_VALU_OPS_BORDER, K6_VALU_OPS_INTERIOR, K6_VALU_OPS_BOX, K6_VALU_OPS_BOX, K6_VALU_OPS_BORDER) + "  launch = the K6 stage of one batch (seed + refinement + anchor + full "
                         "launch), timed by HIP events on the library's stream (the wait for the previous batch's full pass "
                         "between the refinement and the full launch is excluded).  `hbm` holds the algorithmic-bytes "
                         "fraction of the 8 TB/s peak that BASELINE.json asks for",

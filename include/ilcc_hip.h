@@ -277,6 +277,11 @@ int64_t ilcc_fetch_cloud(ilcc_handle* h, uint32_t frame, int32_t which, float* o
 /* non-gray points handed to the cost: y,z (plane frame) and label (0 black, 1 white) */
 int64_t ilcc_fetch_labelled(ilcc_handle* h, uint32_t frame, float* out_yz, uint8_t* out_label,
                             uint64_t cap_points);
+/* the same points in the grid search's WALK layout (GRID solver, frames of at most 8192 labelled points):
+ * [interior class | rim | other border-class points], each part in golden-ratio walk order; counts[0] = interior-class
+ * points (in the board under every rotation and translation of the grid), counts[1] = rim points.  Test/diagnostic entry. */
+int64_t ilcc_fetch_walk(ilcc_handle* h, uint32_t frame, float* out_yz, uint8_t* out_label, uint64_t cap_points,
+                        uint32_t counts[2]);
 
 /* the grid-cost kernel on caller-supplied labelled points (host buffers): full cost volume
  * [n_th][n_ty][n_tz][2 phases] (cost_out may be NULL) and the argmin exactly as the pipeline

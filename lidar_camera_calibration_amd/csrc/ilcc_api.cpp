@@ -1094,6 +1094,28 @@ int64_t ilcc_fetch_labelled(ilcc_handle* h, uint32_t frame, float* out_yz, uint8
   return (int64_t)n;
 }
 
+int64_t ilcc_fetch_walk(ilcc_handle* h, uint32_t frame, float* out_yz, uint8_t* out_label, uint64_t cap_points, uint32_t counts[2]) {
+  if (!h || h->last_slot < 0) return -(int64_t)ILCC_BAD_ARGUMENT;
+  Slot& sl = h->slots[h->last_slot];
+  if (sl.busy || frame >= sl.n_frames || !sl.grid) return -(int64_t)ILCC_BAD_ARGUMENT;
+  uint32_t n = 0;
+  if (hipMemcpy(&n, sl.d_nlab + frame, sizeof(n), hipMemcpyDeviceToHost) != hipSuccess) return -(int64_t)ILCC_HIP_ERROR;
+  if (n > (uint32_t)kGridLdsPointsMax) n = 0;   // such a frame is walked through global memory: no layout
+  if (counts) {
+    if (hipMemcpy(&counts[0], sl.d_walk_mi + frame, sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(&counts[1], sl.d_walk_nrim + frame, sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess)
+      return -(int64_t)ILCC_HIP_ERROR;
+  }
+  const uint64_t m = std::min<uint64_t>(n, cap_points);
+  if (m > 0) {
+    if (out_yz && hipMemcpy(out_yz, sl.d_walk_yz + sl.off[frame], sizeof(float2) * m, hipMemcpyDeviceToHost) != hipSuccess)
+      return -(int64_t)ILCC_HIP_ERROR;
+    if (out_label && hipMemcpy(out_label, sl.d_walk_lab + sl.off[frame], m, hipMemcpyDeviceToHost) != hipSuccess)
+      return -(int64_t)ILCC_HIP_ERROR;
+  }
+  return (int64_t)n;
+}
+
 // shared setup for the two single-kernel test entries: frame 0 of slot 0 = caller's labelled points
 static int32_t stage_labelled(ilcc_handle* h, const float* yz, const uint8_t* label, uint32_t m) {
   if (!h || (m > 0 && (!yz || !label))) return ILCC_BAD_ARGUMENT;

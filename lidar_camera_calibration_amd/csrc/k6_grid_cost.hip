@@ -150,6 +150,22 @@ __device__ __forceinline__ void accumulate_interior(const PointTerms& p, float a
   A1 = fmaf(T, nmf, A1);
 }
 
+
+// Box pre-pass, one point against one tile: adds to lb a lower bound of the point's term (cost / 2, either colour phase) for
+// EVERY translation in [alo, ahi] x [zlo, zhi] -- see the pre-pass in grid_cost_body for the argument.
+__device__ __forceinline__ void box_term(float pi, float pj, float alo, float ahi, float zlo, float zhi, float Wh, float Hh,
+                                         float delta, float& lb) {
+  const float i_lo = pi + alo, i_hi = pi + ahi, j_lo = pj + zlo, j_hi = pj + zhi;
+  const float ui_lo = fabsf(i_lo - Wh) - Wh, ui_hi = fabsf(i_hi - Wh) - Wh;
+  const float uj_lo = fabsf(j_lo - Hh) - Hh, uj_hi = fabsf(j_hi - Hh) - Hh;
+  const bool out_all = fmaxf(fminf(ui_lo, ui_hi), fminf(uj_lo, uj_hi)) >= 0.f;   // out of the board everywhere in the box
+  // |u| closest to zero over the box: the end value nearer to zero, 0 when the ends differ in sign
+  const float R = fabsf(__builtin_amdgcn_fmed3f(ui_lo, ui_hi, 0.f)) + fabsf(__builtin_amdgcn_fmed3f(uj_lo, uj_hi, 0.f));
+  const float Q = fminf(R, delta);
+  const float T = Q * fmaf(-0.5f, Q, R);
+  lb = out_all ? fmaf(T, 0.5f, lb) : lb;
+}
+
 #ifndef ILCC_K6_SPLIT
 #define ILCC_K6_SPLIT 1   // (A/B builds: 0 = one class of points, every point takes the full accumulate<>)
 #endif
@@ -314,15 +330,7 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
         float lb = 0.f;
         for (uint32_t u = (uint32_t)half; u < n_pre; u += 2u) {
           const float2 v = s_ij[Mi + u];
-          const float i_lo = v.x + alo, i_hi = v.x + ahi, j_lo = v.y + zlo, j_hi = v.y + zhi;
-          const float ui_lo = fabsf(i_lo - Wh) - Wh, ui_hi = fabsf(i_hi - Wh) - Wh;
-          const float uj_lo = fabsf(j_lo - Hh) - Hh, uj_hi = fabsf(j_hi - Hh) - Hh;
-          const bool out_all = fmaxf(fminf(ui_lo, ui_hi), fminf(uj_lo, uj_hi)) >= 0.f;
-          // |u| closest to zero over the box: the end value nearer to zero, 0 when the ends differ in sign
-          const float R = fabsf(__builtin_amdgcn_fmed3f(ui_lo, ui_hi, 0.f)) + fabsf(__builtin_amdgcn_fmed3f(uj_lo, uj_hi, 0.f));
-          const float Q = fminf(R, delta2);
-          const float T = Q * fmaf(-0.5f, Q, R);
-          lb = out_all ? fmaf(T, 0.5f, lb) : lb;
+          box_term(v.x, v.y, alo, ahi, zlo, zhi, Wh, Hh, delta2, lb);
         }
         lb += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(lb), 0xB1 /*quad_perm [1,0,3,2]*/, 0xf, 0xf, false));
         if (half == 0 && q < n_tiles && lb * kBoxSafety > lim_box) atomicOr(&s_dead[q >> 5], 1u << (q & 31));
@@ -903,6 +911,17 @@ __global__ void k6_isa_probe(const float* __restrict__ pts, float ay, float az, 
   out[2 * threadIdx.x] = A0;
   out[2 * threadIdx.x + 1] = A1;
 }
+template <int N>
+__global__ void k6_isa_probe_box(const float* __restrict__ pts, float alo, float ahi, float zlo, float zhi, float Wh, float Hh, float delta,
+                                 float* out) {
+  float lb = 0.f;
+  const float t = (float)threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < N; ++k) box_term(pts[2 * k], pts[2 * k + 1], alo + t, ahi + t, zlo - t, zhi - t, Wh, Hh, delta, lb);
+  out[threadIdx.x] = lb;
+}
+template __global__ void k6_isa_probe_box<1>(const float*, float, float, float, float, float, float, float, float*);
+template __global__ void k6_isa_probe_box<3>(const float*, float, float, float, float, float, float, float, float*);
 template __global__ void k6_isa_probe<1, true>(const float*, float, float, float, float, float, float*);
 template __global__ void k6_isa_probe<3, true>(const float*, float, float, float, float, float, float*);
 template __global__ void k6_isa_probe<1, false>(const float*, float, float, float, float, float, float*);

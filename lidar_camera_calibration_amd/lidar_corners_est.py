@@ -351,6 +351,17 @@ class LidarCornersBatch:
         self._lib.ilcc_fetch_labelled(self._h, frame, N.fptr(yz), lab.ctypes.data_as(C.POINTER(C.c_uint8)), n)
         return yz[:n], lab[:n]
 
+    def fetch_walk(self, frame: int):
+        """The frame's labelled points in the grid search's walk layout: (yz, label, n_interior, n_rim)."""
+        counts = (C.c_uint32 * 2)()
+        n = self._lib.ilcc_fetch_walk(self._h, frame, None, None, 0, counts)
+        if n < 0:
+            raise IlccError(-n)
+        yz = np.zeros((max(n, 1), 2), dtype=np.float32)
+        lab = np.zeros(max(n, 1), dtype=np.uint8)
+        self._lib.ilcc_fetch_walk(self._h, frame, N.fptr(yz), lab.ctypes.data_as(C.POINTER(C.c_uint8)), n, counts)
+        return yz[:n], lab[:n], int(counts[0]), int(counts[1])
+
     def grid_cost(self, yz: np.ndarray, label: np.ndarray, use_oob: bool = True, want_volume: bool = False):
         yz = np.ascontiguousarray(yz, dtype=np.float32).reshape(-1, 2)
         label = np.ascontiguousarray(label, dtype=np.uint8)

@@ -172,6 +172,68 @@ def _rand_points(rng, m):
     return yz, lab
 
 
+def _walk_stride(m):
+    """csrc/ilcc_internal.h walk_stride(): ~0.618 M, odd, coprime to M"""
+    import math
+    if m <= 2:
+        return 1
+    s = int(np.float32(m) * np.float32(0.6180339)) | 1
+    while math.gcd(s, m) != 1:
+        s += 2
+    return 1 if s >= m else s
+
+
+def test_walk_layout_is_a_class_partition_of_the_golden_walk(est, frames):
+    """K5w (the grid search's point order, written once per frame): the walk layout must be a permutation of the labelled
+    points; every part keeps golden-ratio walk order; interior-class points are in the board under EVERY rotation and
+    translation of the grid (accumulate_interior's precondition -- the property the exactness of the fast term rests on),
+    every other point leaves it somewhere (or comes within float rounding of doing so)."""
+    clouds, clicks, _ = frames
+    p = _set_solver(est, N.SOLVER_GRID)
+    res = est.extract(clouds, clicks)
+    g, W, H = p.grid_length, p.board_w, p.board_h
+    th = p.th_min + np.arange(p.n_th) * p.th_step
+    ay = np.array([(p.ty_min + a * p.ty_step + W * g / 2) / g for a in (0, p.n_ty - 1)])
+    az = np.array([(p.tz_min + b * p.tz_step + H * g / 2) / g for b in (0, p.n_tz - 1)])
+    checked = 0
+    for f in range(len(clouds)):
+        if res[f].status not in (0, 11):
+            continue
+        yz, lab = est.fetch_labelled(f)
+        wyz, wlab, n_in, n_rim = est.fetch_walk(f)
+        M = len(yz)
+        assert len(wyz) == M and 0 <= n_in <= M and n_in + n_rim <= M
+        # permutation (points may repeat: compare as sorted records)
+        rec = lambda a, l: np.sort(np.rec.fromarrays([a[:, 0], a[:, 1], l]), order=["f0", "f1", "f2"])
+        assert np.array_equal(rec(yz, lab), rec(wyz, wlab))
+        # every part in walk order: map each layout entry back to its walk slot and require increasing slots per part
+        S = _walk_stride(M)
+        slot_of = {}
+        for sl in range(M):
+            i = (sl * S) % M
+            slot_of.setdefault((yz[i, 0].tobytes(), yz[i, 1].tobytes(), int(lab[i])), []).append(sl)
+        for lo, hi in ((0, n_in), (n_in, n_in + n_rim), (n_in + n_rim, M)):
+            last = -1
+            for k in range(lo, hi):
+                cands = slot_of[(wyz[k, 0].tobytes(), wyz[k, 1].tobytes(), int(wlab[k]))]
+                nxt = [c for c in cands if c > last]
+                assert nxt, "part [%d, %d) of frame %d leaves walk order at %d" % (lo, hi, f, k)
+                last = min(nxt)
+        # class property, in double (the kernel decides in fp32: allow a rounding margin on the border side only)
+        y, z = wyz[:, 0].astype(np.float64), wyz[:, 1].astype(np.float64)
+        worst = np.full(M, -np.inf)
+        for t in th:
+            pi, pj = (np.cos(t) * y - np.sin(t) * z) / g, (np.sin(t) * y + np.cos(t) * z) / g
+            for a in ay:
+                worst = np.maximum(worst, np.abs(pi + a - W / 2) - W / 2)
+            for b in az:
+                worst = np.maximum(worst, np.abs(pj + b - H / 2) - H / 2)
+        assert (worst[:n_in] < 1e-5).all(), "an interior-class point can leave the board"
+        assert (worst[n_in:] > -1e-5).all(), "a point that never leaves the board is in the border class"
+        checked += 1
+    assert checked >= 12
+
+
 @pytest.mark.parametrize("m", [0, 1, 63, 64, 65, 1000, 2500])
 @pytest.mark.parametrize("use_oob", [1, 0])
 def test_grid_cost_volume_matches_oracle(ob, est, m, use_oob):
@@ -450,6 +512,40 @@ def test_branch_and_bound_does_not_change_the_result(ob, frames):
         bi, bc, _ = e.grid_cost(yz, lab, 1, want_volume=False)            # branch-and-bound variant
         oflat, oc, ovol = ob.grid_search(yz[:, 0], yz[:, 1], lab.astype(np.int8), op, 1, want_volume=True)
         assert ovol[bi] <= oc * (1 + 2e-5) + 2e-6 and bc == pytest.approx(ovol[bi], rel=2e-5, abs=2e-6)
+    e.close()
+
+
+@pytest.mark.parametrize("grid", [dict(n_th=21, th_step=1.5 * np.pi / 180, n_ty=37, n_tz=39, t_step=0.0081),   # partial tiles on both axes
+                                  dict(n_th=13, th_step=2.5 * np.pi / 180, n_ty=8, n_tz=8, t_step=0.046),      # 3 steps >= 0.9 squares: no box pre-pass
+                                  dict(n_th=31, th_step=1.0 * np.pi / 180, n_ty=80, n_tz=76, t_step=0.004)])   # narrow boxes, 20 x 19 tiles
+def test_box_prepass_on_other_grids_matches_the_oracle(ob, frames, grid):
+    """The full pass's box pre-pass (a lower bound per 4 x 4 tile from the out-of-board cost at the tile's extreme
+    translations) must never drop the argmin or a near tie: GRID-mode results on grids with partial tiles, with boxes too
+    wide for the pre-pass (the host switches it off) and with many narrow tiles are the oracle's, bit for bit."""
+    clouds, clicks, _ = frames
+    p, op = N.default_params(), ob.default_params()
+    op.solver = ob.SOLVER_GRID
+    for q in (p, op):
+        q.n_th, q.n_ty, q.n_tz = grid["n_th"], grid["n_ty"], grid["n_tz"]
+        q.th_step = grid["th_step"]
+        q.th_min = -0.5 * (grid["n_th"] - 1) * grid["th_step"]
+        q.ty_step = q.tz_step = grid["t_step"]
+        q.ty_min = -0.5 * (grid["n_ty"] - 1) * grid["t_step"]
+        q.tz_min = -0.5 * (grid["n_tz"] - 1) * grid["t_step"]
+    e = LidarCornersBatch(16, 28800, p)
+    res = e.extract(clouds, clicks)
+    tm = e.timing()
+    wide = 3.0 * grid["t_step"] >= 0.9 * p.grid_length
+    assert (tm.grid_cost_box_evals_sum == 0) == wide
+    n = 0
+    for f in range(len(clouds)):
+        ref = ob.extract(clouds[f], clicks[f], op)
+        assert res[f].status == ref.status
+        if ref.status in (0, 11):
+            assert res[f].grid_index == ref.grid_index
+            assert tuple(res[f].theta_t) == tuple(ref.theta_t) and res[f].sel_cost == ref.sel_cost
+            n += 1
+    assert n >= 12
     e.close()
 
 

@@ -115,11 +115,13 @@ def test_k6_credit_matches_the_isa():
     src = open(os.path.join(root, "bench.py")).read()
     border = float(re.search(r"^K6_VALU_OPS_BORDER = ([0-9.]+)", src, re.M).group(1))
     interior = float(re.search(r"^K6_VALU_OPS_INTERIOR = ([0-9.]+)", src, re.M).group(1))
-    assert (border, interior) == (committed["border_valu_per_eval"], committed["interior_valu_per_eval"])
+    box = float(re.search(r"^K6_VALU_OPS_BOX = ([0-9.]+)", src, re.M).group(1))
+    assert (border, interior, box) == (committed["border_valu_per_eval"], committed["interior_valu_per_eval"],
+                                       committed["box_valu_per_tile_eval"])
     if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
         pytest.skip("no hipcc")
     fresh = json.loads(subprocess.check_output([os.path.join(root, "tools", "k6_isa_count.sh")], text=True))
-    assert (fresh["border_valu_per_eval"], fresh["interior_valu_per_eval"]) == (border, interior), fresh
+    assert (fresh["border_valu_per_eval"], fresh["interior_valu_per_eval"], fresh["box_valu_per_tile_eval"]) == (border, interior, box), fresh
 
 
 def test_defaults_agree_with_the_oracle(ob):
