@@ -3,9 +3,9 @@
 
 A "step" is one pass of the whole hot path (K1 crop -> K2 cluster -> K3 RANSAC plane -> K4/K5 plane frame + gray
 zone -> K6 exhaustive (theta,ty,tz) x phase grid cost -> K7r monotone refinement + basin check -> K7b corners) over
-configs[3]'s 1024 synthetic frames PER GPU, fed as 4 DISTINCT batches of 256 frames (configs[1] frames: 16 rings x
+configs[3]'s 1024 synthetic frames PER GPU, fed as 2 DISTINCT batches of 512 frames (configs[1] frames: 16 rings x
 1800 azimuths = 28 800 XYZI points, 7x5-corner board @0.15 m, one random board pose per frame) through the
-library's submit/wait pipeline (up to 4 batches in flight).  The 4 batches are 472 MB of distinct input per GPU --
+library's submit/wait pipeline (up to 4 batches in flight).  The 2 batches are 472 MB of distinct input per GPU --
 more than the 256 MB Infinity Cache -- so K1 reads HBM, not cache.  Inputs are resident in HBM when the timed region
 starts (the bench contract); the same pipeline with every batch starting in pinned HOST memory is timed right
 after and reported as `value_h2d_inclusive` (SURVEY.md 8d counts that copy).  Per-frame result records come back
@@ -66,7 +66,7 @@ K6_VALU_OPS_INTERIOR = 15.0
 K6_VALU_OPS_BOX = 24.0
 # PMC passes of the K6 stage at the batch sizes this bench runs (tools/gpu_pmc.sh -> profiles/): per-launch counters of one
 # batch alone on the chip.  roofline.traffic and roofline.issued_vs_credited are computed from these files at run time.
-PMC_FILES = {(2, 256): "profiles/r03_pmc_cfg2_256f.csv", (5, 64): "profiles/r03_pmc_cfg5_64f.csv"}
+PMC_FILES = {(2, 512): "profiles/r03_pmc_cfg2_512f.csv", (5, 64): "profiles/r03_pmc_cfg5_64f.csv"}
 
 
 def k6_pmc(config, frames_per_batch):
@@ -118,8 +118,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", type=int, default=2, choices=(2, 5),
                     help="2: BASELINE configs[1] frames (the headline); 5: configs[4], the dense-cloud fine-grid run")
-    ap.add_argument("--frames-per-batch", type=int, default=0, help="default 256 (config 2) / 64 (config 5)")
-    ap.add_argument("--batches-per-step", type=int, default=0, help="distinct batches per step and GPU: default 4 (config 2) / 2 (config 5)")
+    ap.add_argument("--frames-per-batch", type=int, default=0, help="default 512 (config 2) / 64 (config 5)")
+    ap.add_argument("--batches-per-step", type=int, default=0, help="distinct batches per step and GPU: default 2 (config 2) / 2 (config 5)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline time budget (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the H2D-inclusive / reference-mode legs (profiling runs)")
@@ -134,9 +134,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # batch size measured on one MI355X (1024 frames per step either way): 128: 249 k, 192: 266 k, 256: 275 k, 320: 273 k,
     # 384: 269 k, 512: 273 k, 1024: 269 k frames/s (config 5: 16: 2.87 k, 32: 3.30 k, 64: 3.54 k) -- 128 per-frame
-    # workgroups fill only half of the 256 CUs
-    F = args.frames_per_batch or (256 if args.config == 2 else 64)
-    B = max(1, args.batches_per_step or (4 if args.config == 2 else 2))
+    # workgroups fill only half of the 256 CUs.  Measured again once the grid search had its box pre-pass (round 3, the path no
+    # longer VALU-saturated): 128 x 8: 405 k, 192 x 6: 487 k, 256 x 4: 542 k, 384 x 4: 559 k, 512 x 2: 571 k, 1024 x 1: 577 k
+    # frames/s -- 512 x 2 (four batches = 2048 frames in flight) is the default
+    F = args.frames_per_batch or (512 if args.config == 2 else 64)
+    B = max(1, args.batches_per_step or 2)
     FS = F * B                                        # frames per step and GPU
 
     # synthetic inputs first (forked workers; nothing has touched the HIP runtime yet).  Weak scaling: every rank

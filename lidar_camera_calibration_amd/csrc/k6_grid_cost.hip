@@ -67,6 +67,9 @@ constexpr int kSlices = 4;        // lanes (one quad) sharing a candidate, each 
 constexpr int kUnroll = ILCC_K6_UNROLL;        // points per lane and block (round 1, one class of points: 2: 179 k, 3: 181 k, 4: 178 k, 6: 167 k
                                                // frames/s; round 2, two classes, test after every border block only: 2: 245.6 k, 3: 238 k, 4: 227 k)
 constexpr int kStep = kSlices * kUnroll;
+#ifndef ILCC_BOX_SHIFT
+#define ILCC_BOX_SHIFT 5   // box pre-pass: at least 1/32 of the frame's labelled points per tile (and at least Ctx::box_points)
+#endif
 constexpr int kBoxTilesMax = 4096;                 // box pre-pass: tiles per workgroup its LDS bit mask holds
 constexpr float kBoxSafety = 1.f - 0x1p-12f;
 constexpr int kBoundRefresh = ILCC_K6_BOUND_REFRESH; // points between reloads of the frame's shared bound
@@ -311,7 +314,7 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
     if (use_box) {
       for (int w = threadIdx.x; w < (n_tiles + 31) / 32; w += THREADS) s_dead[w] = 0u;
       __syncthreads();
-      const uint32_t n_pre = min(c.box_points, M - Mi);
+      const uint32_t n_pre = min(max(c.box_points, Mfull >> ILCC_BOX_SHIFT), M - Mi);   // the frame's bound grows with its point count: so must the sample that has to exceed it
       const float lim_box = 0.5f * (1.f + kTieEps) * __uint_as_float(gb_bits);
       const int half = (int)(threadIdx.x & 1u);
       for (int q0 = 0; q0 < n_tiles; q0 += THREADS / 2) {
@@ -700,7 +703,7 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
     }
     atomicAdd(c.grid_iters + (f & (kIterSlots - 1)), (unsigned long long)it_sum);   // spread over 64 words
     atomicAdd(c.grid_iters + kIterSlots + (f & (kIterSlots - 1)), (unsigned long long)in_sum);
-    if (use_box) atomicAdd(c.grid_iters + 2 * kIterSlots + (f & (kIterSlots - 1)), (unsigned long long)n_tiles * min(c.box_points, M - Mi));
+    if (use_box) atomicAdd(c.grid_iters + 2 * kIterSlots + (f & (kIterSlots - 1)), (unsigned long long)n_tiles * min(max(c.box_points, Mfull >> ILCC_BOX_SHIFT), M - Mi));
     Best b = s_best[0];
     for (int w = 1; w < THREADS / ILCC_WAVE; ++w)
       if (better(s_best[w].cost, s_best[w].d2, s_best[w].flat, b)) b = s_best[w];

@@ -2,7 +2,7 @@
 #   - un-contended single-batch timeline (HIP events), both solver modes
 #   - rocprofv3 --kernel-trace --stats of the default bench, timed pipeline only (4 batches in flight) -> <TAG>_kernel_stats_bench_20_5.csv
 #   - the same with --in-flight 1 (one batch alone on the chip: clean per-kernel durations) -> <TAG>_kernel_stats_bench_inflight1.csv
-#   - with `pmc`: PMC passes at the batch sizes the bench runs (tools/gpu_pmc.sh: config 2 / 256 frames, config 5 / 64 frames)
+#   - with `pmc`: PMC passes at the batch sizes the bench runs (tools/gpu_pmc.sh: config 2 / 512 frames, config 5 / 64 frames)
 TAG=${1:-r03}
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out
@@ -19,6 +19,6 @@ import json; d=json.load(open('$R/gpurun_out/prof_${TAG}_bench_$N.json')); print
 done
 cd $R
 if [ "$2" = "pmc" ]; then
-  tools/gpu_pmc.sh $TAG 256 2 | tail -14 | cut -c1-220
+  tools/gpu_pmc.sh $TAG 512 2 | tail -14 | cut -c1-220
   tools/gpu_pmc.sh $TAG 64 5 | tail -16 | cut -c1-220
 fi

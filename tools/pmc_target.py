@@ -1,6 +1,6 @@
 """Light target for rocprofv3 --pmc / --kernel-trace passes: three synchronous batches (GRID mode), one batch alone on
 the chip each time -- per-dispatch counters of every kernel of the path without bench.py's other legs.
-usage: pmc_target.py [frames_per_batch=256] [config=2|5]      (the batch sizes bench.py runs: 256 / 64)"""
+usage: pmc_target.py [frames_per_batch=512] [config=2|5]      (the batch sizes bench.py runs: 512 / 64)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -8,7 +8,7 @@ import torch
 from lidar_camera_calibration_amd import LidarCornersBatch, synth
 from lidar_camera_calibration_amd import _native as N
 config = int(sys.argv[2]) if len(sys.argv) > 2 else 2
-F = int(sys.argv[1]) if len(sys.argv) > 1 else (256 if config == 2 else 64)
+F = int(sys.argv[1]) if len(sys.argv) > 1 else (512 if config == 2 else 64)
 params = N.default_params()
 if config == 5:      # BASELINE configs[4], as bench.py --config 5 sets it up
     lidar = synth.hdl64()
