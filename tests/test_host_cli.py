@@ -199,7 +199,7 @@ def test_bench_multi_rank_path_with_one_rccl_rank():
     step on a side stream, rank 0 verifying tags + content checks of what arrived -- forced with a single rank, so that
     RCCL itself is exercised on the 1-GPU box."""
     out = _bench({"ILCC_BENCH_FORCE_DIST": "1", "MASTER_PORT": "29611"},
-                 ["--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-extra-legs", "--batches-per-step", "2"])
+                 ["--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-extra-legs", "--batches-per-step", "2", "--frames-per-batch", "256"])
     assert out["n_gpus"] == 1 and out["steps"] == 3 and out["value"] > 1000
     assert out["config"]["frames_per_step_per_gpu"] == 512
 
