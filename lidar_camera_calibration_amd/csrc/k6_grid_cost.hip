@@ -12,8 +12,10 @@
 // colour phases).  The branch-and-bound test therefore needs only a quad reduction -- four DPP adds --
 // and runs every 8 positions of the walk (2 points per lane): a tile stops the moment each of its candidates is provably
 // beaten.  The walk starts with the border-class points closest to the board's outline (rim), then the other border-class
-// points, then the interior-class ones (see the staging): 86 % of the tiles are dropped at their first test, and that
-// first block lives in registers (DESIGN.md section 4 has the measurements behind every one of these choices).
+// points, then the interior-class ones -- the layout k5w_walk_order (end of this file) writes once per frame.  Before any
+// tile is started, the full pass runs a BOX PRE-PASS: a lower bound for all 16 candidates of a tile from the out-of-board
+// cost of 32 rim points at the tile's extreme translations (box_term); 93-99 % of the tiles are never started.  The first
+// block of the walk lives in registers (DESIGN.md section 4 has the measurements behind every one of these choices).
 // History of this mapping, measured on the 128-frame batch:
 //  * lanes = points, 4 x 4 candidates in registers (round-1 first design): 14.5 VALU per evaluation
 //    thanks to separable i/j terms, but every test needed a ~130-instruction transposed reduction over
