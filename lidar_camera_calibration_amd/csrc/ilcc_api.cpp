@@ -549,7 +549,10 @@ int32_t enqueue_impl(ilcc_handle* h, int si, const float4* d_xyzi, const uint64_
 #ifndef ILCC_ANCHOR_RADIUS
 #define ILCC_ANCHOR_RADIUS 1
 #endif
-        anchor.refine_window = 1;
+#ifndef ILCC_ANCHOR_WINDOW
+#define ILCC_ANCHOR_WINDOW 2   // 1: 8 x 8 translations per theta, 2: one 4 x 4 tile around the refinement's argmin (measured: 575 k vs 586 k frames/s; with 1 theta: 581 k)
+#endif
+        anchor.refine_window = ILCC_ANCHOR_WINDOW;
         anchor.refine_radius_th = ILCC_ANCHOR_RADIUS;
         anchor.grid_blocks = 2 * ILCC_ANCHOR_RADIUS + 1;
         anchor.partial = sl.d_partial4;

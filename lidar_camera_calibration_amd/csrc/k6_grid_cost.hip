@@ -241,10 +241,17 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
         // full pass starts, which is what lets the full pass cut almost every tile after 8 points
         const int kc = c.seed_off_th + k2 * c.seed_stride_th + (int)blockIdx.x - c.refine_radius_th;
         k = (uint32_t)__builtin_amdgcn_readfirstlane(min(max(kc, 0), c.p.n_th - 1));
-        a_org = __builtin_amdgcn_readfirstlane(min(max(sa - kTile, 0), max(n_ty - 2 * kTile, 0)));
-        b_org = __builtin_amdgcn_readfirstlane(min(max(sbb - kTile, 0), max(n_tz - 2 * kTile, 0)));
-        nta = min(2, nta);
-        ntb = min(2, ntb);
+        if (c.refine_window == 1) {        // 8 x 8 translations around the argmin
+          a_org = __builtin_amdgcn_readfirstlane(min(max(sa - kTile, 0), max(n_ty - 2 * kTile, 0)));
+          b_org = __builtin_amdgcn_readfirstlane(min(max(sbb - kTile, 0), max(n_tz - 2 * kTile, 0)));
+          nta = min(2, nta);
+          ntb = min(2, ntb);
+        } else {                           // one tile: the argmin, one step below and two above it on both axes
+          a_org = __builtin_amdgcn_readfirstlane(min(max(sa - 1, 0), max(n_ty - kTile, 0)));
+          b_org = __builtin_amdgcn_readfirstlane(min(max(sbb - 1, 0), max(n_tz - kTile, 0)));
+          nta = 1;
+          ntb = 1;
+        }
       } else {
         // full pass: start at the tile that holds the seed's best translation; the order never changes the result
         t0 = __builtin_amdgcn_readfirstlane((sa / kTile) * ntb + (sbb / kTile));
