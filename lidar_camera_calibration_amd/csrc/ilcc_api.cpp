@@ -586,7 +586,7 @@ int32_t enqueue_impl(ilcc_handle* h, int si, const float4* d_xyzi, const uint64_
     HIP_TRY(h, hipEventRecord(sl.ev[8], s));
     full.tie_count = sl.d_tie_count;
 #ifndef ILCC_BOX_POINTS
-#define ILCC_BOX_POINTS 32
+#define ILCC_BOX_POINTS 48   // 16: 461 k, 32: 485 k, 48: 487 k, 64: 484 k, 96: 474 k frames/s when it was introduced; with the one-tile anchor 32: 578 k, 48: 590 k
 #endif
     // box pre-pass (k6_grid_cost.hip): its monotonicity argument needs a tile's box narrower than one square on both axes
     full.box_points = (prune && 3.0 * h->p.ty_step < 0.9 * h->p.grid_length && 3.0 * h->p.tz_step < 0.9 * h->p.grid_length) ? (uint32_t)ILCC_BOX_POINTS : 0u;
