@@ -107,6 +107,9 @@ __global__ __launch_bounds__(kPlaneThreadsSmallBatch) void k3_ransac_plane(Ctx c
       const uint32_t i = base + lane;
       const bool in = (i < M) && plane_dist(pl, P[i]) < thr;
       cnt += (uint32_t)__popcll(__ballot(in));
+      // exact early exit: even if every point still to come were an inlier, this hypothesis could not beat (>) the best one
+      // this wavefront has already counted in full (wave-uniform: a scalar branch)
+      if (cnt + (M - min(M, base + (uint32_t)ILCC_WAVE)) <= best_cnt) break;
     }
     if (cnt > best_cnt) {   // h ascending within a wavefront: ties keep the lowest h
       best_cnt = cnt;
