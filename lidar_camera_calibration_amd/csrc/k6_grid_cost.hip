@@ -780,10 +780,11 @@ __global__ __launch_bounds__(THREADS) void k6_grid_cost(Ctx c, float* volume) {
 // K5w walk order: the frame's labelled points in the layout k6_grid_cost stages -- [interior | rim | other border], each part
 // in golden-ratio walk order -- written ONCE per frame (round 3 until here: every one of a frame's ~80 K6 workgroups
 // classified and partitioned the points again, 20 % of the full pass's VALU instructions).
-//   interior: in the board under every rotation of the theta table and every translation of the (ty, tz) tables, decided
-//             with accumulate<>'s own fp32 expressions at the four extreme translations (|i - W/2| - W/2 is V-shaped in i and
-//             every operation is monotone, so the extremes decide for all values in between; the decimated tables of the
-//             seed launch are subsets of the full ones) -> accumulate_interior is exact for these points in every launch;
+//   interior: in the board under every rotation of the theta table and every translation of the (ty, tz) tables -- decided
+//             by a bound, not by trying the 61 rotations (that loop was 10 M of the path's 386 M instructions per 512 frames
+//             and found 7 % more points): |i| <= |y| max|cos| + |z| max|sin|, with a margin far above fp32 rounding; the
+//             decimated tables of the seed launch are subsets of the full ones -> accumulate_interior is exact for these
+//             points in every launch;
 //   rim:      border-class and within ILCC_K6_RIM thousandths of a square of the outline at the grid's centre candidate:
 //             walked first, they are the points that leave the board when the translation is wrong (ordering only).
 #ifndef ILCC_K6_RIM
@@ -817,20 +818,23 @@ __global__ __launch_bounds__(kWalkThreads) void k5w_walk_order(Ctx c) {
   const float ay_c = c.ay[c.c_ty], az_c = c.az[c.c_tz];
   const float rim_thr = -(float)ILCC_K6_RIM * 1e-3f;
   const int n_th = c.p.n_th;
+  float cmax = 0.f, smax = 0.f;   // (uniform: the tables are a few dozen values)
+  for (int k = 0; k < n_th; ++k) {
+    cmax = fmaxf(cmax, fabsf(c.cth[k]));
+    smax = fmaxf(smax, fabsf(c.sth[k]));
+  }
+  const float room_i = fminf(fminf(ay_lo, ay_hi), 2.f * Wh - fmaxf(ay_lo, ay_hi)), room_j = fminf(fminf(az_lo, az_hi), 2.f * Hh - fmaxf(az_lo, az_hi));
   // class of every walk slot: 0 interior, 1 other border, 2 rim
   uint32_t cnt_in = 0, cnt_rim = 0;
   for (uint32_t sl = threadIdx.x; sl < M; sl += kWalkThreads) {
     const float2 v = gyz[(uint32_t)(((uint64_t)sl * S) % M)];
-    float worst = -__builtin_inff();
-    for (int k = 0; k < n_th; ++k) {
-      const float cth = c.cth[k], sth = c.sth[k];
-      const float pi = fmaf(-sth, v.y, cth * v.x), pj = fmaf(cth, v.y, sth * v.x);
-      const float u0 = fabsf((pi + ay_lo) - Wh) - Wh, u1 = fabsf((pi + ay_hi) - Wh) - Wh;
-      const float w0 = fabsf((pj + az_lo) - Hh) - Hh, w1 = fabsf((pj + az_hi) - Hh) - Hh;
-      worst = fmaxf(worst, fmaxf(fmaxf(u0, u1), fmaxf(w0, w1)));
-    }
+    // |i| <= |y| max|cos/g| + |z| max|sin/g| for every theta of the table (and likewise |j|): inside the room the translations
+    // leave on both axes, with 1e-4 square to spare, the point is in the board for every candidate -- fp32 rounding of the
+    // term's own expressions (a few 1e-7 on coordinates of a few squares) included
+    const float bi = fmaf(fabsf(v.y), smax, fabsf(v.x) * cmax), bj = fmaf(fabsf(v.y), cmax, fabsf(v.x) * smax);
+    const bool inside_always = bi + 1e-4f < room_i && bj + 1e-4f < room_j;
     int cl = 0;
-    if (!(worst < 0.f) || !ILCC_K6_SPLIT) {
+    if (!inside_always || !ILCC_K6_SPLIT) {
       const float cth = c.cth[c.c_th], sth = c.sth[c.c_th];
       const float pi = fmaf(-sth, v.y, cth * v.x), pj = fmaf(cth, v.y, sth * v.x);
       const float uc = fabsf((pi + ay_c) - Wh) - Wh, wc = fabsf((pj + az_c) - Hh) - Hh;

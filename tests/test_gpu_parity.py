@@ -186,8 +186,8 @@ def _walk_stride(m):
 def test_walk_layout_is_a_class_partition_of_the_golden_walk(est, frames):
     """K5w (the grid search's point order, written once per frame): the walk layout must be a permutation of the labelled
     points; every part keeps golden-ratio walk order; interior-class points are in the board under EVERY rotation and
-    translation of the grid (accumulate_interior's precondition -- the property the exactness of the fast term rests on),
-    every other point leaves it somewhere (or comes within float rounding of doing so)."""
+    translation of the grid (accumulate_interior's precondition -- the property the exactness of the fast term rests on);
+    of the other points at most a tenth never leave it (the class is decided by a conservative bound)."""
     clouds, clicks, _ = frames
     p = _set_solver(est, N.SOLVER_GRID)
     res = est.extract(clouds, clicks)
@@ -228,8 +228,10 @@ def test_walk_layout_is_a_class_partition_of_the_golden_walk(est, frames):
                 worst = np.maximum(worst, np.abs(pi + a - W / 2) - W / 2)
             for b in az:
                 worst = np.maximum(worst, np.abs(pj + b - H / 2) - H / 2)
-        assert (worst[:n_in] < 1e-5).all(), "an interior-class point can leave the board"
-        assert (worst[n_in:] > -1e-5).all(), "a point that never leaves the board is in the border class"
+        assert (worst[:n_in] < 0).all(), "an interior-class point can leave the board"
+        # (the class is decided by a bound on |i|, |j| over the rotations: a few per cent of the points that never leave
+        # the board stay in the border class, which is always safe -- but not many)
+        assert (worst[n_in:] < -1e-3).sum() <= 0.1 * M + 8
         checked += 1
     assert checked >= 12
 
