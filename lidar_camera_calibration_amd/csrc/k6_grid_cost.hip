@@ -354,24 +354,6 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
   const int my_s = lane & (kSlices - 1), my_c = lane >> 2;
   const int my_a = my_c >> 2, my_b = my_c & 3;
 
-  // tiles wid, wid+4, ... of the rotated order, tracked as (row, column): no division per tile
-  // (wave-uniform values, pinned to scalar registers: the walk then costs SALU slots, not VALU slots)
-  int t_first = wid + t0;
-  if (t_first >= n_tiles) t_first -= n_tiles;
-  int ta = __builtin_amdgcn_readfirstlane(t_first / ntb);
-  int tb = __builtin_amdgcn_readfirstlane(t_first - ta * ntb);
-  const int ntb_s = __builtin_amdgcn_readfirstlane(ntb), nta_s = __builtin_amdgcn_readfirstlane(nta);
-  auto advance = [&]() {   // to this wavefront's next tile
-    tb += THREADS / ILCC_WAVE;
-    while (tb >= ntb_s) {
-      tb -= ntb_s;
-      ++ta;
-    }
-    if (ta >= nta_s) ta -= nta_s;
-    ta = __builtin_amdgcn_readfirstlane(ta);
-    tb = __builtin_amdgcn_readfirstlane(tb);
-  };
-
   // first block of each class in registers (see run_tile); needs a full block of both classes
 #ifndef ILCC_K6_FIRST_IN
 #define ILCC_K6_FIRST_IN 0   // interior- / border-class points per lane in the first (register-resident) block
@@ -655,37 +637,52 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
   // only the surviving tiles into the quad-sliced loop.  An instruction-count model from simulated death times promised
   // -12 %; on the chip: 85 instead of 72 VGPRs (5 instead of 7 waves per SIMD) and sixteen serial evaluations per lane:
   // 0.611 instead of 0.564 ms per batch, 235 k instead of 250.6 k frames/s.)
-  for (int tt = wid; tt < n_tiles; tt += THREADS / ILCC_WAVE) {
-    const int tile_a = ta, tile_b = tb;
-    advance();
-    if (use_box) {
-      const int q = tile_a * ntb + tile_b;
-      if ((__builtin_amdgcn_readfirstlane((int)s_dead[q >> 5]) >> (q & 31)) & 1) continue;
+  // This wavefront's tiles are wid, wid + 4, ... of the order rotated by t0 (the tile of the seed's best translation first).
+  // 64 of them at a time, one per lane: the lanes look their tiles up in the pre-pass's bit mask, a ballot gives the ones
+  // still alive, and only those are visited (a handful of a wavefront's 25: the loop over dead tiles was a third of the
+  // kernel's scalar instructions).
+  constexpr int kWaves = THREADS / ILCC_WAVE;
+  const int per_wave = __builtin_amdgcn_readfirstlane(wid < n_tiles ? (n_tiles - wid + kWaves - 1) / kWaves : 0);
+  const int ntb_s = __builtin_amdgcn_readfirstlane(ntb);
+  for (int k0 = 0; k0 < per_wave; k0 += ILCC_WAVE) {
+    bool alive = false;
+    if (k0 + lane < per_wave) {
+      int q = wid + kWaves * (k0 + lane) + t0;
+      if (q >= n_tiles) q -= n_tiles;
+      alive = !use_box || !((s_dead[q >> 5] >> (q & 31)) & 1u);
     }
+    unsigned long long todo = __ballot(alive);
+    while (todo) {
+      const int bit = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(todo));
+      todo &= todo - 1ull;
+      int qs = wid + kWaves * (k0 + bit) + t0;
+      if (qs >= n_tiles) qs -= n_tiles;
+      const int tile_a = __builtin_amdgcn_readfirstlane(qs / ntb_s), tile_b = __builtin_amdgcn_readfirstlane(qs - tile_a * ntb_s);
 #ifdef ILCC_K6_TIMING
-    const unsigned long long tt0 = K6_NOW();
-    const uint32_t pd0 = pts_done;
-    const float bc0 = best.cost;
-    const uint32_t bf0 = best.flat;
+      const unsigned long long tt0 = K6_NOW();
+      const uint32_t pd0 = pts_done;
+      const float bc0 = best.cost;
+      const uint32_t bf0 = best.flat;
 #endif
-    run_tile(tile_a, tile_b, 0.f, 0.f, 0u, Mi);
+      run_tile(tile_a, tile_b, 0.f, 0.f, 0u, Mi);
 #ifdef ILCC_K6_TIMING
-    {
-      const unsigned long long dt = K6_NOW() - tt0;
-      const uint32_t walked = pts_done - pd0;
-      if (walked <= (uint32_t)(2 * kStep) && walked < M) {
-        ++n_rej;
-        t_rej += dt;
-      } else {
-        ++n_surv;
-        t_surv += dt;
-        p_surv += walked;
-        if (walked >= M) ++n_done;
+      {
+        const unsigned long long dt = K6_NOW() - tt0;
+        const uint32_t walked = pts_done - pd0;
+        if (walked <= (uint32_t)(2 * kStep) && walked < M) {
+          ++n_rej;
+          t_rej += dt;
+        } else {
+          ++n_surv;
+          t_surv += dt;
+          p_surv += walked;
+          if (walked >= M) ++n_done;
+        }
+        (void)bc0;
+        (void)bf0;
       }
-      (void)bc0;
-      (void)bf0;
-    }
 #endif
+    }
   }
   [[maybe_unused]] const unsigned long long t_tiles = K6_NOW();
 
