@@ -72,6 +72,10 @@ constexpr int kStep = kSlices * kUnroll;
 #ifndef ILCC_BOX_SHIFT
 #define ILCC_BOX_SHIFT 5   // box pre-pass: at least 1/32 of the frame's labelled points per tile (and at least Ctx::box_points)
 #endif
+#ifndef ILCC_BOX_CHECK
+#define ILCC_BOX_CHECK 4
+#endif
+constexpr int kBoxCheck = ILCC_BOX_CHECK;          // box pre-pass: points per lane between two looks at "is every tile of this wavefront beaten already"
 constexpr int kBoxTilesMax = 4096;                 // box pre-pass: tiles per workgroup its LDS bit mask holds
 constexpr float kBoxSafety = 1.f - 0x1p-12f;
 constexpr int kBoundRefresh = ILCC_K6_BOUND_REFRESH; // points between reloads of the frame's shared bound
@@ -318,6 +322,7 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
   // leave the board when the translation is wrong.  A tile whose bound already exceeds the frame's bound is never started.
   // kBoxSafety: the bound is a sum in another order than the candidates' own fp32 sums (<= 2^12 terms per lane).
   bool use_box = false;
+  unsigned long long box_evals = 0;   // (point, tile) evaluations of this workgroup's pre-pass
   if constexpr (PRUNE && LDS_POINTS && OOB) {
     use_box = c.box_points != 0u && n_tiles <= kBoxTilesMax && M > Mi;
     if (use_box) {
@@ -326,6 +331,7 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
       const uint32_t n_pre = min(max(c.box_points, Mfull >> ILCC_BOX_SHIFT), M - Mi);   // the frame's bound grows with its point count: so must the sample that has to exceed it
       const float lim_box = 0.5f * (1.f + kTieEps) * __uint_as_float(gb_bits);
       const int half = (int)(threadIdx.x & 1u);
+      uint32_t wave_evals = 0;   // (point, tile) evaluations this wavefront really did (wave-uniform)
       for (int q0 = 0; q0 < n_tiles; q0 += THREADS / 2) {
         const int q = q0 + (int)(threadIdx.x >> 1);
         const int qc = min(q, n_tiles - 1);
@@ -339,14 +345,28 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
           zlo = fminf(zlo, vz);
           zhi = fmaxf(zhi, vz);
         }
-        float lb = 0.f;
-        for (uint32_t u = (uint32_t)half; u < n_pre; u += 2u) {
-          const float2 v = s_ij[Mi + u];
-          box_term(v.x, v.y, alo, ahi, zlo, zhi, Wh, Hh, delta2, lb);
+        // (the sum only grows: a wavefront whose 32 tiles are all beaten already stops looking at further points -- most
+        // wavefronts, far from the minimum, after the first few)
+        float lb = 0.f, both = 0.f;
+        const uint32_t wave_tiles = (uint32_t)max(0, min(ILCC_WAVE / 2, n_tiles - (q0 + wid * (ILCC_WAVE / 2))));
+        for (uint32_t u0 = 0; u0 < n_pre; u0 += 2u * kBoxCheck) {
+          wave_evals += wave_tiles * min(2u * kBoxCheck, n_pre - u0);
+#pragma unroll
+          for (uint32_t d = 0; d < (uint32_t)kBoxCheck; ++d) {
+            const uint32_t u = u0 + 2u * d + (uint32_t)half;
+            if (u < n_pre) {
+              const float2 v = s_ij[Mi + u];
+              box_term(v.x, v.y, alo, ahi, zlo, zhi, Wh, Hh, delta2, lb);
+            }
+          }
+          both = lb + __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(lb), 0xB1 /*quad_perm [1,0,3,2]*/, 0xf, 0xf, false));
+          if (__ballot(q < n_tiles && !(both * kBoxSafety > lim_box)) == 0ull) break;
         }
-        lb += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(lb), 0xB1 /*quad_perm [1,0,3,2]*/, 0xf, 0xf, false));
-        if (half == 0 && q < n_tiles && lb * kBoxSafety > lim_box) atomicOr(&s_dead[q >> 5], 1u << (q & 31));
+        if (half == 0 && q < n_tiles && both * kBoxSafety > lim_box) atomicOr(&s_dead[q >> 5], 1u << (q & 31));
       }
+      if (lane == 0) s_iters[wid] = wave_evals;   // (s_iters is free until the epilogue)
+      __syncthreads();
+      for (int w = 0; w < THREADS / ILCC_WAVE; ++w) box_evals += s_iters[w];
       __syncthreads();
     }
   }
@@ -709,7 +729,7 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
     }
     atomicAdd(c.grid_iters + (f & (kIterSlots - 1)), (unsigned long long)it_sum);   // spread over 64 words
     atomicAdd(c.grid_iters + kIterSlots + (f & (kIterSlots - 1)), (unsigned long long)in_sum);
-    if (use_box) atomicAdd(c.grid_iters + 2 * kIterSlots + (f & (kIterSlots - 1)), (unsigned long long)n_tiles * min(max(c.box_points, Mfull >> ILCC_BOX_SHIFT), M - Mi));
+    if (use_box) atomicAdd(c.grid_iters + 2 * kIterSlots + (f & (kIterSlots - 1)), box_evals);
     Best b = s_best[0];
     for (int w = 1; w < THREADS / ILCC_WAVE; ++w)
       if (better(s_best[w].cost, s_best[w].d2, s_best[w].flat, b)) b = s_best[w];
