@@ -804,14 +804,14 @@ __device__ __forceinline__ int stencil_sweep(const Ctx& c, const Board& bd, cons
     // integer sums: any reduction order gives the same totals
 #pragma unroll
     for (int e = 0; e < 9; ++e) {
+      // within the 16-lane rows only (plain DPP); the four rows then add their totals to the LDS word themselves -- the two
+      // cross-row steps (permlane swaps and selects on both halves of a 64-bit value) cost more than three more atomics
       unsigned long long t = (unsigned long long)(long long)acc[e];
-      t += xor_lane_u64<32>(t);
-      t += xor_lane_u64<16>(t);
       t += xor_lane_u64<8>(t);
       t += xor_lane_u64<4>(t);
       t += xor_lane_u64<2>(t);
       t += xor_lane_u64<1>(t);
-      if (lane_id() == 0) atomicAdd(&sh.acc[buf][it * 9 + e], t);
+      if ((lane_id() & 15) == 0) atomicAdd(&sh.acc[buf][it * 9 + e], t);
     }
   }
   __syncthreads();
