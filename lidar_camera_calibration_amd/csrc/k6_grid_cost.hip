@@ -272,26 +272,33 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
   // A subsampled launch (walk_limit) stages a prefix of each part, in proportion.
   const uint32_t S = Mfull ? c.walk_stride[f] : 1u;   // (the walk through global memory of frames too large for LDS)
   uint32_t Mi = 0;
+  uint32_t stage_lo = 0, stage_hi = 0;   // walk positions staged so far: [stage_lo, stage_hi)
+  const float2* __restrict__ wyz = c.walk_yz + beg;
+  const uint8_t* __restrict__ wlab = c.walk_lab + beg;
+  const uint32_t Mi_all = LDS_POINTS ? c.walk_mi[f] : 0u, n_rim_all = LDS_POINTS ? c.walk_nrim[f] : 0u;
+  uint32_t n_in = Mi_all, n_rm = n_rim_all;
+  if (LDS_POINTS && M < Mfull) {
+    n_in = (uint32_t)(((uint64_t)Mi_all * M) / Mfull);
+    n_rm = (uint32_t)(((uint64_t)n_rim_all * M) / Mfull);
+  }
+  auto stage_point = [&](uint32_t sl) {
+    uint32_t src = sl < n_in ? sl : sl < n_in + n_rm ? Mi_all + (sl - n_in) : Mi_all + n_rim_all + (sl - n_in - n_rm);
+    src = min(src, Mfull - 1u);
+    const float2 v = wyz[src];
+    // Rx(theta) on (0,y,z), already divided by g (Optimization.h:37-46)
+    s_ij[sl] = make_float2(fmaf(-sth, v.y, cth * v.x), fmaf(cth, v.y, sth * v.x));
+    s_hw[sl] = wlab[src] ? 0.5f : 0.f;
+  };
   if (LDS_POINTS) {
-    const float2* __restrict__ wyz = c.walk_yz + beg;
-    const uint8_t* __restrict__ wlab = c.walk_lab + beg;
-    const uint32_t Mi_all = c.walk_mi[f], n_rim_all = c.walk_nrim[f];
-    uint32_t n_in = Mi_all, n_rm = n_rim_all;
-    if (M < Mfull) {
-      n_in = (uint32_t)(((uint64_t)Mi_all * M) / Mfull);
-      n_rm = (uint32_t)(((uint64_t)n_rim_all * M) / Mfull);
-    }
     // (parts are prefixes: n_in <= Mi_all, n_rm <= n_rim_all, and the rest M - n_in - n_rm <= the other border points + 2:
     // floor() twice; the source index below is clamped for that)
-    for (uint32_t sl = threadIdx.x; sl < M; sl += THREADS) {
-      uint32_t src = sl < n_in ? sl : sl < n_in + n_rm ? Mi_all + (sl - n_in) : Mi_all + n_rim_all + (sl - n_in - n_rm);
-      src = min(src, Mfull - 1u);
-      const float2 v = wyz[src];
-      // Rx(theta) on (0,y,z), already divided by g (Optimization.h:37-46)
-      s_ij[sl] = make_float2(fmaf(-sth, v.y, cth * v.x), fmaf(cth, v.y, sth * v.x));
-      s_hw[sl] = wlab[src] ? 0.5f : 0.f;
-    }
     Mi = n_in;
+    // The full pass stages the points its box pre-pass looks at first: a workgroup the pre-pass leaves no tile (half of
+    // them: every theta more than a few steps from the minimum) never stages, or reads, the rest.
+    const bool box_first = PRUNE && OOB && c.box_points != 0u && nta * ntb <= kBoxTilesMax && M > Mi;   // (= use_box below)
+    stage_lo = box_first ? Mi : 0u;
+    stage_hi = box_first ? Mi + min(max(c.box_points, Mfull >> ILCC_BOX_SHIFT), M - Mi) : M;
+    for (uint32_t sl = stage_lo + threadIdx.x; sl < stage_hi; sl += THREADS) stage_point(sl);
   }
   // (ty, tz) tables in LDS: a cut-short tile lasts about as long as one L2 round trip, so its
   // prologue must not wait for global loads
@@ -327,6 +334,7 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
     use_box = c.box_points != 0u && n_tiles <= kBoxTilesMax && M > Mi;
     if (use_box) {
       for (int w = threadIdx.x; w < (n_tiles + 31) / 32; w += THREADS) s_dead[w] = 0u;
+      if (threadIdx.x == 0) s_cnt[0] = 0u;   // "a tile of this workgroup is still alive" (s_cnt is free until the epilogue)
       __syncthreads();
       const uint32_t n_pre = min(max(c.box_points, Mfull >> ILCC_BOX_SHIFT), M - Mi);   // the frame's bound grows with its point count: so must the sample that has to exceed it
       const float lim_box = 0.5f * (1.f + kTieEps) * __uint_as_float(gb_bits);
@@ -362,11 +370,30 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
           both = lb + __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(lb), 0xB1 /*quad_perm [1,0,3,2]*/, 0xf, 0xf, false));
           if (__ballot(q < n_tiles && !(both * kBoxSafety > lim_box)) == 0ull) break;
         }
-        if (half == 0 && q < n_tiles && both * kBoxSafety > lim_box) atomicOr(&s_dead[q >> 5], 1u << (q & 31));
+        if (half == 0 && q < n_tiles) {
+          if (both * kBoxSafety > lim_box)
+            atomicOr(&s_dead[q >> 5], 1u << (q & 31));
+          else
+            s_cnt[0] = 1u;
+        }
       }
       if (lane == 0) s_iters[wid] = wave_evals;   // (s_iters is free until the epilogue)
       __syncthreads();
       for (int w = 0; w < THREADS / ILCC_WAVE; ++w) box_evals += s_iters[w];
+      const bool any_alive = s_cnt[0] != 0u;
+      __syncthreads();
+      if (!any_alive) {   // nothing to walk at this theta: the rest of the frame's points is never staged
+        if (threadIdx.x == 0) {
+          out->cost = __builtin_inff();
+          out->d2 = 0xFFFFFFFFu;
+          out->flat = 0xFFFFFFFFu;
+          out->pad = 0u;
+          atomicAdd(c.grid_iters + 2 * kIterSlots + (f & (kIterSlots - 1)), box_evals);
+        }
+        return;
+      }
+      for (uint32_t sl = threadIdx.x; sl < stage_lo; sl += THREADS) stage_point(sl);
+      for (uint32_t sl = stage_hi + threadIdx.x; sl < M; sl += THREADS) stage_point(sl);
       __syncthreads();
     }
   }
