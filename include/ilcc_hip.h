@@ -36,7 +36,7 @@ extern "C" {
 #endif
 
 #define ILCC_MAX_CORNERS 256
-#define ILCC_ABI_VERSION 3
+#define ILCC_ABI_VERSION 4
 
 /* per-frame / per-call status */
 enum {
@@ -139,7 +139,9 @@ typedef struct ilcc_params {
  * points and presses 'o' or 'r' (LidarCornersEst.cpp:415-441).  The automatic stand-in has two signals:
  *   status == ILCC_AMBIGUOUS   a basin one square away costs about the same (basin_margin < ambiguity_eps)
  *   flags & ILCC_FLAG_LOW_COVERAGE   the labelled points leave more than 10 % of the squares empty (cells_hit)
- * Recommended rule (what the class mirrors' get_corners applies): accept iff status == ILCC_OK and the flag is clear.
+ * Recommended rule (the DEFAULT of the class mirrors' get_corners; each signal has its own switch there,
+ * accept_ambiguous / accept_low_coverage, because the reference leaves the decision to the operator): accept iff
+ * status == ILCC_OK and the flag is clear.
  * On 2 x 1024 synthetic VLP-16 frames at 2-3.5 m (profiles/r03_confidence_study.json) that rule accepts 1916 of the 1959
  * ILCC_OK frames, rejects all 8 whose corners are a full square (150 mm) off, and the worst accepted frame is 16.7 mm
  * off; status alone accepts those 8. */
@@ -185,6 +187,13 @@ typedef struct ilcc_timing {
                                             translation of the grid (cheaper term: no out-of-board logic) */
   uint64_t grid_cost_box_evals_sum; /* (point, 16-candidate tile) evaluations of the box pre-pass: a lower bound for a whole
                                        tile at once (not part of grid_cost_evals_sum) */
+  /* ABI 4: the K6 stage kernel by kernel.  grid_cost_ms_sum above is the SPAN of the stage between two HIP events on the
+   * batch's stream -- with other batches in flight it contains the gaps in which the stage's short launches wait for a
+   * CU.  The four kernels are also bracketed one by one (seed, refinement, anchor, full pass): their summed durations are
+   * what a rocprofv3 kernel trace of the same run adds up to. */
+  double grid_cost_kernel_ms_sum;   /* sum over batches of (seed + refinement + anchor + full pass) kernel durations, ms */
+  double grid_cost_full_ms_sum;     /* the full pass alone */
+  double walk_order_ms_sum;         /* K5w (once per frame, in front of the K6 launches) */
 } ilcc_timing;
 
 int32_t ilcc_abi_version(void);
@@ -198,7 +207,8 @@ void ilcc_default_params(ilcc_params* p);
  * corner_in_x, corner_in_y from an OpenCV-YAML file, squares = corners+1, sorted ascending. */
 int32_t ilcc_set_chessboard_param(ilcc_params* p, const char* cam_yaml);
 
-/* device < 0: current device.  max_frames / max_total_points bound one batch call. */
+/* device < 0: current device.  max_frames / max_total_points bound one batch call.  A fresh handle sizes its on-chip
+ * staging from the batches it sees: call ilcc_reserve right after ilcc_create when the FIRST batch's latency matters. */
 ilcc_handle* ilcc_create(int32_t device, const ilcc_params* p, uint32_t max_frames,
                          uint64_t max_total_points);
 void ilcc_destroy(ilcc_handle* h);
@@ -231,9 +241,9 @@ int32_t ilcc_extract_batch_device(ilcc_handle* h, const float* d_xyzi, const uin
  * GPU_MAX_HW_QUEUES >= 5, HIP's default of 4 makes two of the streams share a hardware queue), so the short
  * latency-bound stages of one batch overlap with the grid search of another.  *ticket identifies the
  * batch; ilcc_wait blocks until it is complete and copies its records to out (n_frames entries).
- * (When GPU_MAX_HW_QUEUES is not in the environment at the time the library is loaded, the library's constructor sets it
- * to 8 -- never overriding a value of yours -- which takes effect only if the HIP runtime has not been initialised yet;
- * the first use of the fourth slot prints a one-time note in that case.)
+ * (The library never touches the environment: the HOST exports GPU_MAX_HW_QUEUES=8 before the HIP runtime starts --
+ * the Python package does it on import, the C++ mains in host/ do it first thing in main().  The first use of the
+ * fourth slot prints a one-time note when the variable is absent or below 5.)
  * Tickets must be waited for in submission order once all slots are taken (ILCC_CAPACITY otherwise).
  * The inputs must stay valid and unchanged until the matching ilcc_wait returns. */
 int32_t ilcc_submit_batch_device(ilcc_handle* h, const float* d_xyzi, const uint64_t* offsets,
@@ -249,12 +259,31 @@ int32_t ilcc_wait(ilcc_handle* h, int32_t ticket, ilcc_result* out);
  * (one collective of corner records per step): d_records[n_frames][ILCC_RECORD_HEADER + 3*n_corners]
  * floats = status, n_corners, phase, grid_index, iters_a, iters_b, cost_a, cost_b, sel_cost, theta,
  * ty, tz, n_plane, n_black, n_white, basin_margin, tag (= tag_base + frame index: lets the receiver check WHOSE
- * record sits where), check (24-bit xor-fold of the corner bits and the tag: lets it check the contents), flags, 0,
+ * record sits where), check (24-bit xor-fold of the corner bits and the tag: lets it check the contents), flags, n_roi,
  * then x y z per corner (zero beyond the frame's n_corners).
- * Complete on return, so the caller can hand the buffer to RCCL on any stream. */
+ * Complete on return, so the caller can hand the buffer to RCCL on any stream.  out may be NULL (ABI 4): nothing but the
+ * device-side records is produced then. */
 #define ILCC_RECORD_HEADER 20
 int32_t ilcc_wait_records_device(ilcc_handle* h, int32_t ticket, ilcc_result* out, void* d_records, uint32_t n_corners,
                                  uint32_t tag_base);
+
+/* Result traffic (ABI 4).  SURVEY.md 8(d) counts 12 * n_corners + 64 bytes of result per frame; ilcc_result is a
+ * 3.3 KB record sized for ILCC_MAX_CORNERS.  Two things keep the copy back near the algorithmic size:
+ *   - ilcc_wait copies, per frame, only the record's head and the corners of the handle's board
+ *     (offsetof(ilcc_result, corners) + 12 * (board_w - 1) * (board_h - 1) bytes: 652 B for the 7 x 5 board); corners beyond
+ *     the board's count are left as the caller passed them;
+ *   - ILCC_RESULTS_COMPACT: the batch's own stream packs the gather records described above (K9: ILCC_RECORD_HEADER
+ *     floats + 3 per corner = 500 B for the 7 x 5 board; tag = frame index within the batch; slot 19 = n_roi) and ONLY
+ *     those cross PCIe; ilcc_wait_compact hands them over.  The full records stay in HBM: ilcc_fetch_results reads
+ *     them for the last completed batch.
+ * Both waits work in both modes -- the mode decides which copy is enqueued with the batch (the other one is then a
+ * synchronous copy inside the wait).  Default: ILCC_RESULTS_FULL. */
+enum { ILCC_RESULTS_FULL = 0, ILCC_RESULTS_COMPACT = 1 };
+int32_t ilcc_set_result_mode(ilcc_handle* h, int32_t mode);   /* no batch may be in flight */
+/* records: n_frames x (ILCC_RECORD_HEADER + 3 * (board_w - 1) * (board_h - 1)) floats, host memory */
+int32_t ilcc_wait_compact(ilcc_handle* h, int32_t ticket, float* records);
+/* full records [first, first + n) of the last completed batch, copied from HBM (synchronous) */
+int32_t ilcc_fetch_results(ilcc_handle* h, uint32_t first, uint32_t n, ilcc_result* out);
 
 /* LidarCornersEst::get_chessboard_by_point (LidarCornersEst.cpp:72-115), the front half of the path as
  * the online node uses it (ilcc2/test/lidar_chessboard_online.cpp:91-101): NO ROI crop, Euclidean

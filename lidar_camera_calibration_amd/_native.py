@@ -30,7 +30,10 @@ EXPORTS = [
     "ilcc_extract_batch", "ilcc_extract_batch_device", "ilcc_submit_batch_device", "ilcc_submit_batch", "ilcc_wait", "ilcc_wait_records_device", "ilcc_fetch_cloud", "ilcc_fetch_labelled", "ilcc_fetch_walk", "ilcc_chessboard_by_point_batch", "ilcc_fetch_classes",
     "ilcc_grid_cost", "ilcc_pattern_refine", "ilcc_get_theta_t", "ilcc_get_timing", "ilcc_reset_timing",
     "ilcc_save_corners2txt", "ilcc_read_lidar_corners",
+    "ilcc_set_result_mode", "ilcc_wait_compact", "ilcc_fetch_results",
 ]
+ABI_VERSION = 4            # the layout of Params / Result / Timing below is ILCC_ABI_VERSION 4 of include/ilcc_hip.h
+RESULTS_FULL, RESULTS_COMPACT = 0, 1
 
 
 class Params(C.Structure):
@@ -105,6 +108,9 @@ class Timing(C.Structure):
         ("grid_cost_evals_nominal_sum", C.c_uint64),
         ("grid_cost_evals_interior_sum", C.c_uint64),
         ("grid_cost_box_evals_sum", C.c_uint64),
+        ("grid_cost_kernel_ms_sum", C.c_double),
+        ("grid_cost_full_ms_sum", C.c_double),
+        ("walk_order_ms_sum", C.c_double),
     ]
 
 
@@ -122,6 +128,11 @@ def lib():
         vp, fp = C.c_void_p, C.POINTER(C.c_float)
         pp, rp = C.POINTER(Params), C.POINTER(Result)
         L.ilcc_abi_version.restype = C.c_int32
+        got = L.ilcc_abi_version()
+        if got != ABI_VERSION:
+            # a stale build would load silently and every Result after frame 0 would be read at the wrong stride
+            raise OSError(f"{LIB_PATH} implements ABI {got}, this package declares ABI {ABI_VERSION}: rebuild it "
+                          "(python -c 'import __graft_entry__ as g; g.build()')")
         L.ilcc_strerror.argtypes = [C.c_int32]
         L.ilcc_strerror.restype = C.c_char_p
         L.ilcc_last_error.argtypes = [vp]
@@ -176,6 +187,12 @@ def lib():
         L.ilcc_save_corners2txt.restype = C.c_int32
         L.ilcc_read_lidar_corners.argtypes = [C.c_char_p, C.c_uint32, C.POINTER(C.c_double)]
         L.ilcc_read_lidar_corners.restype = C.c_int32
+        L.ilcc_set_result_mode.argtypes = [vp, C.c_int32]
+        L.ilcc_set_result_mode.restype = C.c_int32
+        L.ilcc_wait_compact.argtypes = [vp, C.c_int32, fp]
+        L.ilcc_wait_compact.restype = C.c_int32
+        L.ilcc_fetch_results.argtypes = [vp, C.c_uint32, C.c_uint32, rp]
+        L.ilcc_fetch_results.restype = C.c_int32
         _lib = L
     return _lib
 

@@ -28,6 +28,7 @@ constexpr int kSlots = ILCC_SLOTS;   // batches in flight per handle (submit/wai
 struct Slot {
   hipStream_t stream = nullptr;
   hipEvent_t ev[10]{};   // 0..6 stage boundaries; 7, 8: end of K6's seed + refinement passes / start of its full pass
+  hipEvent_t k6ev[3]{};  // inside the K6 stage: after K5w, after the seed launch, after the refinement launch (kernel-by-kernel durations)
   hipEvent_t k6_done = nullptr;
   bool allocated = false;
   // device buffers
@@ -49,7 +50,9 @@ struct Slot {
   uint32_t* d_tie_count = nullptr;
   GridPartial* d_tie_list = nullptr;
   unsigned long long* d_iters = nullptr;
+  float* d_rec = nullptr;    // K9 records of the batch (ILCC_RESULTS_COMPACT): max_frames x (ILCC_RECORD_HEADER + 3 ILCC_MAX_CORNERS) floats
   // pinned host staging
+  float* h_rec = nullptr;
   ilcc_result* h_res = nullptr;
   unsigned long long* h_iters = nullptr;
   uint64_t* h_off = nullptr;   // pinned copy of `off`: the upload at the head of a batch must not stage through pageable memory
@@ -57,6 +60,9 @@ struct Slot {
   std::vector<uint64_t> off;
   uint32_t n_frames = 0;
   bool busy = false, grid = false;
+  bool h_res_valid = false;  // h_res holds the last completed batch's full (trimmed) records
+  bool compact = false;      // what was enqueued with the batch in flight: the K9 records (true) or the trimmed full records
+  uint32_t rec_corners = 0;  // corners per K9 record of that batch
 };
 
 struct ilcc_handle {
@@ -86,6 +92,7 @@ struct ilcc_handle {
   uint32_t big_grid = 1024;          // workgroups of K2's persistent kernels (4 x the device's CUs)
   bool poisoned = false;             // a failed ilcc_set_params could not restore the device tables: every later call fails
   bool big_armed = false;            // K2's multi-workgroup kernels are launched: set once a frame above the LDS capacity was seen (finish()) or by ilcc_reserve
+  int32_t result_mode = ILCC_RESULTS_FULL;
   ilcc_timing timing{};
   std::string err;
 };
@@ -234,15 +241,18 @@ int32_t upload_tables(ilcc_handle* h) {
 }
 
 void free_slot(Slot& sl) {
-  void* bufs[] = {sl.d_xyzi, sl.d_clicks, sl.d_off, sl.d_res, sl.d_roi, sl.d_cluster, sl.d_board, sl.d_pca, sl.d_optim,
+  void* bufs[] = {sl.d_rec, sl.d_xyzi, sl.d_clicks, sl.d_off, sl.d_res, sl.d_roi, sl.d_cluster, sl.d_board, sl.d_pca, sl.d_optim,
                   sl.d_yz, sl.d_walk_yz, sl.d_walk_lab, sl.d_walk_mi, sl.d_walk_nrim, sl.d_lab, sl.d_cls, sl.d_nlab, sl.d_walk, sl.d_counts, sl.d_parent, sl.d_count, sl.d_hash_head, sl.d_hash_next, sl.d_big, sl.d_partial, sl.d_partial2, sl.d_partial3, sl.d_partial4, sl.d_masks,
                   sl.d_solverec, sl.d_bound, sl.d_bound_sub, sl.d_iters, sl.d_tie_count, sl.d_tie_list};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (sl.h_res) (void)hipHostFree(sl.h_res);
+  if (sl.h_rec) (void)hipHostFree(sl.h_rec);
   if (sl.h_iters) (void)hipHostFree(sl.h_iters);
   if (sl.h_off) (void)hipHostFree(sl.h_off);
   for (auto& ev : sl.ev)
+    if (ev) (void)hipEventDestroy(ev);
+  for (auto& ev : sl.k6ev)
     if (ev) (void)hipEventDestroy(ev);
   if (sl.k6_done) (void)hipEventDestroy(sl.k6_done);
   if (sl.stream) (void)hipStreamDestroy(sl.stream);
@@ -250,36 +260,19 @@ void free_slot(Slot& sl) {
 }
 
 // The HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share a queue
-// serialise: a fourth batch in flight only pays with >= 5 queues.  The variable is read when the runtime
-// initialises, so the library sets it (when unset) as soon as it is loaded, and says so when it finds a value that
-// is too small at the moment the fourth slot is first used.
-// (setenv from a library constructor is a side effect on the host process: it only ever ADDS the variable, never
-// overrides a value the user chose, and is documented in include/ilcc_hip.h at ilcc_submit_batch_device.)
-bool g_hwq_set_by_user = false;   // GPU_MAX_HW_QUEUES was already in the environment when the library was loaded
-__attribute__((constructor)) void ilcc_default_hw_queues() {
-  g_hwq_set_by_user = std::getenv("GPU_MAX_HW_QUEUES") != nullptr;
-  (void)setenv("GPU_MAX_HW_QUEUES", "8", /*overwrite=*/0);
-}
-
+// serialise: a fourth batch in flight only pays with >= 5 queues.  The variable is read when the runtime initialises and
+// belongs to the HOST process (the Python package exports it on import, the C++ mains in host/ first thing in main()):
+// the library only reads it, and says so once when the fourth slot is first used with fewer than 5 queues configured.
 void warn_hw_queues_once(int slot_index) {
   static std::once_flag once;   // handles of several threads (one per GPU) may reach this together
   if (slot_index < 3) return;
   std::call_once(once, [] {
     const char* v = std::getenv("GPU_MAX_HW_QUEUES");
-    if (g_hwq_set_by_user && v && std::atoi(v) >= 5) return;   // the user's own, sufficient setting
-    if (g_hwq_set_by_user)
-      std::fprintf(stderr,
-                   "libilcc_hip: GPU_MAX_HW_QUEUES=%s: with fewer than 5 hardware queues the fourth batch in flight shares a "
-                   "queue with another one and serialises; keep at most 3 tickets outstanding or export GPU_MAX_HW_QUEUES=8 "
-                   "before the HIP runtime starts\n", v ? v : "(unset)");
-    else
-      // the library set the variable itself when it was loaded -- which only helps if the HIP runtime had not been
-      // initialised by then (e.g. by an earlier `import torch`): it cannot tell, so it says so once
-      std::fprintf(stderr,
-                   "libilcc_hip: GPU_MAX_HW_QUEUES was unset when the library was loaded; it has been set to 8, which takes effect "
-                   "only if the HIP runtime had not started yet.  If something initialised HIP earlier (e.g. torch), the runtime "
-                   "keeps 4 hardware queues and the fourth batch in flight serialises with another one: export "
-                   "GPU_MAX_HW_QUEUES=8 before starting the process\n");
+    if (v && std::atoi(v) >= 5) return;
+    std::fprintf(stderr,
+                 "libilcc_hip: GPU_MAX_HW_QUEUES=%s: with fewer than 5 hardware queues the fourth batch in flight shares a "
+                 "queue with another one and serialises; keep at most 3 tickets outstanding or export GPU_MAX_HW_QUEUES=8 "
+                 "before the HIP runtime starts (the library does not modify the environment)\n", v ? v : "(unset: HIP's default is 4)");
   });
 }
 
@@ -290,12 +283,14 @@ int32_t alloc_slot(ilcc_handle* h, Slot& sl) {
   const uint32_t mf = h->max_frames;
   HIP_TRY(h, hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
   for (auto& ev : sl.ev) HIP_TRY(h, hipEventCreate(&ev));
+  for (auto& ev : sl.k6ev) HIP_TRY(h, hipEventCreate(&ev));
   HIP_TRY(h, hipEventCreateWithFlags(&sl.k6_done, hipEventDisableTiming));
 #define ALLOC(ptr, bytes) HIP_TRY(h, hipMalloc((void**)&(ptr), (size_t)(bytes)))
   ALLOC(sl.d_xyzi, sizeof(float4) * np);
   ALLOC(sl.d_clicks, sizeof(float) * 3 * mf);
   ALLOC(sl.d_off, sizeof(uint64_t) * (mf + 1));
   ALLOC(sl.d_res, sizeof(ilcc_result) * mf);
+  ALLOC(sl.d_rec, sizeof(float) * (size_t)mf * (ILCC_RECORD_HEADER + 3 * ILCC_MAX_CORNERS));
   ALLOC(sl.d_roi, sizeof(float4) * np);
   ALLOC(sl.d_cluster, sizeof(float4) * np);
   ALLOC(sl.d_board, sizeof(float4) * np);
@@ -329,6 +324,7 @@ int32_t alloc_slot(ilcc_handle* h, Slot& sl) {
   ALLOC(sl.d_iters, sizeof(unsigned long long) * 3 * kIterSlots);
 #undef ALLOC
   HIP_TRY(h, hipHostMalloc((void**)&sl.h_res, sizeof(ilcc_result) * mf, hipHostMallocDefault));
+  HIP_TRY(h, hipHostMalloc((void**)&sl.h_rec, sizeof(float) * (size_t)mf * (ILCC_RECORD_HEADER + 3 * ILCC_MAX_CORNERS), hipHostMallocDefault));
   HIP_TRY(h, hipHostMalloc((void**)&sl.h_iters, sizeof(unsigned long long) * 3 * kIterSlots, hipHostMallocDefault));
   HIP_TRY(h, hipHostMalloc((void**)&sl.h_off, sizeof(uint64_t) * (mf + 1), hipHostMallocDefault));
   sl.allocated = true;
@@ -433,6 +429,16 @@ int32_t check_offsets(ilcc_handle* h, const uint64_t* offsets, uint32_t n_frames
 int32_t enqueue_impl(ilcc_handle* h, int si, const float4* d_xyzi, const uint64_t* offsets, uint32_t n_frames, const float* d_clicks,
                      bool front_only, bool no_crop);
 
+uint32_t board_corners(const ilcc_params& p) { return (uint32_t)((p.board_w - 1) * (p.board_h - 1)); }
+size_t trimmed_bytes(uint32_t n_corners) { return offsetof(ilcc_result, corners) + sizeof(float) * 3 * (size_t)n_corners; }
+
+// per frame only the record's head and the board's corners (a pitched copy: rows of trimmed_bytes out of sizeof(ilcc_result))
+hipError_t copy_results_trimmed(ilcc_result* dst, const ilcc_result* d_src, uint32_t n_frames, uint32_t n_corners, hipStream_t s) {
+  if (n_frames == 0) return hipSuccess;
+  return hipMemcpy2DAsync(dst, sizeof(ilcc_result), d_src, sizeof(ilcc_result), trimmed_bytes(n_corners), n_frames,
+                          hipMemcpyDeviceToHost, s);
+}
+
 // enqueue the whole path for one batch on the slot's stream (no host synchronisation).  On a mid-pipeline failure the
 // kernels already queued may still be running on the slot's buffers: wait for them before handing the error back, so
 // that the next submit can reuse the slot.
@@ -489,6 +495,8 @@ int32_t enqueue_impl(ilcc_handle* h, int si, const float4* d_xyzi, const uint64_
   if (sl.grid) {
     const bool prune = h->p.grid_prune != 0;
     launch_walk_order(c, s);   // K5w: the labelled points in K6's walk layout, once per frame
+    HIP_TRY(h, hipEventRecord(sl.k6ev[0], s));
+    bool ev1 = false, ev2 = false;
     Ctx full = c;
     // (grid_prune = 0 keeps the two small passes: they only initialise the frame's bound, which the cut-free full
     // pass still needs to recognise near ties; it never cuts a tile)
@@ -520,6 +528,8 @@ int32_t enqueue_impl(ilcc_handle* h, int si, const float4* d_xyzi, const uint64_
       seed.walk_limit = sub;
       if (sub) seed.grid_bound = sl.d_bound_sub;
       launch_grid_cost(seed, s, /*use_oob=*/1, nullptr, true);
+      HIP_TRY(h, hipEventRecord(sl.k6ev[1], s));
+      ev1 = true;
       Ctx refine = c;
       refine.seed_partial = sl.d_partial2;
       refine.seed_blocks = (uint32_t)h->n_th2;
@@ -536,6 +546,8 @@ int32_t enqueue_impl(ilcc_handle* h, int si, const float4* d_xyzi, const uint64_
       refine.walk_limit = sub;
       if (sub) refine.grid_bound = sl.d_bound_sub;
       launch_grid_cost(refine, s, /*use_oob=*/1, nullptr, true);
+      HIP_TRY(h, hipEventRecord(sl.k6ev[2], s));
+      ev2 = true;
       if (sub) {
         Ctx anchor = c;
         anchor.seed_partial = sl.d_partial3;
@@ -577,6 +589,8 @@ int32_t enqueue_impl(ilcc_handle* h, int si, const float4* d_xyzi, const uint64_
     // The FULL passes of different slots are chained so that they never share the chip (their HIP-event
     // durations stay clean and they do not fight for LDS); the seed and refinement passes above are small,
     // latency-bound launches and are left free to overlap with another batch's full pass, like K2/K3/K7.
+    if (!ev1) HIP_TRY(h, hipEventRecord(sl.k6ev[1], s));
+    if (!ev2) HIP_TRY(h, hipEventRecord(sl.k6ev[2], s));
     HIP_TRY(h, hipEventRecord(sl.ev[7], s));
 #ifndef ILCC_K6_CHAIN
 #define ILCC_K6_CHAIN 1   // (A/B builds: 0 lets the full passes of different batches overlap)
@@ -606,29 +620,65 @@ int32_t enqueue_impl(ilcc_handle* h, int si, const float4* d_xyzi, const uint64_
   }
   HIP_TRY(h, hipEventRecord(sl.ev[6], s));
   HIP_TRY(h, hipGetLastError());
-  HIP_TRY(h, hipMemcpyAsync(sl.h_res, sl.d_res, sizeof(ilcc_result) * n_frames, hipMemcpyDeviceToHost, s));
+  // the copy back: what the result mode asks for rides on the batch's stream (include/ilcc_hip.h, "Result traffic")
+  sl.compact = h->result_mode == ILCC_RESULTS_COMPACT;
+  sl.rec_corners = board_corners(h->p);
+  if (sl.compact) {
+    launch_pack_records(sl.d_res, n_frames, sl.rec_corners, 0u, sl.d_rec, s);
+    HIP_TRY(h, hipMemcpyAsync(sl.h_rec, sl.d_rec, sizeof(float) * (size_t)n_frames * (ILCC_RECORD_HEADER + 3 * sl.rec_corners),
+                              hipMemcpyDeviceToHost, s));
+  } else {
+    HIP_TRY(h, copy_results_trimmed(sl.h_res, sl.d_res, n_frames, sl.rec_corners, s));
+  }
   HIP_TRY(h, hipMemcpyAsync(sl.h_iters, sl.d_iters, sizeof(unsigned long long) * 3 * kIterSlots, hipMemcpyDeviceToHost, s));
   sl.busy = true;
   return ILCC_OK;
 }
 
-// wait for the slot's batch, hand the records over, account the timing
-int32_t finish(ilcc_handle* h, int si, ilcc_result* out, float* d_records = nullptr, uint32_t n_corners = 0,
-               uint32_t tag_base = 0) {
+// the slot's full records in its pinned staging (they are there already unless the batch ran in ILCC_RESULTS_COMPACT mode)
+int32_t ensure_full(ilcc_handle* h, Slot& sl) {
+  if (sl.h_res_valid) return ILCC_OK;
+  HIP_TRY(h, copy_results_trimmed(sl.h_res, sl.d_res, sl.n_frames, sl.rec_corners, sl.stream));
+  HIP_TRY(h, hipStreamSynchronize(sl.stream));
+  sl.h_res_valid = true;
+  return ILCC_OK;
+}
+
+// wait for the slot's batch, hand the records over (full and / or compact), account the timing
+int32_t finish(ilcc_handle* h, int si, ilcc_result* out, float* out_compact = nullptr, float* d_records = nullptr,
+               uint32_t n_corners = 0, uint32_t tag_base = 0) {
   Slot& sl = h->slots[si];
   if (d_records) launch_pack_records(sl.d_res, sl.n_frames, n_corners, tag_base, d_records, sl.stream);   // same stream: after K7
+  const uint32_t n_frames = sl.n_frames;
+  const size_t rec_w = (size_t)ILCC_RECORD_HEADER + 3 * (size_t)sl.rec_corners;
+  if (out_compact && !sl.compact) {   // not enqueued with the batch: pack and copy now
+    launch_pack_records(sl.d_res, n_frames, sl.rec_corners, 0u, sl.d_rec, sl.stream);
+    HIP_TRY(h, hipMemcpyAsync(sl.h_rec, sl.d_rec, sizeof(float) * n_frames * rec_w, hipMemcpyDeviceToHost, sl.stream));
+  }
   HIP_TRY(h, hipStreamSynchronize(sl.stream));
   sl.busy = false;
+  sl.h_res_valid = !sl.compact;
   h->last_slot = si;
-  const uint32_t n_frames = sl.n_frames;
-  std::memcpy(out, sl.h_res, sizeof(ilcc_result) * n_frames);
+  if (out) {
+    const int32_t st = ensure_full(h, sl);
+    if (st != ILCC_OK) return st;
+    const size_t row = trimmed_bytes(sl.rec_corners);
+    for (uint32_t f = 0; f < n_frames; ++f) std::memcpy(&out[f], &sl.h_res[f], row);
+  }
+  if (out_compact) std::memcpy(out_compact, sl.h_rec, sizeof(float) * n_frames * rec_w);
   float ms[6];
   for (int k = 0; k < 6; ++k) HIP_TRY(h, hipEventElapsedTime(&ms[k], sl.ev[k], sl.ev[k + 1]));
+  float k6k[5] = {0.f, 0.f, 0.f, 0.f, 0.f};   // K5w, seed, refinement, anchor, full pass
   if (sl.grid) {   // K6 = (seed + refinement passes) + (full pass); the wait for the previous batch's full pass in between is not K6 time
     float pre = 0.f, fullp = 0.f;
     HIP_TRY(h, hipEventElapsedTime(&pre, sl.ev[4], sl.ev[7]));
     HIP_TRY(h, hipEventElapsedTime(&fullp, sl.ev[8], sl.ev[5]));
     ms[4] = pre + fullp;
+    HIP_TRY(h, hipEventElapsedTime(&k6k[0], sl.ev[4], sl.k6ev[0]));
+    HIP_TRY(h, hipEventElapsedTime(&k6k[1], sl.k6ev[0], sl.k6ev[1]));
+    HIP_TRY(h, hipEventElapsedTime(&k6k[2], sl.k6ev[1], sl.k6ev[2]));
+    HIP_TRY(h, hipEventElapsedTime(&k6k[3], sl.k6ev[2], sl.ev[7]));
+    k6k[4] = fullp;
   }
   float tot = 0;
   HIP_TRY(h, hipEventElapsedTime(&tot, sl.ev[0], sl.ev[6]));
@@ -643,16 +693,32 @@ int32_t finish(ilcc_handle* h, int si, ilcc_result* out, float* d_records = null
   uint32_t max_lab = 0, max_roi = 0;
   uint64_t evals = 0;
   for (uint32_t f = 0; f < n_frames; ++f) {
-    if (out[f].n_roi > 0 && (uint32_t)out[f].n_roi <= (uint32_t)kClusterLdsPointsMax) max_roi = std::max(max_roi, (uint32_t)out[f].n_roi);
-    if (out[f].n_roi > kClusterLdsPointsMax) h->big_armed = true;
-    if (out[f].status != ILCC_OK && out[f].status != ILCC_AMBIGUOUS) continue;
-    const uint32_t m = (uint32_t)(out[f].n_black + out[f].n_white);
+    // (status, n_roi, labelled points) from whichever record came back with the batch
+    int32_t status, n_roi;
+    uint32_t m;
+    if (sl.h_res_valid) {
+      const ilcc_result& r = sl.h_res[f];
+      status = r.status;
+      n_roi = r.n_roi;
+      m = (uint32_t)(r.n_black + r.n_white);
+    } else {
+      const float* r = sl.h_rec + (size_t)f * rec_w;
+      status = (int32_t)r[0];
+      n_roi = (int32_t)r[19];
+      m = (uint32_t)r[13] + (uint32_t)r[14];
+    }
+    if (n_roi > 0 && (uint32_t)n_roi <= (uint32_t)kClusterLdsPointsMax) max_roi = std::max(max_roi, (uint32_t)n_roi);
+    if (n_roi > kClusterLdsPointsMax) h->big_armed = true;
+    if (status != ILCC_OK && status != ILCC_AMBIGUOUS) continue;
     max_lab = std::max(max_lab, m);
     evals += (uint64_t)m * (uint64_t)h->p.n_th * h->p.n_ty * h->p.n_tz;
   }
   if (sl.grid) {
     t.grid_cost_launches += 1;
     t.grid_cost_ms_sum += ms[4];
+    t.walk_order_ms_sum += k6k[0];
+    t.grid_cost_kernel_ms_sum += (double)k6k[1] + k6k[2] + k6k[3] + k6k[4];
+    t.grid_cost_full_ms_sum += k6k[4];
     t.grid_cost_evals_nominal_sum += evals;
     // (both colour phases of a (point, candidate) pair = 1 evaluation)
     unsigned long long iters = 0;
@@ -969,12 +1035,47 @@ int32_t ilcc_wait(ilcc_handle* h, int32_t ticket, ilcc_result* out) {
 
 int32_t ilcc_wait_records_device(ilcc_handle* h, int32_t ticket, ilcc_result* out, void* d_records, uint32_t n_corners,
                                  uint32_t tag_base) {
-  if (!h || !out || !d_records || n_corners > ILCC_MAX_CORNERS || ticket < 0 || ticket >= kSlots || !h->slots[ticket].busy) {
+  if (!h || !d_records || n_corners > ILCC_MAX_CORNERS || ticket < 0 || ticket >= kSlots || !h->slots[ticket].busy) {   // (out may be NULL: device records only)
     if (h) h->err = "ilcc_wait_records_device: bad argument or no batch in flight under this ticket";
     return ILCC_BAD_ARGUMENT;
   }
   HIP_TRY(h, hipSetDevice(h->device));
-  return finish(h, ticket, out, static_cast<float*>(d_records), n_corners, tag_base);
+  return finish(h, ticket, out, nullptr, static_cast<float*>(d_records), n_corners, tag_base);
+}
+
+int32_t ilcc_set_result_mode(ilcc_handle* h, int32_t mode) {
+  if (!h || (mode != ILCC_RESULTS_FULL && mode != ILCC_RESULTS_COMPACT)) return ILCC_BAD_ARGUMENT;
+  for (const Slot& sl : h->slots)
+    if (sl.busy) {
+      h->err = "ilcc_set_result_mode with a batch in flight: ilcc_wait first";
+      return ILCC_BAD_ARGUMENT;
+    }
+  h->result_mode = mode;
+  return ILCC_OK;
+}
+
+int32_t ilcc_wait_compact(ilcc_handle* h, int32_t ticket, float* records) {
+  if (!h || !records || ticket < 0 || ticket >= kSlots || !h->slots[ticket].busy) {
+    if (h) h->err = "ilcc_wait_compact: no batch in flight under this ticket";
+    return ILCC_BAD_ARGUMENT;
+  }
+  HIP_TRY(h, hipSetDevice(h->device));
+  return finish(h, ticket, nullptr, records);
+}
+
+int32_t ilcc_fetch_results(ilcc_handle* h, uint32_t first, uint32_t n, ilcc_result* out) {
+  if (!h || !out || h->last_slot < 0) return ILCC_BAD_ARGUMENT;
+  Slot& sl = h->slots[h->last_slot];
+  if (sl.busy || first > sl.n_frames || n > sl.n_frames - first) {
+    h->err = "ilcc_fetch_results: no completed batch, or the range exceeds it";
+    return ILCC_BAD_ARGUMENT;
+  }
+  HIP_TRY(h, hipSetDevice(h->device));
+  const int32_t st = ensure_full(h, sl);
+  if (st != ILCC_OK) return st;
+  const size_t row = trimmed_bytes(sl.rec_corners);
+  for (uint32_t f = 0; f < n; ++f) std::memcpy(&out[f], &sl.h_res[first + f], row);
+  return ILCC_OK;
 }
 
 int32_t ilcc_extract_batch_device(ilcc_handle* h, const float* d_xyzi, const uint64_t* offsets,
@@ -1047,6 +1148,7 @@ int64_t ilcc_fetch_classes(ilcc_handle* h, uint32_t frame, uint8_t* out_class, u
   if (!h || h->last_slot < 0) return -(int64_t)ILCC_BAD_ARGUMENT;
   Slot& sl = h->slots[h->last_slot];
   if (sl.busy || frame >= sl.n_frames) return -(int64_t)ILCC_BAD_ARGUMENT;
+  if (ensure_full(h, sl) != ILCC_OK) return -(int64_t)ILCC_HIP_ERROR;
   const ilcc_result& r = sl.h_res[frame];
   const int64_t n = (r.status == ILCC_OK || r.status == ILCC_AMBIGUOUS || r.status == ILCC_BOARD_NOT_FOUND) ? r.n_plane : 0;
   const int64_t m = std::min<int64_t>(n, (int64_t)cap_points);
@@ -1060,6 +1162,7 @@ int64_t ilcc_fetch_cloud(ilcc_handle* h, uint32_t frame, int32_t which, float* o
   if (!h || h->last_slot < 0) return -(int64_t)ILCC_BAD_ARGUMENT;
   Slot& sl = h->slots[h->last_slot];
   if (sl.busy || frame >= sl.n_frames) return -(int64_t)ILCC_BAD_ARGUMENT;
+  if (ensure_full(h, sl) != ILCC_OK) return -(int64_t)ILCC_HIP_ERROR;
   const ilcc_result& r = sl.h_res[frame];
   const float4* src = nullptr;
   int64_t n = 0;

@@ -1298,7 +1298,8 @@ __global__ __launch_bounds__(128) void k9_pack_records(const ilcc_result* __rest
         case 15: v = (float)r.basin_margin; break;
         case 16: v = (float)tag; break;
         case 18: v = (float)r.flags; break;
-        default: v = 0.f;   // 17 (check) is written below, 19 is spare
+        case 19: v = (float)r.n_roi; break;
+        default: v = 0.f;   // 17 (check) is written below
       }
     }
     if (k != 17u) o[k] = v;

@@ -41,6 +41,11 @@ bool LidarCornersEst::run() {
   if (m_done) return true;
   if (!m_input) return false;
   if (!m_handle) {
+    if (ilcc_abi_version() != ILCC_ABI_VERSION) {   // a stale libilcc_hip.so: ilcc_result / ilcc_params would be read at the wrong offsets
+      std::cerr << "libilcc_hip.so implements ABI " << ilcc_abi_version() << ", this host was compiled against ABI "
+                << ILCC_ABI_VERSION << std::endl;
+      return false;
+    }
     m_handle = ilcc_create(m_device, &m_params, 1, m_max_points);
     if (!m_handle) {
       std::cerr << "ilcc_create failed: " << ilcc_last_error(nullptr) << std::endl;
@@ -100,7 +105,7 @@ bool LidarCornersEst::get_corners(std::vector<std::array<double, 3>>& corners) {
     std::cout << "reject this scan" << std::endl;   // :439
     return false;
   }
-  if ((m_result.flags & ILCC_FLAG_LOW_COVERAGE) && !accept_ambiguous) {
+  if ((m_result.flags & ILCC_FLAG_LOW_COVERAGE) && !accept_low_coverage) {
     // the second half of the operator's look at the viewer: the virtual board must sit ON the points.  With more than
     // 10 % of the squares empty a one-square slip can fit better than the truth (include/ilcc_hip.h "accepting a frame")
     std::cout << "reject this scan (pattern under-sampled: " << m_result.cells_hit << " of "

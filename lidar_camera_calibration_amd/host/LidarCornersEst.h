@@ -40,10 +40,13 @@ class LidarCornersEst {
   void PCA();                                                 // :366-372
   bool get_corners(std::vector<std::array<double, 3>>& corners);   // :374-450
 
-  // ILCC_AMBIGUOUS scans (GRID solver: a basin one square away costs about the same) and scans flagged
-  // ILCC_FLAG_LOW_COVERAGE (more than 10 % of the squares empty): get_corners returns false unless this is set -- the
-  // automatic stand-in for the operator who would press 'r' at the viewer
+  // The automatic stand-ins for the operator who would press 'r' at the viewer, one switch per signal:
+  // ILCC_AMBIGUOUS scans (GRID solver: a basin one square away costs about the same): get_corners returns false unless
+  // accept_ambiguous; ILCC_OK scans flagged ILCC_FLAG_LOW_COVERAGE (fewer than params().min_cell_coverage of the squares
+  // hold a labelled point -- a far board on a 16-ring sensor): false unless accept_low_coverage.  result().flags keeps
+  // the flag either way, so a caller can also take the decision itself.
   bool accept_ambiguous = false;
+  bool accept_low_coverage = false;
 
   PointXYZI m_click_point{};
   myPointCloudPtr m_cloud_ROI, m_cloud_chessboard, m_cloud_PCA, m_cloud_optim, m_cloud_corners;

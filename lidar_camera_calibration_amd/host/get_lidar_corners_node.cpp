@@ -5,6 +5,8 @@
 //   node name            lidar_corners (ros::init), launched as type get_lidar_corners
 //   private parameters   ~bag_path_prefix ("20181101_"), ~bag_num (1), ~lidar_topic
 //                        ("/velodyne_points"), ~camera_name ("front"), ~yaml_path ("front.yaml")
+//                        added (the operator's 'r' key made automatic, one switch per signal, both default false):
+//                        ~accept_ambiguous, ~accept_low_coverage
 //   subscribes           /clicked_point  geometry_msgs/PointStamped, queue 100
 //   advertises           /velodyne_points /ChessBoard /pca_cloud /Optim_cloud /lidar_corners
 //                        sensor_msgs/PointCloud2, queue 10, frame_id "/velodyne"
@@ -27,6 +29,7 @@
 #include <sensor_msgs/PointCloud2.h>
 
 #include <array>
+#include <cstdlib>
 #include <map>
 #include <string>
 #include <vector>
@@ -46,8 +49,11 @@ struct NodeConfig {
   std::string camera = "front";
   std::string yaml = "front.yaml";
   std::string package_dir;
+  bool accept_ambiguous = false, accept_low_coverage = false;
 
   void load(ros::NodeHandle& priv) {
+    priv.param<bool>("accept_ambiguous", accept_ambiguous, accept_ambiguous);
+    priv.param<bool>("accept_low_coverage", accept_low_coverage, accept_low_coverage);
     priv.param<std::string>("bag_path_prefix", bag_prefix, bag_prefix);
     priv.param<int>("bag_num", bag_count, bag_count);
     priv.param<std::string>("lidar_topic", lidar_topic, lidar_topic);
@@ -108,6 +114,8 @@ class CornerNode {
     cfg_.load(priv);
     ROS_INFO("ilcc2 package at %s, %d bag(s)", cfg_.package_dir.c_str(), cfg_.bag_count);
     estimator_.register_viewer();
+    estimator_.accept_ambiguous = cfg_.accept_ambiguous;
+    estimator_.accept_low_coverage = cfg_.accept_low_coverage;
     estimator_.set_chessboard_param(cfg_.package_dir + "/config/" + cfg_.yaml);
     click_sub_ = nh.subscribe<geometry_msgs::PointStamped>("/clicked_point", 100, &CornerNode::on_click, this);
     const char* topics[] = {"/velodyne_points", "/ChessBoard", "/pca_cloud", "/Optim_cloud", "/lidar_corners"};
@@ -178,6 +186,7 @@ class CornerNode {
 }  // namespace
 
 int main(int argc, char** argv) {
+  (void)setenv("GPU_MAX_HW_QUEUES", "8", /*overwrite=*/0);   // host-side, before the HIP runtime starts (include/ilcc_hip.h)
   ros::init(argc, argv, "lidar_corners");
   ros::NodeHandle nh;
   CornerNode node(nh);

@@ -1,7 +1,7 @@
 // ilcc_corners -- ROS-free driver of the get_lidar_corners path for machines without ROS (the GPU
 // box): one frame (raw float32 x,y,z,intensity records) + one click -> process_data-format file.
 //   ilcc_corners --cloud frame.bin --click x y z --yaml pointgrey.yaml --out pointgrey_lidar_1.txt
-//                [--solver grid|reference] [--device N] [--accept-ambiguous]
+//                [--solver grid|reference] [--device N] [--accept-ambiguous] [--accept-low-coverage]
 //   ilcc_corners --bag 20181101_1.bag [--topic /velodyne_points] --click x y z ... (first PointCloud2
 //                of the bag, read without ROS: include/ilcc_ingest.h)
 // Mirrors the per-bag body of /root/reference/ilcc2/test/get_lidar_corners.cpp:133-204.
@@ -18,10 +18,13 @@
 using namespace ilcc_host;
 
 int main(int argc, char** argv) {
+  // the library keeps up to four batches in flight on four HIP streams: more hardware queues than HIP's default of 4,
+  // exported by the HOST before the runtime starts (include/ilcc_hip.h, ilcc_submit_batch_device); never overrides the user
+  (void)setenv("GPU_MAX_HW_QUEUES", "8", /*overwrite=*/0);
   std::string cloud_path, bag_path, topic = "/velodyne_points", yaml_path, out_path, solver = "grid";
   PointXYZI click{0, 0, 0, 0};
   int device = -1;
-  bool have_click = false, accept_ambiguous = false;
+  bool have_click = false, accept_ambiguous = false, accept_low_coverage = false;
   for (int i = 1; i < argc; ++i) {
     const std::string a = argv[i];
     if (a == "--cloud" && i + 1 < argc) cloud_path = argv[++i];
@@ -32,6 +35,7 @@ int main(int argc, char** argv) {
     else if (a == "--solver" && i + 1 < argc) solver = argv[++i];
     else if (a == "--device" && i + 1 < argc) device = std::atoi(argv[++i]);
     else if (a == "--accept-ambiguous") accept_ambiguous = true;
+    else if (a == "--accept-low-coverage") accept_low_coverage = true;
     else if (a == "--click" && i + 3 < argc) {
       click.x = (float)std::atof(argv[++i]);
       click.y = (float)std::atof(argv[++i]);
@@ -44,7 +48,7 @@ int main(int argc, char** argv) {
   }
   if ((cloud_path.empty() == bag_path.empty()) || out_path.empty() || !have_click) {
     std::fprintf(stderr, "usage: ilcc_corners (--cloud frame.bin | --bag file.bag [--topic /velodyne_points]) --click x y z "
-                         "[--yaml board.yaml] --out file.txt [--solver grid|reference] [--device N] [--accept-ambiguous]\n");
+                         "[--yaml board.yaml] --out file.txt [--solver grid|reference] [--device N] [--accept-ambiguous] [--accept-low-coverage]\n");
     return 2;
   }
   myPointCloudPtr cloud(new myPointCloud);
@@ -75,6 +79,7 @@ int main(int argc, char** argv) {
   LidarCornersEst est(device, (uint32_t)cloud->size() + 1);
   est.params().solver = (solver == "reference") ? ILCC_SOLVER_REFERENCE_LOCAL : ILCC_SOLVER_GRID;
   est.accept_ambiguous = accept_ambiguous;
+  est.accept_low_coverage = accept_low_coverage;
   est.register_viewer();
   if (!yaml_path.empty() && !est.set_chessboard_param(yaml_path)) return 1;
 

@@ -159,6 +159,7 @@ int run_rank(RankJob* j) {
 }  // namespace
 
 int main(int argc, char** argv) {
+  (void)setenv("GPU_MAX_HW_QUEUES", "8", /*overwrite=*/0);   // host-side, before the first HIP call (include/ilcc_hip.h)
   if (argc < 8 || (argc - 4) % 4 != 0) {
     std::fprintf(stderr, "usage: %s <yaml|-> <out_prefix> <n_gpus, 0 = all> {<cloud.bin> <cx> <cy> <cz>}...\n", argv[0]);
     return 2;

@@ -26,6 +26,7 @@ static myPointCloudPtr load(const std::string& path) {
 }
 
 int main(int argc, char** argv) {
+  (void)setenv("GPU_MAX_HW_QUEUES", "8", /*overwrite=*/0);   // host-side, before the HIP runtime starts (include/ilcc_hip.h)
   if (argc < 8 || (argc - 4) % 4 != 0) {
     std::fprintf(stderr, "usage: %s <yaml> <out_prefix> <grid|reference> {<cloud.bin> <cx> <cy> <cz>}...\n", argv[0]);
     return 2;

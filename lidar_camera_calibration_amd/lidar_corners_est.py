@@ -42,9 +42,13 @@ class LidarCornersEst:
         self._cloud = None
         self._click = None
         self._result: Optional[N.Result] = None
-        # ILCC_AMBIGUOUS scans (a basin one square away costs about the same) and ILCC_FLAG_LOW_COVERAGE scans (more than
-        # 10 % of the squares empty): get_corners() returns False unless this is set -- the automatic stand-in for the operator who would press 'r' at the viewer
+        # The automatic stand-ins for the operator who would press 'r' at the viewer, one switch per signal:
+        # ILCC_AMBIGUOUS scans (a basin one square away costs about the same) -> get_corners() returns False unless
+        # accept_ambiguous; ILCC_OK scans flagged ILCC_FLAG_LOW_COVERAGE (fewer than params.min_cell_coverage of the squares
+        # hold a labelled point: a far board on a 16-ring sensor) -> False unless accept_low_coverage.  The flag stays in
+        # `result.flags` either way.
         self.accept_ambiguous = False
+        self.accept_low_coverage = False
         self.m_click_point = None
         self.m_cloud_ROI = self.m_cloud_chessboard = self.m_cloud_PCA = None
         self.m_cloud_optim = self.m_cloud_corners = None
@@ -189,7 +193,7 @@ class LidarCornersEst:
         if res.status not in (N.OK, N.AMBIGUOUS):
             print("reject this scan")
             return False
-        if (res.flags & N.FLAG_LOW_COVERAGE) and not self.accept_ambiguous:
+        if (res.flags & N.FLAG_LOW_COVERAGE) and not self.accept_low_coverage:
             print("reject this scan (pattern under-sampled: %d of %d squares hold points)"
                   % (res.cells_hit, self.params.board_w * self.params.board_h))
             return False
@@ -235,6 +239,31 @@ class LidarCornersBatch:
         st = self._lib.ilcc_set_params(self._h, C.byref(params))
         if st != N.OK:
             raise IlccError(st, self._err())
+
+    def set_result_mode(self, mode: int):
+        """ILCC_RESULTS_FULL (default) / ILCC_RESULTS_COMPACT: which records ride back with a submitted batch."""
+        st = self._lib.ilcc_set_result_mode(self._h, int(mode))
+        if st != N.OK:
+            raise IlccError(st, self._err())
+
+    def wait_compact(self, ticket) -> np.ndarray:
+        """The batch's compact records: [n_frames, RECORD_HEADER + 3 * board corners] float32 (layout:
+        ``sharding.pack_records``; tag = frame index within the batch)."""
+        t, n_frames = ticket
+        nc = (self.params.board_w - 1) * (self.params.board_h - 1)
+        rec = np.empty((n_frames, N.RECORD_HEADER + 3 * nc), dtype=np.float32)
+        st = self._lib.ilcc_wait_compact(self._h, t, N.fptr(rec))
+        if st != N.OK:
+            raise IlccError(st, self._err())
+        return rec
+
+    def fetch_results(self, first: int, n: int):
+        """Full records [first, first + n) of the last completed batch (read from HBM)."""
+        res = (N.Result * n)()
+        st = self._lib.ilcc_fetch_results(self._h, int(first), int(n), res)
+        if st != N.OK:
+            raise IlccError(st, self._err())
+        return res
 
     def reserve(self, labelled_points_per_frame: int, roi_points_per_frame: int):
         """ilcc_reserve: size the on-chip staging (grid search: labelled points; clustering: ROI points) up front, so the
@@ -294,12 +323,14 @@ class LidarCornersBatch:
             raise IlccError(st, self._err())
         return ticket.value, n_frames
 
-    def wait(self, ticket, d_records_ptr: Optional[int] = None, n_corners: int = 0, tag_base: int = 0):
+    def wait(self, ticket, d_records_ptr: Optional[int] = None, n_corners: int = 0, tag_base: int = 0,
+             want_results: bool = True):
         """Results of a submitted batch.  With ``d_records_ptr`` (device memory, n_frames x (RECORD_HEADER +
         3*n_corners) float32) the fixed-size gather records are also packed on the GPU
-        (``ilcc_wait_records_device``); record f carries the tag ``tag_base + f``."""
+        (``ilcc_wait_records_device``); record f carries the tag ``tag_base + f``.  ``want_results=False`` (only with
+        ``d_records_ptr``): nothing but the device-side records is produced."""
         t, n_frames = ticket
-        res = (N.Result * n_frames)()
+        res = (N.Result * n_frames)() if (want_results or d_records_ptr is None) else None
         if d_records_ptr is not None:
             st = self._lib.ilcc_wait_records_device(self._h, t, res, C.c_void_p(d_records_ptr), n_corners,
                                                     int(tag_base) & 0xFFFFFFFF)

@@ -75,7 +75,7 @@ def pack_records(results: Sequence, n_frames: int, n_corners: Optional[int] = No
     """ilcc_result-like records -> [n_frames, record_floats] float32.
 
     header: status, n_corners, phase, grid_index, iters_a, iters_b, cost_a, cost_b, sel_cost,
-    theta, ty, tz, n_plane, n_black, n_white, basin_margin, tag, check, flags, 0 ; then corners x y z
+    theta, ty, tz, n_plane, n_black, n_white, basin_margin, tag, check, flags, n_roi ; then corners x y z
     (bit-identical to the device-side K9 ``pack_records``)."""
     if n_corners is None:
         n_corners = max([int(results[f].n_corners) for f in range(n_frames)] + [0])
@@ -91,6 +91,7 @@ def pack_records(results: Sequence, n_frames: int, n_corners: Optional[int] = No
         out[:, 14] = sa["n_white"]
         out[:, 15] = sa["basin_margin"]
         out[:, 18] = sa["flags"]
+        out[:, 19] = sa["n_roi"]
         out[:, HEADER_FLOATS:] = sa["corners"][:, :3 * n_corners]
         ok = np.arange(3 * n_corners)[None, :] < 3 * np.maximum(sa["n_corners"], 0)[:, None]
         out[:, HEADER_FLOATS:] = np.where(ok, out[:, HEADER_FLOATS:], np.float32(0))
@@ -104,6 +105,7 @@ def pack_records(results: Sequence, n_frames: int, n_corners: Optional[int] = No
                        r.sel_cost, r.theta_t[0], r.theta_t[1], r.theta_t[2], r.n_plane, r.n_black, r.n_white)
         out[f, 15] = getattr(r, "basin_margin", 0.0)
         out[f, 18] = getattr(r, "flags", 0)
+        out[f, 19] = getattr(r, "n_roi", 0)
         k = min(int(r.n_corners), n_corners)
         if k > 0:
             out[f, HEADER_FLOATS:HEADER_FLOATS + 3 * k] = np.ctypeslib.as_array(r.corners)[:3 * k]

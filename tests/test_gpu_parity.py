@@ -376,7 +376,9 @@ def test_ambiguous_frames_are_flagged_not_silently_returned(ob):
     m.PCA()
     corners = []
     assert m.get_corners(corners) is False and corners == []
-    m.accept_ambiguous = True
+    m.accept_ambiguous = True            # the basin signal alone: the middle-rows-only board is ALSO under-sampled,
+    assert m.get_corners(corners) is False and corners == []    # and the coverage gate has its own switch
+    m.accept_low_coverage = True
     assert m.get_corners(corners) is True and len(corners) == 35
     m.close()
 
@@ -384,7 +386,8 @@ def test_ambiguous_frames_are_flagged_not_silently_returned(ob):
 def test_low_coverage_flag_and_accept_rule(ob):
     """The second confidence signal: cells_hit / n_oob equal the oracle's; a board whose far
     end is cut off by the ROI leaves squares empty -> ILCC_FLAG_LOW_COVERAGE, and the class mirror's get_corners
-    rejects the scan unless accept_ambiguous is set; min_cell_coverage <= 0 switches the flag off."""
+    rejects the scan unless accept_low_coverage is set (its own switch: accept_ambiguous does not open this gate);
+    min_cell_coverage <= 0 switches the flag off."""
     board = synth.Board()
     pose = synth.pose_from_fixture(0)
     cloud = synth.make_frame(synth.vlp16(), board, pose, 0xC0FFEE)
@@ -415,7 +418,13 @@ def test_low_coverage_flag_and_accept_rule(ob):
         m.PCA()
         got = []
         assert m.get_corners(got) is False and got == []
-        m.accept_ambiguous = True
+        if r2.status == N.OK:
+            m.accept_ambiguous = True        # the other signal's switch does not accept an under-sampled scan
+            assert m.get_corners(got) is False and got == []
+            m.accept_ambiguous = False
+        else:
+            m.accept_ambiguous = True
+        m.accept_low_coverage = True
         got = []
         assert m.get_corners(got) is True and len(got) == 35
         m.close()
@@ -609,7 +618,9 @@ def test_full_size_batch_properties():
     # square (150 mm) off, and the rule keeps >= 90 % of the batch
     acc = [f for f in ok if not low[f]]
     err_acc = np.array([synth.corner_error(r1[f].reshape(35, 3), gts[f], BOARD) for f in acc])
-    assert len(acc) >= 0.90 * F and err_acc.max() < 0.03, (len(acc), err_acc.max())
+    # (measured on these 128 frames: 119 accepted, worst accepted frame 16.7 mm, p99 of the OK frames 9.1 mm)
+    assert len(acc) >= 0.92 * F and err_acc.max() < 0.02, (len(acc), err_acc.max())
+    assert np.percentile(err, 99) < 0.010 or np.sort(err)[-3] < 0.010, np.sort(err)[-4:]   # all but the one or two one-square slips
     # every result is an exact planar 0.15 m lattice (what the consumer relies on)
     for f in ok[:16]:
         g = r1[f].reshape(5, 7, 3)
@@ -762,6 +773,36 @@ def test_reserved_handle_runs_its_first_batch_like_a_warmed_one(frames):
     res.close()
 
 
+def test_reserved_handle_first_batch_config5():
+    """The same on BASELINE config 5's dense frames (a handle reserved for 4500 labelled points issued
+    4.3 x the K6 instructions on its first batch -- frames above the reserved capacity walk their points through L2).
+    Reserved for what these frames hold, the first call executes what a warmed handle's call executes."""
+    board = synth.Board(9, 12, 0.10)
+    clouds, clicks, _, _ = synth.make_batch(4, synth.hdl64(), board, seed=0xC0FFEE, range_m=(2.0, 3.0), yaw_deg=25.0,
+                                            pitch_deg=15.0, roll_deg=30.0)
+    warm = LidarCornersBatch(4, 131072, config5_params(N.default_params()))
+    r0 = warm.extract(clouds, clicks)
+    m_max = max(r.n_black + r.n_white for r in r0)
+    roi_max = max(r.n_roi for r in r0)
+    cold = int(warm.timing().grid_cost_evals_sum)
+    warm.reset_timing()
+    r1 = warm.extract(clouds, clicks)
+    t1 = warm.timing()
+    res = LidarCornersBatch(4, 131072, config5_params(N.default_params()))
+    res.reserve(m_max, roi_max)
+    r2 = res.extract(clouds, clicks)
+    t2 = res.timing()
+    print("config 5: labelled points <= %d, ROI points <= %d; executed K6 evaluations: fresh %d, warmed %d, reserved (first call) %d"
+          % (m_max, roi_max, cold, t1.grid_cost_evals_sum, t2.grid_cost_evals_sum))
+    assert abs(int(t1.grid_cost_evals_sum) - int(t2.grid_cost_evals_sum)) <= 0.10 * t1.grid_cost_evals_sum
+    for a, b, c in zip(r0, r1, r2):
+        assert (a.status, a.grid_index) == (b.status, b.grid_index) == (c.status, c.grid_index)
+        assert tuple(a.theta_t) == tuple(b.theta_t) == tuple(c.theta_t)
+        assert np.array_equal(b.corners_array(), c.corners_array())
+    warm.close()
+    res.close()
+
+
 def test_cluster_size_gates_and_non_finite_points(ob, frames):
     """EuclideanClusterExtraction's [min, max] size gate: when the click's component is inadmissible the
     largest admissible one is taken (plane_index 0); NaN/inf points never reach the clustering."""
@@ -859,6 +900,43 @@ def test_device_records_equal_host_packing():
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
     from lidar_camera_calibration_amd.sharding import verify_records
     verify_records(got, 4096 + np.arange(F))
+    est.close()
+
+
+def test_compact_result_mode_ships_the_gather_records_only():
+    """ILCC_RESULTS_COMPACT (ABI 4, SURVEY.md 8d: 12 * n_corners + 64 result bytes per frame): the batch's stream packs the
+    K9 records and only those come back with the batch -- bit-identical to sharding.pack_records of the full records,
+    which stay in HBM (ilcc_fetch_results) and equal a FULL-mode run of the same frames; both waits work in both modes."""
+    import torch
+    from lidar_camera_calibration_amd.sharding import pack_records, record_floats, verify_records
+    board, lidar = synth.Board(), synth.vlp16()
+    F = 12
+    clouds, clicks, _, _ = synth.make_batch(F, lidar, board, seed=321)
+    clicks[3] = (50.0, 50.0, 50.0)          # nothing in the ROI
+    clouds[7, :, 3] = 40.0                  # flat intensity -> degenerate histogram
+    est = LidarCornersBatch(F, lidar.n_points, N.default_params(), device=0)
+    d_clouds, d_clicks = torch.from_numpy(clouds).cuda(), torch.from_numpy(clicks).cuda()
+    torch.cuda.synchronize()
+    full = est.wait(est.submit_device(d_clouds.data_ptr(), F, lidar.n_points, d_clicks.data_ptr()))
+    want = pack_records(full, F, board.n_corners, tag_base=0)
+    assert want[0, 19] == full[0].n_roi > 0                       # header slot 19 carries n_roi (the handle sizes K2 from it)
+    late = est.wait_compact(est.submit_device(d_clouds.data_ptr(), F, lidar.n_points, d_clicks.data_ptr()))   # FULL mode: packed inside the wait
+    assert np.array_equal(late.view(np.uint32), want.view(np.uint32))
+    est.set_result_mode(N.RESULTS_COMPACT)
+    t = est.submit_device(d_clouds.data_ptr(), F, lidar.n_points, d_clicks.data_ptr())
+    with pytest.raises(Exception):
+        est.set_result_mode(N.RESULTS_FULL)                       # not with a batch in flight
+    rec = est.wait_compact(t)
+    assert rec.shape == (F, record_floats(board.n_corners)) and rec.nbytes == F * 500
+    assert np.array_equal(rec.view(np.uint32), want.view(np.uint32))
+    verify_records(rec, np.arange(F))
+    back = est.fetch_results(0, F)                                # the full records of that batch, read from HBM
+    for a, b in zip(full, back):
+        assert (a.status, a.n_roi, a.n_plane, a.grid_index, a.flags) == (b.status, b.n_roi, b.n_plane, b.grid_index, b.flags)
+        assert tuple(a.theta_t) == tuple(b.theta_t) and np.array_equal(a.corners_array(), b.corners_array())
+    assert len(est.fetch_cloud(0, N.CLOUD_CHESSBOARD)) == full[0].n_plane      # the fetch entries fill the records in themselves
+    res = est.wait(est.submit_device(d_clouds.data_ptr(), F, lidar.n_points, d_clicks.data_ptr()))   # the full wait still works (copy inside)
+    assert all(np.array_equal(a.corners_array(), b.corners_array()) and a.status == b.status for a, b in zip(full, res))
     est.close()
 
 

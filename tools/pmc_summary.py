@@ -1,16 +1,24 @@
-"""Per-kernel means of rocprofv3 --pmc counter passes (counter_collection.csv files under <prefix>*): one CSV row
-per (kernel, grid size) with the mean of every counter over its dispatches.  usage: pmc_summary.py <dir prefix>"""
+"""Per-kernel summary of rocprofv3 --pmc counter passes (counter_collection.csv files under <prefix>*): one CSV row per
+(kernel, grid size) with, for every counter, the MEAN over its dispatches EXCLUDING the first one (the target's warm-up batch:
+a cold dispatch once doubled a committed mean), and `<counter>_min` / `<counter>_max` over the same dispatches so that an
+outlier shows.  usage: pmc_summary.py <dir prefix> [--keep-first]"""
 import csv, glob, sys, collections
 prefix = sys.argv[1]
+keep_first = "--keep-first" in sys.argv
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for path in glob.glob(prefix + "*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(path)):
         name = row.get("Kernel_Name", "")[:60]
         key = (name, row.get("Grid_Size", ""))
-        acc[key][row["Counter_Name"]].append(float(row["Counter_Value"]))
+        acc[key][row["Counter_Name"]].append((int(row.get("Dispatch_Id", "0") or 0), float(row["Counter_Value"])))
 counters = sorted({c for v in acc.values() for c in v})
 w = csv.writer(sys.stdout)
-w.writerow(["kernel", "grid", "dispatches"] + counters)
+w.writerow(["kernel", "grid", "dispatches"] + counters + [c + s for c in counters for s in ("_min", "_max")])
 for (name, grid), v in sorted(acc.items()):
-    n = max(len(x) for x in v.values())
-    w.writerow([name, grid, n] + [("%.6g" % (sum(v[c]) / len(v[c]))) if c in v else "" for c in counters])
+    vals = {}
+    for c, lst in v.items():
+        lst = [x for _, x in sorted(lst)]
+        vals[c] = lst[1:] if (len(lst) > 1 and not keep_first) else lst
+    n = max(len(x) for x in vals.values())
+    w.writerow([name, grid, n] + [("%.6g" % (sum(vals[c]) / len(vals[c]))) if c in vals else "" for c in counters] +
+               [("%.6g" % f(vals[c])) if c in vals else "" for c in counters for f in (min, max)])

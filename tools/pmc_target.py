@@ -1,5 +1,8 @@
-"""Light target for rocprofv3 --pmc / --kernel-trace passes: three synchronous batches (GRID mode), one batch alone on
-the chip each time -- per-dispatch counters of every kernel of the path without bench.py's other legs.
+"""Light target for rocprofv3 --pmc / --kernel-trace passes: four synchronous batches (GRID mode), one batch alone on
+the chip each time -- per-dispatch counters of every kernel of the path without bench.py's other legs.  The FIRST batch
+is a warm-up (tools/pmc_summary.py drops every kernel's first dispatch): round 3's config-5 file averaged a first dispatch in
+that issued 4.3 x the K6 instructions -- its handle was reserved for 4500 labelled points and these frames hold up to ~6 k,
+so the frames above the reserved capacity walked their points through L2 until the handle had grown.
 usage: pmc_target.py [frames_per_batch=512] [config=2|5]      (the batch sizes bench.py runs: 512 / 64)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -25,8 +28,8 @@ else:
     n = 28800
 d_c = torch.from_numpy(clouds).cuda(); d_k = torch.from_numpy(clicks).cuda()
 est = LidarCornersBatch(F, n, params)
-est.reserve(4500 if config == 5 else 2048, 25000 if config == 5 else 2560)   # every dispatch takes the steady-state kernels (ilcc_reserve)
-for _ in range(3):
+est.reserve(8192 if config == 5 else 2048, 25000 if config == 5 else 2560)   # every dispatch takes the steady-state kernels (ilcc_reserve)
+for _ in range(4):
     est.extract_device(d_c.data_ptr(), F, n, d_k.data_ptr())
 t = est.timing()
 print("pmc_target config %d, %d frames: grid_cost %.4f ms, total %.4f ms" % (config, F, t.grid_cost, t.total))
