@@ -88,7 +88,8 @@ struct ilcc_handle {
   double* d_solve = nullptr;   // 3 theta_t + 2 (cost, iterations) for the test entries
   RefineOut* d_refine_io = nullptr;
   uint32_t grid_lds_points = 1024;   // grows with the frames seen (finish()); frames above it take the global-memory path
-  uint32_t cluster_lds_points = 2048;   // K2's LDS capacity in ROI points per frame: grows likewise (<= 4096); larger frames take the multi-workgroup path
+  uint32_t cluster_lds_points = 2048;   // K2's LDS capacity for cell-sorted ROI points per frame: grows likewise (<= 4096); larger frames sort into HBM
+  uint32_t cluster_cells_cap = kClusterCellsMin;   // K2's LDS capacity in occupied cells per frame: grows with what the batches needed
   uint32_t big_grid = 1024;          // workgroups of K2's persistent kernels (4 x the device's CUs)
   bool poisoned = false;             // a failed ilcc_set_params could not restore the device tables: every later call fails
   bool big_armed = false;            // K2's multi-workgroup kernels are launched: set once a frame above the LDS capacity was seen (finish()) or by ilcc_reserve
@@ -321,11 +322,11 @@ int32_t alloc_slot(ilcc_handle* h, Slot& sl) {
   ALLOC(sl.d_bound_sub, sizeof(uint32_t) * mf);
   ALLOC(sl.d_tie_count, sizeof(uint32_t) * mf);
   ALLOC(sl.d_tie_list, sizeof(GridPartial) * (size_t)mf * kTieCap);
-  ALLOC(sl.d_iters, sizeof(unsigned long long) * 3 * kIterSlots);
+  ALLOC(sl.d_iters, sizeof(unsigned long long) * kBatchWords);
 #undef ALLOC
   HIP_TRY(h, hipHostMalloc((void**)&sl.h_res, sizeof(ilcc_result) * mf, hipHostMallocDefault));
   HIP_TRY(h, hipHostMalloc((void**)&sl.h_rec, sizeof(float) * (size_t)mf * (ILCC_RECORD_HEADER + 3 * ILCC_MAX_CORNERS), hipHostMallocDefault));
-  HIP_TRY(h, hipHostMalloc((void**)&sl.h_iters, sizeof(unsigned long long) * 3 * kIterSlots, hipHostMallocDefault));
+  HIP_TRY(h, hipHostMalloc((void**)&sl.h_iters, sizeof(unsigned long long) * kBatchWords, hipHostMallocDefault));
   HIP_TRY(h, hipHostMalloc((void**)&sl.h_off, sizeof(uint64_t) * (mf + 1), hipHostMallocDefault));
   sl.allocated = true;
   return ILCC_OK;
@@ -361,6 +362,7 @@ Ctx make_ctx(ilcc_handle* h, Slot& sl, const float4* d_xyzi, const float* d_clic
   c.uf_hash_head = sl.d_hash_head;
   c.uf_hash_next = sl.d_hash_next;
   c.cluster_lds_points = h->cluster_lds_points;
+  c.cluster_cells_cap = h->cluster_cells_cap;
   c.big_count = sl.d_big;
   c.big_list = sl.d_big + 1;
   c.big_grid = h->big_grid;
@@ -428,6 +430,13 @@ int32_t check_offsets(ilcc_handle* h, const uint64_t* offsets, uint32_t n_frames
 
 int32_t enqueue_impl(ilcc_handle* h, int si, const float4* d_xyzi, const uint64_t* offsets, uint32_t n_frames, const float* d_clicks,
                      bool front_only, bool no_crop);
+
+// K2's workgroup keeps bitmap + per-cell arrays + (up to cluster_lds_points) sorted points in LDS: when the cell arrays have
+// grown large (dense clouds), give up LDS points first -- frames of that size sort into HBM anyway
+void fit_cluster_lds(ilcc_handle* h) {
+  while (cluster_lds_bytes(h->cluster_lds_points, h->cluster_cells_cap) > 150u * 1024u && h->cluster_lds_points > 0)
+    h->cluster_lds_points = h->cluster_lds_points > 512u ? h->cluster_lds_points - 512u : 0u;
+}
 
 uint32_t board_corners(const ilcc_params& p) { return (uint32_t)((p.board_w - 1) * (p.board_h - 1)); }
 size_t trimmed_bytes(uint32_t n_corners) { return offsetof(ilcc_result, corners) + sizeof(float) * 3 * (size_t)n_corners; }
@@ -630,7 +639,7 @@ int32_t enqueue_impl(ilcc_handle* h, int si, const float4* d_xyzi, const uint64_
   } else {
     HIP_TRY(h, copy_results_trimmed(sl.h_res, sl.d_res, n_frames, sl.rec_corners, s));
   }
-  HIP_TRY(h, hipMemcpyAsync(sl.h_iters, sl.d_iters, sizeof(unsigned long long) * 3 * kIterSlots, hipMemcpyDeviceToHost, s));
+  HIP_TRY(h, hipMemcpyAsync(sl.h_iters, sl.d_iters, sizeof(unsigned long long) * kBatchWords, hipMemcpyDeviceToHost, s));
   sl.busy = true;
   return ILCC_OK;
 }
@@ -708,7 +717,6 @@ int32_t finish(ilcc_handle* h, int si, ilcc_result* out, float* out_compact = nu
       m = (uint32_t)r[13] + (uint32_t)r[14];
     }
     if (n_roi > 0 && (uint32_t)n_roi <= (uint32_t)kClusterLdsPointsMax) max_roi = std::max(max_roi, (uint32_t)n_roi);
-    if (n_roi > kClusterLdsPointsMax) h->big_armed = true;
     if (status != ILCC_OK && status != ILCC_AMBIGUOUS) continue;
     max_lab = std::max(max_lab, m);
     evals += (uint64_t)m * (uint64_t)h->p.n_th * h->p.n_ty * h->p.n_tz;
@@ -741,6 +749,14 @@ int32_t finish(ilcc_handle* h, int si, ilcc_result* out, float* out_compact = nu
   // is room for K6 workgroups of other batches
   want = std::min<uint32_t>((uint32_t)kClusterLdsPointsMax, (max_roi + 511u) & ~511u);
   if (want > h->cluster_lds_points) h->cluster_lds_points = want;
+  // ... and for its per-cell arrays: the most occupied cells a frame of this batch needed (+ 1/8), steps of 256.  Frames the
+  // cell grid cannot hold at any capacity (bounding grid too large: un-cropped clouds; more cells than the largest capacity)
+  // arm the multi-workgroup point-level kernels for the batches that follow.
+  const uint64_t cells_needed = sl.h_iters[3 * kIterSlots], ungridded = sl.h_iters[3 * kIterSlots + 1];
+  want = (uint32_t)std::min<uint64_t>((uint64_t)kClusterCellsMax, (cells_needed + cells_needed / 8 + 255u) & ~255ull);
+  if (want > h->cluster_cells_cap) h->cluster_cells_cap = want;
+  if (ungridded > 0 || cells_needed > (uint64_t)kClusterCellsMax) h->big_armed = true;
+  fit_cluster_lds(h);
   return ILCC_OK;
 }
 
@@ -974,7 +990,14 @@ int32_t ilcc_reserve(ilcc_handle* h, uint32_t labelled_points_per_frame, uint32_
   h->grid_lds_points = std::max(h->grid_lds_points, std::max(1024u, lab));
   const uint32_t roi = std::min<uint32_t>((uint32_t)kClusterLdsPointsMax, (std::max(roi_points_per_frame, 1u) + 511u) & ~511u);
   h->cluster_lds_points = std::max(h->cluster_lds_points, std::max((uint32_t)kClusterLdsPointsMin, roi));
-  if (roi_points_per_frame > (uint32_t)kClusterLdsPointsMax) h->big_armed = true;
+  // occupied cells: a cell of side 0.57 tol holds ~4.5 points of a VLP-16 ROI and ~8 of a 64-ring one; a quarter of the
+  // points is a safe capacity (a frame above it takes the slower point-level path once and the handle grows)
+  const uint32_t cells = std::min<uint32_t>((uint32_t)kClusterCellsMax, (roi_points_per_frame / 4u + 255u) & ~255u);
+  h->cluster_cells_cap = std::max(h->cluster_cells_cap, std::max((uint32_t)kClusterCellsMin, cells));
+  // above 32768 points per frame the caller is describing un-cropped clouds (the online caller): their bounding grid does not
+  // fit the cell bitmap -> the multi-workgroup point-level kernels
+  if (roi_points_per_frame > 4u * (uint32_t)kClusterCellsMax) h->big_armed = true;
+  fit_cluster_lds(h);
   return ILCC_OK;
 }
 

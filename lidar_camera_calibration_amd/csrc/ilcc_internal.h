@@ -15,9 +15,9 @@ namespace ilcc {
 constexpr int kCropThreads = 256;      // K1
 constexpr int kCropChunk = 4096;       // points per K1 block
 #ifndef ILCC_K2_THREADS
-#define ILCC_K2_THREADS 1024
+#define ILCC_K2_THREADS 256    // round 4: the clustering runs on cells (k2_cluster.hip); rounds 1-3: 1024 threads and 100 KB of LDS per frame
 #endif
-constexpr int kFrameThreads = ILCC_K2_THREADS;    // K2: one workgroup per frame
+constexpr int kFrameThreads = ILCC_K2_THREADS;    // K2: one workgroup per frame (1024 threads in batches of <= kSmallBatchFrames frames)
 #ifndef ILCC_K3_THREADS
 #define ILCC_K3_THREADS 256    // measured in the pipelined bench: 1024: 229.6 k, 512: 230.4 k, 256: 235.2 k frames/s
 #endif
@@ -65,13 +65,16 @@ constexpr int kTieCap = 256;           // K6 -> K7a: near-tie candidates kept pe
 constexpr float kTieEps = 2e-5f;       // relative cost window of a near-tie (fp32 sums of ~1e3 terms agree to ~1e-6)
 constexpr int kCoverageCellsMax = 1024;   // K7b: board squares tracked by the coverage mask (board_w x board_h)
 constexpr int kIterSlots = 64;         // K6 executed-iteration counters (spread to avoid one hot atomic); [0,64): all points, [64,128): interior-class points, [128,192): (point, tile) evaluations of the box pre-pass
+constexpr int kBatchWords = 3 * kIterSlots + 2;   // Ctx::grid_iters: the K6 counters, then K2's two: [192] most occupied cells a frame needed, [193] frames its cell grid could not hold
 #ifndef ILCC_K2_ALLPAIRS_MAX
 #define ILCC_K2_ALLPAIRS_MAX 256
 #endif
 constexpr int kClusterAllPairsMax = ILCC_K2_ALLPAIRS_MAX;   // K2: above this many points the spatial hash finds neighbours
 constexpr int kClusterHashSize = 1 << 17;    // K2: hash buckets per frame (global memory)
-constexpr int kClusterLdsPointsMax = 4096;   // K2: largest LDS capacity (ROI points per frame) of the one-workgroup path
+constexpr int kClusterLdsPointsMax = 4096;   // K2: largest LDS capacity for the cell-sorted points (ROI points per frame); larger frames keep them in HBM/L2
 constexpr int kClusterLdsPointsMin = 1024;   // K2: smallest (the handle grows it in steps of 512 with the ROI sizes it sees)
+constexpr int kClusterCellsMin = 512;        // K2: occupied cells per frame the LDS arrays hold: smallest ...
+constexpr int kClusterCellsMax = 6144;       // ... and largest capacity (5 words per cell: 120 KiB) -- the handle grows it in steps of 256
 
 struct GridPartial {   // per K6 workgroup best candidate
   float cost;
@@ -125,7 +128,8 @@ struct Ctx {
   uint32_t* uf_count;        // K2 component sizes
   uint32_t* uf_hash_head;    // K2 spatial hash: n_frames x kClusterHashSize bucket heads
   uint32_t* uf_hash_next;    // K2 spatial hash: chain links, one per point
-  uint32_t cluster_lds_points;   // K2: ROI points per frame the one-workgroup LDS path is sized for; larger frames are listed
+  uint32_t cluster_lds_points;   // K2: ROI points per frame whose cell-sorted copy fits the workgroup's LDS; larger frames sort into HBM
+  uint32_t cluster_cells_cap;    // K2: occupied cells per frame the workgroup's LDS arrays hold; frames with more take the point-level path
   uint32_t* big_count;       // K2: number of listed frames of this batch (reset by K1)
   uint32_t* big_list;        // K2: their frame indices
   uint32_t big_grid;         // K2: workgroups of the persistent multi-workgroup kernels
@@ -275,6 +279,7 @@ void launch_pattern_refine_corners(const Ctx& c, hipStream_t s);
 void launch_pattern_refine_test(const Ctx& c, hipStream_t s, RefineOut* d_io);
 // once per (process, device): raise the dynamic-LDS limits of the kernels that need more than 64 KiB
 hipError_t set_kernel_attributes_k2();
+size_t cluster_lds_bytes(uint32_t pts_cap, uint32_t cells_cap);   // K2's dynamic LDS for these capacities
 hipError_t set_kernel_attributes_k6();
 hipError_t set_kernel_attributes_k7();
 // stand-alone local solve on the labelled points of frame 0 (test entry)

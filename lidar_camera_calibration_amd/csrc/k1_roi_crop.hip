@@ -49,7 +49,7 @@ __global__ __launch_bounds__(kCropThreads) void k1_roi_count(Ctx c) {
   if (s == 0) {
     uint32_t* w = reinterpret_cast<uint32_t*>(&c.res[f]);
     for (uint32_t k = threadIdx.x; k < sizeof(ilcc_result) / 4; k += kCropThreads) w[k] = 0u;
-    if (f == 0 && threadIdx.x < 3 * kIterSlots) c.grid_iters[threadIdx.x] = 0ull;
+    if (f == 0 && threadIdx.x < kBatchWords) c.grid_iters[threadIdx.x] = 0ull;   // (kBatchWords <= kCropThreads)
     __syncthreads();
   }
   if (s == 0 && threadIdx.x == 0) {
