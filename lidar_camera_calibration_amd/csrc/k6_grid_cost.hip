@@ -199,7 +199,8 @@ __device__ __forceinline__ Best seed_argmin(const Ctx& c, uint32_t f, uint32_t& 
 
 template <bool OOB, bool VOLUME, bool LDS_POINTS, bool PRUNE, int THREADS>
 __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, float2* s_ij, float* s_hw, Best* s_best,
-                                               uint32_t* s_iters, uint32_t* s_cnt, float* s_ay, float* s_az, uint32_t* s_dead) {
+                                               uint32_t* s_iters, uint32_t* s_cnt, float* s_ay, float* s_az, uint32_t* s_dead,
+                                               uint32_t* s_next) {
   const uint32_t f = blockIdx.y;
   uint32_t k = blockIdx.x;   // theta index (refinement pass: set from the seed below)
   [[maybe_unused]] const unsigned long long t_entry = K6_NOW();
@@ -304,6 +305,7 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
   // prologue must not wait for global loads
   for (int i = threadIdx.x; i < c.p.n_ty; i += THREADS) s_ay[i] = c.ay[i];
   for (int i = threadIdx.x; i < c.p.n_tz; i += THREADS) s_az[i] = c.az[i];
+  if (threadIdx.x == 0) *s_next = 0u;   // the workgroup's tile-chunk counter (see the tile loop)
   __syncthreads();
   [[maybe_unused]] const unsigned long long t_staged = K6_NOW();
 
@@ -688,47 +690,114 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
   // 64 of them at a time, one per lane: the lanes look their tiles up in the pre-pass's bit mask, a ballot gives the ones
   // still alive, and only those are visited (a handful of a wavefront's 25: the loop over dead tiles was a third of the
   // kernel's scalar instructions).
-  constexpr int kWaves = THREADS / ILCC_WAVE;
-  const int per_wave = __builtin_amdgcn_readfirstlane(wid < n_tiles ? (n_tiles - wid + kWaves - 1) / kWaves : 0);
-  const int ntb_s = __builtin_amdgcn_readfirstlane(ntb);
-  for (int k0 = 0; k0 < per_wave; k0 += ILCC_WAVE) {
-    bool alive = false;
-    if (k0 + lane < per_wave) {
-      int q = wid + kWaves * (k0 + lane) + t0;
-      if (q >= n_tiles) q -= n_tiles;
-      alive = !use_box || !((s_dead[q >> 5] >> (q & 31)) & 1u);
-    }
-    unsigned long long todo = __ballot(alive);
-    while (todo) {
-      const int bit = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(todo));
-      todo &= todo - 1ull;
-      int qs = wid + kWaves * (k0 + bit) + t0;
-      if (qs >= n_tiles) qs -= n_tiles;
-      const int tile_a = __builtin_amdgcn_readfirstlane(qs / ntb_s), tile_b = __builtin_amdgcn_readfirstlane(qs - tile_a * ntb_s);
-#ifdef ILCC_K6_TIMING
-      const unsigned long long tt0 = K6_NOW();
-      const uint32_t pd0 = pts_done;
-      const float bc0 = best.cost;
-      const uint32_t bf0 = best.flat;
+  if constexpr (THREADS == kGridThreadsLarge && kGridThreadsLarge != kGridThreads) {
+    // The 512-thread instance (frames of several thousand labelled points, ~1000 tiles per workgroup): which wavefront takes
+    // which tile is decided at run time.  The tiles that survive the pre-pass AND walk far (the candidates around the minimum)
+    // used to fall to whichever wavefront the static interleave gave them, and the workgroup waited at its last barrier for the
+    // unlucky one (16 % of a wavefront's life on BASELINE config 5, tools/dev_k6_timing.py): 23.2 -> 24.0 k frames/s there.  (The
+    // 256-thread instance keeps the static interleave below: with 100 tiles and 2.4 survivors per wavefront the claims cost
+    // more than they balance -- 775 -> 740 k frames/s.)  A wavefront
+    // claims CHUNKS of kChunk tile slots from a counter in LDS; slot n of chunk c is tile (c + n_chunks * n + t0) mod n_tiles,
+    // so neighbouring tiles -- the expensive ones are neighbours -- sit in different chunks, and chunk 0 starts with the tile of
+    // the seed's best translation.  The lanes look their slots up in the pre-pass's bit mask, a ballot gives the ones still
+    // alive, and only those are visited.  The order never changes the result.
+#ifndef ILCC_K6_CHUNK
+#define ILCC_K6_CHUNK 8   // tile slots per claim
 #endif
-      run_tile(tile_a, tile_b, 0.f, 0.f, 0u, Mi);
-#ifdef ILCC_K6_TIMING
-      {
-        const unsigned long long dt = K6_NOW() - tt0;
-        const uint32_t walked = pts_done - pd0;
-        if (walked <= (uint32_t)(2 * kStep) && walked < M) {
-          ++n_rej;
-          t_rej += dt;
-        } else {
-          ++n_surv;
-          t_surv += dt;
-          p_surv += walked;
-          if (walked >= M) ++n_done;
+    constexpr int kChunk = ILCC_K6_CHUNK;
+    static_assert(kChunk >= 1 && kChunk <= ILCC_WAVE, "a chunk is looked up by the lanes of one wavefront");
+    const int n_chunks = __builtin_amdgcn_readfirstlane((n_tiles + kChunk - 1) / kChunk);
+    const int ntb_s = __builtin_amdgcn_readfirstlane(ntb);
+    for (;;) {
+      int cl = 0;
+      if (lane == 0) cl = (int)atomicAdd(s_next, 1u);
+      const int ch = __builtin_amdgcn_readfirstlane(cl);
+      if (ch >= n_chunks) break;
+      bool alive = false;
+      if (lane < kChunk) {
+        const int slot = ch + n_chunks * lane;
+        if (slot < n_tiles) {
+          int q = slot + t0;
+          if (q >= n_tiles) q -= n_tiles;
+          alive = !use_box || !((s_dead[q >> 5] >> (q & 31)) & 1u);
         }
-        (void)bc0;
-        (void)bf0;
       }
+      unsigned long long todo = __ballot(alive);
+      while (todo) {
+        const int bit = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(todo));
+        todo &= todo - 1ull;
+        int qs = ch + n_chunks * bit + t0;
+        if (qs >= n_tiles) qs -= n_tiles;
+        const int tile_a = __builtin_amdgcn_readfirstlane(qs / ntb_s), tile_b = __builtin_amdgcn_readfirstlane(qs - tile_a * ntb_s);
+#ifdef ILCC_K6_TIMING
+        const unsigned long long tt0 = K6_NOW();
+        const uint32_t pd0 = pts_done;
+        const float bc0 = best.cost;
+        const uint32_t bf0 = best.flat;
 #endif
+        run_tile(tile_a, tile_b, 0.f, 0.f, 0u, Mi);
+#ifdef ILCC_K6_TIMING
+        {
+          const unsigned long long dt = K6_NOW() - tt0;
+          const uint32_t walked = pts_done - pd0;
+          if (walked <= (uint32_t)(2 * kStep) && walked < M) {
+            ++n_rej;
+            t_rej += dt;
+          } else {
+            ++n_surv;
+            t_surv += dt;
+            p_surv += walked;
+            if (walked >= M) ++n_done;
+          }
+          (void)bc0;
+          (void)bf0;
+        }
+#endif
+      }
+    }
+  } else {
+    constexpr int kWaves = THREADS / ILCC_WAVE;
+    const int per_wave = __builtin_amdgcn_readfirstlane(wid < n_tiles ? (n_tiles - wid + kWaves - 1) / kWaves : 0);
+    const int ntb_s = __builtin_amdgcn_readfirstlane(ntb);
+    for (int k0 = 0; k0 < per_wave; k0 += ILCC_WAVE) {
+      bool alive = false;
+      if (k0 + lane < per_wave) {
+        int q = wid + kWaves * (k0 + lane) + t0;
+        if (q >= n_tiles) q -= n_tiles;
+        alive = !use_box || !((s_dead[q >> 5] >> (q & 31)) & 1u);
+      }
+      unsigned long long todo = __ballot(alive);
+      while (todo) {
+        const int bit = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(todo));
+        todo &= todo - 1ull;
+        int qs = wid + kWaves * (k0 + bit) + t0;
+        if (qs >= n_tiles) qs -= n_tiles;
+        const int tile_a = __builtin_amdgcn_readfirstlane(qs / ntb_s), tile_b = __builtin_amdgcn_readfirstlane(qs - tile_a * ntb_s);
+#ifdef ILCC_K6_TIMING
+        const unsigned long long tt0 = K6_NOW();
+        const uint32_t pd0 = pts_done;
+        const float bc0 = best.cost;
+        const uint32_t bf0 = best.flat;
+#endif
+        run_tile(tile_a, tile_b, 0.f, 0.f, 0u, Mi);
+#ifdef ILCC_K6_TIMING
+        {
+          const unsigned long long dt = K6_NOW() - tt0;
+          const uint32_t walked = pts_done - pd0;
+          if (walked <= (uint32_t)(2 * kStep) && walked < M) {
+            ++n_rej;
+            t_rej += dt;
+          } else {
+            ++n_surv;
+            t_surv += dt;
+            p_surv += walked;
+            if (walked >= M) ++n_done;
+          }
+          (void)bc0;
+          (void)bf0;
+        }
+#endif
+      }
     }
   }
   [[maybe_unused]] const unsigned long long t_tiles = K6_NOW();
@@ -808,6 +877,7 @@ __global__ __launch_bounds__(THREADS) void k6_grid_cost(Ctx c, float* volume) {
   __shared__ uint32_t s_iters[THREADS / ILCC_WAVE];
   __shared__ uint32_t s_cnt[THREADS / ILCC_WAVE];
   __shared__ uint32_t s_dead[kBoxTilesMax / 32];   // box pre-pass: one bit per tile of the workgroup
+  __shared__ uint32_t s_next;                      // next chunk of tiles to hand to a wavefront
   float2* s_ij = reinterpret_cast<float2*>(smem);
   float* s_hw = reinterpret_cast<float*>(smem + sizeof(float2) * (size_t)c.grid_lds_points);
   float* s_ay = s_hw + c.grid_lds_points;   // n_ty floats
@@ -816,9 +886,9 @@ __global__ __launch_bounds__(THREADS) void k6_grid_cost(Ctx c, float* volume) {
   const uint32_t M = c.walk_limit ? min(Mall, max(c.walk_limit, Mall >> ILCC_SEED_SHIFT)) : Mall;
   (void)M;
   if (Mall <= c.grid_lds_points)   // (k5w_walk_order has laid out every frame of at most kGridLdsPointsMax points)
-    grid_cost_body<OOB, VOLUME, true, PRUNE, THREADS>(c, volume, s_ij, s_hw, s_best, s_iters, s_cnt, s_ay, s_az, s_dead);
+    grid_cost_body<OOB, VOLUME, true, PRUNE, THREADS>(c, volume, s_ij, s_hw, s_best, s_iters, s_cnt, s_ay, s_az, s_dead, &s_next);
   else
-    grid_cost_body<OOB, VOLUME, false, PRUNE, THREADS>(c, volume, s_ij, s_hw, s_best, s_iters, s_cnt, s_ay, s_az, s_dead);
+    grid_cost_body<OOB, VOLUME, false, PRUNE, THREADS>(c, volume, s_ij, s_hw, s_best, s_iters, s_cnt, s_ay, s_az, s_dead, &s_next);
 }
 
 // K5w walk order: the frame's labelled points in the layout k6_grid_cost stages -- [interior | rim | other border], each part

@@ -1,6 +1,6 @@
 """Per-wavefront cycle budget of K6's full pass (s_memtime build): where a workgroup's life goes.
 Build the instrumented library first (tools/build_variant.sh k6timing -DILCC_K6_TIMING) and run on the GPU box:
-    ILCC_HIP_LIB=build/ab/libilcc_hip_k6timing.so python tools/dev_k6_timing.py [frames]"""
+    ILCC_HIP_LIB=build/ab/libilcc_hip_k6timing.so python tools/dev_k6_timing.py [frames] [config=2|5]"""
 import ctypes as C
 import os
 import sys
@@ -9,10 +9,22 @@ import torch
 from lidar_camera_calibration_amd import LidarCornersBatch, synth
 from lidar_camera_calibration_amd import _native as N
 
+import numpy as np
 F = int(sys.argv[1]) if len(sys.argv) > 1 else 128
-board, lidar = synth.Board(), synth.vlp16()
-clouds, clicks, _, _ = synth.make_batch(F, lidar, board, seed=0xC0FFEE)
-est = LidarCornersBatch(F, lidar.n_points, N.default_params(), device=0)
+config = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+params = N.default_params()
+if config == 5:      # BASELINE configs[4], as bench.py --config 5 sets it up
+    board, lidar = synth.Board(9, 12, 0.10), synth.hdl64()
+    clouds, clicks, _, _ = synth.make_batch(F, lidar, board, seed=0xC0FFEE, range_m=(2.0, 3.0), yaw_deg=25.0, pitch_deg=15.0, roll_deg=30.0)
+    params.board_w, params.board_h, params.grid_length = 9, 12, 0.10
+    params.n_th = params.n_ty = params.n_tz = 129
+    params.th_min, params.th_step = -16.0 * np.pi / 180.0, 0.25 * np.pi / 180.0
+    params.ty_min = params.tz_min = -0.10
+    params.ty_step = params.tz_step = 0.10 / 64
+else:
+    board, lidar = synth.Board(), synth.vlp16()
+    clouds, clicks, _, _ = synth.make_batch(F, lidar, board, seed=0xC0FFEE)
+est = LidarCornersBatch(F, lidar.n_points, params, device=0)
 d_c, d_k = torch.from_numpy(clouds).cuda(), torch.from_numpy(clicks).cuda()
 lib = N.lib()
 prof = (C.c_ulonglong * 16)()

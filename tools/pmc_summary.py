@@ -1,10 +1,11 @@
 """Per-kernel summary of rocprofv3 --pmc counter passes (counter_collection.csv files under <prefix>*): one CSV row per
 (kernel, grid size) with, for every counter, the MEAN over its dispatches EXCLUDING the first one (the target's warm-up batch:
 a cold dispatch once doubled a committed mean), and `<counter>_min` / `<counter>_max` over the same dispatches so that an
-outlier shows.  usage: pmc_summary.py <dir prefix> [--keep-first]"""
+outlier shows.  usage: pmc_summary.py <dir prefix> [--keep-first | --drop N]"""
 import csv, glob, sys, collections
 prefix = sys.argv[1]
 keep_first = "--keep-first" in sys.argv
+drop = int(sys.argv[sys.argv.index("--drop") + 1]) if "--drop" in sys.argv else 1
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for path in glob.glob(prefix + "*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(path)):
@@ -18,7 +19,7 @@ for (name, grid), v in sorted(acc.items()):
     vals = {}
     for c, lst in v.items():
         lst = [x for _, x in sorted(lst)]
-        vals[c] = lst[1:] if (len(lst) > 1 and not keep_first) else lst
+        vals[c] = lst[drop:] if (len(lst) > drop and not keep_first) else lst
     n = max(len(x) for x in vals.values())
     w.writerow([name, grid, n] + [("%.6g" % (sum(vals[c]) / len(vals[c]))) if c in vals else "" for c in counters] +
                [("%.6g" % f(vals[c])) if c in vals else "" for c in counters for f in (min, max)])

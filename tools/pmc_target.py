@@ -1,8 +1,8 @@
-"""Light target for rocprofv3 --pmc / --kernel-trace passes: four synchronous batches (GRID mode), one batch alone on
-the chip each time -- per-dispatch counters of every kernel of the path without bench.py's other legs.  The FIRST batch
-is a warm-up (tools/pmc_summary.py drops every kernel's first dispatch): round 3's config-5 file averaged a first dispatch in
-that issued 4.3 x the K6 instructions -- its handle was reserved for 4500 labelled points and these frames hold up to ~6 k,
-so the frames above the reserved capacity walked their points through L2 until the handle had grown.
+"""Light target for rocprofv3 --pmc / --kernel-trace passes: synchronous batches (GRID mode), one batch alone on the chip each
+time -- per-dispatch counters of every kernel of the path without bench.py's other legs.  The FIRST batch (config 5: the first
+two) is a warm-up that tools/pmc_summary.py drops: round 3's config-5 file averaged a first dispatch in that issued 4.3 x the K6
+instructions -- its handle was reserved for 4500 labelled points and these frames hold up to ~5.4 k, so the frames above the
+reserved capacity walked their points through L2 until the handle had grown.
 usage: pmc_target.py [frames_per_batch=512] [config=2|5]      (the batch sizes bench.py runs: 512 / 64)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -28,8 +28,12 @@ else:
     n = 28800
 d_c = torch.from_numpy(clouds).cuda(); d_k = torch.from_numpy(clicks).cuda()
 est = LidarCornersBatch(F, n, params)
-est.reserve(8192 if config == 5 else 2048, 25000 if config == 5 else 2560)   # every dispatch takes the steady-state kernels (ilcc_reserve)
-for _ in range(4):
+# config 2: every dispatch takes the steady-state kernels (ilcc_reserve).  config 5: the handle sizes its K6 staging from the
+# batches it sees, exactly like bench.py's (reserving the maximum, 8192 points = 96 KB per workgroup, would profile a
+# one-workgroup-per-CU full pass the bench never runs): two warm-up batches, tools/gpu_pmc.sh drops them (--drop 2)
+if config != 5:
+    est.reserve(2048, 2560)
+for _ in range(5 if config == 5 else 4):
     est.extract_device(d_c.data_ptr(), F, n, d_k.data_ptr())
 t = est.timing()
 print("pmc_target config %d, %d frames: grid_cost %.4f ms, total %.4f ms" % (config, F, t.grid_cost, t.total))
