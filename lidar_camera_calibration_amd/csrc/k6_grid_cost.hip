@@ -70,7 +70,14 @@ constexpr int kUnroll = ILCC_K6_UNROLL;        // points per lane and block (rou
                                                // frames/s; round 2, two classes, test after every border block only: 2: 245.6 k, 3: 238 k, 4: 227 k)
 constexpr int kStep = kSlices * kUnroll;
 #ifndef ILCC_BOX_SHIFT
-#define ILCC_BOX_SHIFT 5   // box pre-pass: at least 1/32 of the frame's labelled points per tile (and at least Ctx::box_points)
+#define ILCC_BOX_SHIFT 3   // box pre-pass: at least 1/8 of the frame's labelled points per tile (and at least Ctx::box_points).  Round 3: 1/32
+                           // (config 5: 1/16: 15.6 k, 1/32: 15.4 k, 1/64: 13.6 k frames/s).  Measured again in round 4, once the rest of
+                           // the path had become cheaper: config 2 (1 007 points, 100 tiles per workgroup) shift 5 / 4 / 3 / 2 / 1 / 0:
+                           // 776 / 792 / 798 / 770 / 690 / 667 k frames/s
+#endif
+#ifndef ILCC_BOX_SHIFT_LARGE
+#define ILCC_BOX_SHIFT_LARGE 2   // the 512-thread instance (config 5: 4 300 points, 1 089 tiles per workgroup) shift 6 / 5 / 4 / 3 / 2 / 1 / 0:
+                                 // 17.3 / 24.2 / 34.7 / 38.6 / 41.9 / 39.3 / 39.3 k frames/s
 #endif
 #ifndef ILCC_BOX_CHECK
 #define ILCC_BOX_CHECK 4
@@ -209,6 +216,7 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
   const ilcc_result* r = &c.res[f];
   const int lane = lane_id();
   const int wid = __builtin_amdgcn_readfirstlane(wave_id());
+  constexpr int kBoxShift = (THREADS == kGridThreadsLarge && kGridThreadsLarge != kGridThreads) ? ILCC_BOX_SHIFT_LARGE : ILCC_BOX_SHIFT;
   GridPartial* out = &c.partial[(uint64_t)f * c.grid_blocks + blockIdx.x];
   if (r->status != ILCC_OK) {
     if (threadIdx.x == 0) {
@@ -298,7 +306,7 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
     // them: every theta more than a few steps from the minimum) never stages, or reads, the rest.
     const bool box_first = PRUNE && OOB && c.box_points != 0u && nta * ntb <= kBoxTilesMax && M > Mi;   // (= use_box below)
     stage_lo = box_first ? Mi : 0u;
-    stage_hi = box_first ? Mi + min(max(c.box_points, Mfull >> ILCC_BOX_SHIFT), M - Mi) : M;
+    stage_hi = box_first ? Mi + min(max(c.box_points, Mfull >> kBoxShift), M - Mi) : M;
     for (uint32_t sl = stage_lo + threadIdx.x; sl < stage_hi; sl += THREADS) stage_point(sl);
   }
   // (ty, tz) tables in LDS: a cut-short tile lasts about as long as one L2 round trip, so its
@@ -338,7 +346,7 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
       for (int w = threadIdx.x; w < (n_tiles + 31) / 32; w += THREADS) s_dead[w] = 0u;
       if (threadIdx.x == 0) s_cnt[0] = 0u;   // "a tile of this workgroup is still alive" (s_cnt is free until the epilogue)
       __syncthreads();
-      const uint32_t n_pre = min(max(c.box_points, Mfull >> ILCC_BOX_SHIFT), M - Mi);   // the frame's bound grows with its point count: so must the sample that has to exceed it
+      const uint32_t n_pre = min(max(c.box_points, Mfull >> kBoxShift), M - Mi);   // the frame's bound grows with its point count: so must the sample that has to exceed it
       const float lim_box = 0.5f * (1.f + kTieEps) * __uint_as_float(gb_bits);
       const int half = (int)(threadIdx.x & 1u);
       uint32_t wave_evals = 0;   // (point, tile) evaluations this wavefront really did (wave-uniform)

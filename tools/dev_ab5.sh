@@ -1,0 +1,7 @@
+# A/B on BASELINE config 5 (run through gpurun from the repo root): tools/dev_ab5.sh NAME...  -> build/ab/libilcc_hip_NAME.so, resident leg only, twice each
+for V in "$@"; do
+  for R in 1 2; do
+    ILCC_HIP_LIB=$([ "$V" = base ] && echo lidar_camera_calibration_amd/libilcc_hip.so || echo build/ab/libilcc_hip_$V.so) timeout 300 python bench.py --config 5 --steps 10 --warmup 3 --no-cpu-baseline --no-extra-legs 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); r=d['roofline']; print('CONFIG5 $V', round(d['value']), 'full', round(r['full_pass_ms'],4), d['frames_ok'])"
+  done
+done
