@@ -1,4 +1,4 @@
-// K4 plane_frame + K5 gray_zone_hist, fused: one 1024-thread workgroup per frame.
+// K4 plane_frame + K5 gray_zone_hist, fused: one workgroup of kHistThreads (256) threads per frame.
 //
 // K4 replaces LidarCornersEst::transformbyPCA (/root/reference/ilcc2/src/LidarCornersEst.cpp:330-364):
 //   compute3DCentroid, computeCovarianceMatrixNormalized (/N), SelfAdjointEigenSolver
