@@ -307,15 +307,15 @@ def main():
 
     dptrs = [t.data_ptr() for t in d_clouds]
 
-    def warm(ptrs, w_steps):
+    def warm(ptrs, w_steps, host_clicks=None):
         """W steps, then blocks of 5 steps until the median step time of a block is within 2 % of the previous block's
         median and >= 0.3 s have passed (cap: 3 s).  Returns (extra steps, seconds)."""
         t0 = time.perf_counter()
-        run(max(1, w_steps), ptrs)
+        run(max(1, w_steps), ptrs, host_clicks=host_clicks)
         extra, prev = 0, None
         while True:
             ts = [time.perf_counter()]
-            run(5, ptrs, step_times=ts)
+            run(5, ptrs, step_times=ts, host_clicks=host_clicks)
             extra += 5
             med = float(np.median(np.diff(ts)))
             now = time.perf_counter() - t0
@@ -820,7 +820,7 @@ def h2d_inclusive_leg(torch, dist, rec_dev, est, clouds, d_clicks, F, B, FS, n_p
             dt = float(t.item())
         return dt
 
-    run(3, hptrs, host_clicks=hclicks)
+    warm(hptrs, 2, host_clicks=hclicks)      # the same steady-state rule as the resident leg (pinned pages touched, link clocks up)
     dt_copy = timed(lambda: run(n, hptrs, host_clicks=hclicks))
     frames = world * FS * n
     copy = {"value": frames / dt_copy, "ms_per_step": 1e3 * dt_copy / n, "link_GBps_achieved_per_gpu": nbytes * B * n / dt_copy / 1e9}

@@ -671,8 +671,9 @@ def test_config5_dense_64_ring_cloud_fine_grid(ob):
 
 
 def test_large_roi_takes_the_global_memory_paths(ob):
-    """ROI wider than the LDS union-find capacity (16 384 parents) and more labelled points than the
-    K6/K7 LDS stage: the global-memory variants of K2, K6 and K7a must give the oracle's result."""
+    """A 12 x 12 x 12 m ROI over a 64-ring cloud: > 16 384 ROI points in a bounding grid far larger than K2's cell bitmap (the
+    point-level spatial hash in global memory takes the frame: the fresh handle's own workgroup, unarmed) and more labelled
+    points than a fresh handle's K6 / K7 LDS stage: these variants must give the oracle's result."""
     board = synth.Board(9, 12, 0.10)
     rng = np.random.default_rng(21)
     pose = synth.random_pose(rng, range_m=(2.0, 2.3), yaw_deg=10, pitch_deg=8, roll_deg=20)
@@ -704,9 +705,10 @@ def test_large_roi_takes_the_global_memory_paths(ob):
 
 
 def test_large_roi_one_workgroup_and_multi_workgroup_clustering_agree(ob):
-    """K2 above its LDS capacity: a fresh handle has not armed the multi-workgroup kernels (the frame's own workgroup
-    does the work), a reserved / warmed one launches them -- identical clusters, planes and corners, and both equal
-    to the oracle (previous test)."""
+    """K2's three ways through a dense ROI (~12 k points, ~1 300 occupied cells): a fresh handle's cell arrays hold 512 cells,
+    so its first call clusters these frames with the point-level spatial hash (its own workgroup: the multi-workgroup
+    kernels are not armed); its second call, the capacity grown, takes the cell-level path with the sorted points in
+    HBM; a reserved handle takes that path at once -- identical clusters, planes and corners (and the oracle's: previous test)."""
     board = synth.Board(9, 12, 0.10)
     rng = np.random.default_rng(33)
     clouds, clicks = [], []
@@ -722,11 +724,11 @@ def test_large_roi_one_workgroup_and_multi_workgroup_clustering_agree(ob):
     p.ty_min = p.tz_min = -0.04
     p.ty_step = p.tz_step = 0.01
     cold = LidarCornersBatch(3, 131072, p)
-    r_cold = cold.extract(clouds, clicks)            # unarmed: one workgroup per large frame
-    r_warm = cold.extract(clouds, clicks)            # the handle has seen n_roi > 4096: multi-workgroup kernels
+    r_cold = cold.extract(clouds, clicks)            # more occupied cells than a fresh handle's 512: point-level hash, unarmed
+    r_warm = cold.extract(clouds, clicks)            # capacity grown: components on cells, sorted points in HBM
     res = LidarCornersBatch(3, 131072, p)
     res.reserve(4500, 25000)
-    r_res = res.extract(clouds, clicks)              # armed up front
+    r_res = res.extract(clouds, clicks)              # cell capacity reserved up front (25 000 ROI points also arm the multi-workgroup kernels: unused here)
     assert min(r.n_roi for r in r_cold) > 4096
     for a, b, c in zip(r_cold, r_warm, r_res):
         for r in (b, c):
@@ -825,6 +827,55 @@ def test_cluster_size_gates_and_non_finite_points(ob, frames):
         if o.status in (N.OK, N.AMBIGUOUS):
             assert np.abs(r.corners_array() - ob.result_corners(o)).max() < 1e-6
         e.close()
+
+
+def test_cluster_threshold_geometry_matches_the_oracle(ob):
+    """K2 builds its components on cells of side 0.57 tol (a cell is a clique; neighbours are looked for within +-2 cells per
+    axis): geometry made to sit on those thresholds.  Clumps of coincident points whose mutual distances straddle the 0.12 m
+    tolerance by 1e-5 m (along an axis, along face and space diagonals, across the 2-cell reach), points ON cell borders of the
+    bounding grid, a chain that only holds together through near-threshold links -- 24 ragged frames, each compared point for
+    point with the oracle's BFS clustering of the same ROI cloud."""
+    rng = np.random.default_rng(2024)
+    tol = 0.12
+    frames, clicks = [], []
+    dirs = [np.array(d, np.float64) / np.linalg.norm(d) for d in ((1, 0, 0), (0, 1, 0), (0, 0, 1), (1, 1, 0), (1, 0, 1), (0, 1, 1), (1, 1, 1),
+                                                                    (1, -1, 1), (2, 1, 0), (1, 2, 2), (-1, 1, 2), (3, 1, 2))]
+    for t in range(24):
+        base = np.array([2.5, 0.0, 0.0]) + rng.uniform(-0.2, 0.2, 3)
+        pts = []
+        # a chain of clumps: link k is just inside (even k) or just outside (odd k) the tolerance
+        at = base.copy()
+        for k in range(10):
+            n = int(rng.integers(25, 60))
+            pts.append(np.repeat(at[None], n, 0) + (rng.uniform(-1e-4, 1e-4, (n, 3)) if k % 3 == 0 else 0.0))
+            d = dirs[(t + k) % len(dirs)]
+            at = at + d * (tol + (1e-5 if k % 2 else -1e-5) + 2e-4 * (k % 3 == 0))   # (the jittered clumps need a little more room)
+        # points on the cell borders of a 0.0684 m lattice anchored at the cloud's minimum, and a dense sheet
+        lat = base + np.array([-0.6, -0.6, -0.3]) + 0.57 * tol * np.stack(np.meshgrid(np.arange(9), np.arange(9), np.arange(3), indexing="ij"), -1).reshape(-1, 3)
+        pts.append(lat)
+        sheet = base + np.array([0.3, 0.0, 0.0]) + np.stack([np.zeros(400), rng.uniform(-0.4, 0.4, 400), rng.uniform(-0.3, 0.3, 400)], 1)
+        pts.append(sheet)
+        xyz = np.concatenate(pts).astype(np.float32)
+        cloud = np.concatenate([xyz, np.full((len(xyz), 1), 40.0, np.float32)], 1)
+        frames.append(cloud[rng.permutation(len(cloud))])
+        clicks.append((base if t % 2 else base + np.array([0.3, 0.0, 0.0])).astype(np.float32))
+    off = np.concatenate([[0], np.cumsum([len(f) for f in frames])]).astype(np.uint64)
+    p = N.default_params()
+    p.cluster_min = 20
+    e = LidarCornersBatch(len(frames), int(off[-1]), p)
+    res = e.extract(np.concatenate(frames), np.stack(clicks), offsets=off)
+    op = ob.default_params()
+    op.cluster_min = 20
+    sizes = set()
+    for f, cloud in enumerate(frames):
+        roi = cloud[ob.roi_crop(cloud, clicks[f], op)]
+        idx, _ = ob.cluster(roi, clicks[f], op)
+        got = e.fetch_cloud(f, N.CLOUD_CLUSTER)
+        assert res[f].n_roi == len(roi) and res[f].n_cluster == len(idx), (f, res[f].n_cluster, len(idx))
+        assert np.array_equal(got, roi[idx]), f
+        sizes.add(len(idx))
+    assert len(sizes) > 3            # the near-threshold links really produce different partitions
+    e.close()
 
 
 def test_online_caller_get_chessboard_by_point(ob):
@@ -965,10 +1016,10 @@ def test_near_tie_is_ordered_like_the_fp64_oracle(ob):
         assert np.abs(r.corners_array() - ob.result_corners(ref)).max() < 1e-6
 
 
-def test_sparse_wide_roi_takes_the_hashed_lds_cell_lists(ob):
-    """K2's fourth neighbour search: <= 4096 ROI points whose bounding box needs more than 16 384 cells (a wide
-    ROI over a thinned cloud) -- the hashed-bucket LDS cell lists instead of the direct cell grid.  Stage counts and
-    the cluster cloud must equal the oracle's."""
+def test_sparse_wide_roi_takes_the_point_level_hash(ob):
+    """<= 4096 ROI points whose bounding grid is far larger than K2's cell bitmap (a 12 x 12 x 6 m ROI over a thinned cloud:
+    ~2.7 M cells of 0.068 m against 96 k bits): the frame falls back to the point-level spatial hash in global memory.
+    Stage counts and the cluster cloud must equal the oracle's."""
     board = synth.Board()
     pose = synth.pose_from_fixture(1)
     cloud = synth.make_frame(synth.vlp16(), board, pose, 11)
@@ -990,7 +1041,7 @@ def test_sparse_wide_roi_takes_the_hashed_lds_cell_lists(ob):
     o, chess, pca = ob.extract(thin, click, op, want_clouds=True)
     assert 256 < r.n_roi <= 4096, r.n_roi
     ext = thin[:, :3].max(0) - thin[:, :3].min(0)
-    assert np.prod(np.floor(np.minimum(ext, [12, 12, 6]) / 0.12) + 1) > 16384      # the direct grid does not fit
+    assert np.prod(np.floor(np.minimum(ext, [12, 12, 6]) / (0.57 * 0.12)) + 5) > 96 * 1024      # the cell bitmap does not hold it
     assert (r.status, r.n_roi, r.n_cluster, r.n_plane) == (o.status, o.n_roi, o.n_cluster, o.n_plane)
     assert r.n_cluster >= 100 and len(got) == r.n_cluster
     if r.status in (N.OK, N.AMBIGUOUS):
