@@ -14,5 +14,5 @@ for C in "SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE S
   timeout 900 rocprofv3 --kernel-trace --pmc $C --output-format csv -d ${P}_$N -- python $R/tools/pmc_target.py $F $CFG 2>&1 | grep pmc_target
 done
 cd $R
-python tools/pmc_summary.py ${P}_ --drop $([ "$CFG" = 5 ] && echo 2 || echo 1) > gpurun_out/${TAG}_pmc_cfg${CFG}_${F}f.csv
+python tools/pmc_summary.py ${P}_ > gpurun_out/${TAG}_pmc_cfg${CFG}_${F}f.csv
 cat gpurun_out/${TAG}_pmc_cfg${CFG}_${F}f.csv | cut -c1-260

@@ -28,12 +28,11 @@ else:
     n = 28800
 d_c = torch.from_numpy(clouds).cuda(); d_k = torch.from_numpy(clicks).cuda()
 est = LidarCornersBatch(F, n, params)
-# config 2: every dispatch takes the steady-state kernels (ilcc_reserve).  config 5: the handle sizes its K6 staging from the
-# batches it sees, exactly like bench.py's (reserving the maximum, 8192 points = 96 KB per workgroup, would profile a
-# one-workgroup-per-CU full pass the bench never runs): two warm-up batches, tools/gpu_pmc.sh drops them (--drop 2)
-if config != 5:
-    est.reserve(2048, 2560)
-for _ in range(5 if config == 5 else 4):
+# every dispatch takes the steady-state kernels: the capacities are reserved exactly as bench.py reserves them (config 5:
+# 6000 labelled points = 72 KB per K6 workgroup, two per CU like the bench's; reserving the maximum, 8192 = 96 KB, would
+# profile a one-workgroup-per-CU full pass the bench never runs).  The first batch is still a warm-up (pmc_summary.py drops it).
+est.reserve(6000, 20000) if config == 5 else est.reserve(2048, 2560)
+for _ in range(4):
     est.extract_device(d_c.data_ptr(), F, n, d_k.data_ptr())
 t = est.timing()
 print("pmc_target config %d, %d frames: grid_cost %.4f ms, total %.4f ms" % (config, F, t.grid_cost, t.total))
