@@ -50,6 +50,8 @@ struct Slot {
   uint32_t* d_tie_count = nullptr;
   GridPartial* d_tie_list = nullptr;
   unsigned long long* d_iters = nullptr;
+  uint32_t *d_tri_alive = nullptr, *d_tri_mask = nullptr;   // K6's common pre-pass per (frame, triple of thetas): state word, rejected-tile mask
+  size_t tri_alive_cap = 0, tri_mask_cap = 0;
   float* d_rec = nullptr;    // K9 records of the batch (ILCC_RESULTS_COMPACT): max_frames x (ILCC_RECORD_HEADER + 3 ILCC_MAX_CORNERS) floats
   // pinned host staging
   float* h_rec = nullptr;
@@ -242,7 +244,7 @@ int32_t upload_tables(ilcc_handle* h) {
 }
 
 void free_slot(Slot& sl) {
-  void* bufs[] = {sl.d_rec, sl.d_xyzi, sl.d_clicks, sl.d_off, sl.d_res, sl.d_roi, sl.d_cluster, sl.d_board, sl.d_pca, sl.d_optim,
+  void* bufs[] = {sl.d_tri_alive, sl.d_tri_mask, sl.d_rec, sl.d_xyzi, sl.d_clicks, sl.d_off, sl.d_res, sl.d_roi, sl.d_cluster, sl.d_board, sl.d_pca, sl.d_optim,
                   sl.d_yz, sl.d_walk_yz, sl.d_walk_lab, sl.d_walk_mi, sl.d_walk_nrim, sl.d_lab, sl.d_cls, sl.d_nlab, sl.d_walk, sl.d_counts, sl.d_parent, sl.d_count, sl.d_hash_head, sl.d_hash_next, sl.d_big, sl.d_partial, sl.d_partial2, sl.d_partial3, sl.d_partial4, sl.d_masks,
                   sl.d_solverec, sl.d_bound, sl.d_bound_sub, sl.d_iters, sl.d_tie_count, sl.d_tie_list};
   for (void* b : bufs)
@@ -598,6 +600,47 @@ int32_t enqueue_impl(ilcc_handle* h, int si, const float4* d_xyzi, const uint64_
     // The FULL passes of different slots are chained so that they never share the chip (their HIP-event
     // durations stay clean and they do not fight for LDS); the seed and refinement passes above are small,
     // latency-bound launches and are left free to overlap with another batch's full pass, like K2/K3/K7.
+#ifndef ILCC_BOX_POINTS
+#define ILCC_BOX_POINTS 48   // 16: 461 k, 32: 485 k, 48: 487 k, 64: 484 k, 96: 474 k frames/s when it was introduced; with the one-tile anchor 32: 578 k, 48: 590 k
+#endif
+    // box pre-pass (k6_grid_cost.hip): its monotonicity argument needs a tile's box narrower than one square on both axes
+    full.box_points = (prune && 3.0 * h->p.ty_step < 0.9 * h->p.grid_length && 3.0 * h->p.tz_step < 0.9 * h->p.grid_length) ? (uint32_t)ILCC_BOX_POINTS : 0u;
+#ifndef ILCC_K6_TRIPLE
+#define ILCC_K6_TRIPLE 1
+#endif
+    {
+      // k6_triple_prepass: one box pre-pass for three consecutive thetas, launched HERE -- behind the anchor (it needs the frame's
+      // bound), in front of the wait for the previous batch's full pass, so it runs beside that pass like the other small
+      // launches.  Conditions: the per-theta pre-pass's own and, for the points it leaves out, every translation of the
+      // tables keeping the board's centre inside the board.
+      const double g = h->p.grid_length;
+      const double ty_hi = h->p.ty_min + (h->p.n_ty - 1) * h->p.ty_step, tz_hi = h->p.tz_min + (h->p.n_tz - 1) * h->p.tz_step;
+      const bool centre_in = h->p.ty_min > -0.45 * h->p.board_w * g && ty_hi < 0.45 * h->p.board_w * g && h->p.tz_min > -0.45 * h->p.board_h * g &&
+                             tz_hi < 0.45 * h->p.board_h * g;
+      const uint32_t n_tiles = (uint32_t)(((h->p.n_ty + 3) / 4) * ((h->p.n_tz + 3) / 4));
+      if (ILCC_K6_TRIPLE && full.box_points != 0u && h->p.n_th >= 3 && centre_in && n_tiles <= 4096u) {
+        full.tri_count = (uint32_t)((h->p.n_th + 2) / 3);
+        full.tri_words = (n_tiles + 31u) / 32u;
+        const size_t need_alive = (size_t)n_frames * full.tri_count, need_mask = need_alive * full.tri_words;
+        if (need_alive > sl.tri_alive_cap) {
+          if (sl.d_tri_alive) (void)hipFree(sl.d_tri_alive);
+          sl.d_tri_alive = nullptr;
+          sl.tri_alive_cap = 0;
+          HIP_TRY(h, hipMalloc((void**)&sl.d_tri_alive, sizeof(uint32_t) * need_alive));
+          sl.tri_alive_cap = need_alive;
+        }
+        if (need_mask > sl.tri_mask_cap) {
+          if (sl.d_tri_mask) (void)hipFree(sl.d_tri_mask);
+          sl.d_tri_mask = nullptr;
+          sl.tri_mask_cap = 0;
+          HIP_TRY(h, hipMalloc((void**)&sl.d_tri_mask, sizeof(uint32_t) * need_mask));
+          sl.tri_mask_cap = need_mask;
+        }
+        launch_triple_prepass(full, s, sl.d_tri_alive, sl.d_tri_mask);
+        full.tri_alive = sl.d_tri_alive;
+        full.tri_mask = sl.d_tri_mask;
+      }
+    }
     if (!ev1) HIP_TRY(h, hipEventRecord(sl.k6ev[1], s));
     if (!ev2) HIP_TRY(h, hipEventRecord(sl.k6ev[2], s));
     HIP_TRY(h, hipEventRecord(sl.ev[7], s));
@@ -608,11 +651,6 @@ int32_t enqueue_impl(ilcc_handle* h, int si, const float4* d_xyzi, const uint64_
       HIP_TRY(h, hipStreamWaitEvent(s, h->slots[h->k6_last].k6_done, 0));
     HIP_TRY(h, hipEventRecord(sl.ev[8], s));
     full.tie_count = sl.d_tie_count;
-#ifndef ILCC_BOX_POINTS
-#define ILCC_BOX_POINTS 48   // 16: 461 k, 32: 485 k, 48: 487 k, 64: 484 k, 96: 474 k frames/s when it was introduced; with the one-tile anchor 32: 578 k, 48: 590 k
-#endif
-    // box pre-pass (k6_grid_cost.hip): its monotonicity argument needs a tile's box narrower than one square on both axes
-    full.box_points = (prune && 3.0 * h->p.ty_step < 0.9 * h->p.grid_length && 3.0 * h->p.tz_step < 0.9 * h->p.grid_length) ? (uint32_t)ILCC_BOX_POINTS : 0u;
     launch_grid_cost(full, s, /*use_oob=*/1, nullptr, prune);
     HIP_TRY(h, hipEventRecord(sl.k6_done, s));
     h->k6_last = si;

@@ -149,6 +149,10 @@ struct Ctx {
   GridPartial* tie_list;     // n_frames x kTieCap: cost (fp32), d2, flat
   unsigned long long* grid_iters;  // executed K6 work in counts of grid_cost_evals_per_count() evaluations, for the VALU rate
   uint32_t box_points;             // K6 full pass: border-class walk positions the box pre-pass looks at per tile (0: no pre-pass)
+  // K6 full pass behind k6_triple_prepass (nullptr: no common pre-pass): per (frame, triple of thetas) a state word and a bit mask
+  const uint32_t* tri_alive;
+  const uint32_t* tri_mask;
+  uint32_t tri_count, tri_words;   // triples per frame = ceil(n_th / 3); mask words per triple = ceil(tiles / 32)
   // seeding pass of the branch-and-bound (a decimated subset of the same grid, evaluated first)
   const GridPartial* seed_partial; // n_frames x seed_blocks, nullptr when this launch is the seed pass / unused
   uint32_t seed_blocks;
@@ -269,6 +273,7 @@ void launch_plane_frame_hist(const Ctx& c, hipStream_t s);
 void launch_walk_order(const Ctx& c, hipStream_t s);   // K5w (k6_grid_cost.hip): before any launch_grid_cost on the frames
 void launch_grid_cost(const Ctx& c, hipStream_t s, int32_t use_oob, float* cost_volume /*nullable*/,
                       bool prune);
+void launch_triple_prepass(const Ctx& c, hipStream_t s, uint32_t* tri_alive, uint32_t* tri_mask);   // in front of the full pass (c.tri_count, c.tri_words set)
 uint32_t grid_cost_evals_per_count();   // (point, candidate) evaluations behind one count of Ctx::grid_iters
 void launch_refine_corners(const Ctx& c, hipStream_t s);
 void launch_pack_records(const ilcc_result* d_res, uint32_t n_frames, uint32_t n_corners, uint32_t tag_base, float* d_out,

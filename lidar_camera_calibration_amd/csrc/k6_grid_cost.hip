@@ -169,9 +169,11 @@ __device__ __forceinline__ void accumulate_interior(const PointTerms& p, float a
 
 // Box pre-pass, one point against one tile: adds to lb a lower bound of the point's term (cost / 2, either colour phase) for
 // EVERY translation in [alo, ahi] x [zlo, zhi] -- see the pre-pass in grid_cost_body for the argument.
-__device__ __forceinline__ void box_term(float pi, float pj, float alo, float ahi, float zlo, float zhi, float Wh, float Hh,
-                                         float delta, float& lb) {
-  const float i_lo = pi + alo, i_hi = pi + ahi, j_lo = pj + zlo, j_hi = pj + zhi;
+// (pi_lo, pi_hi), (pj_lo, pj_hi): the point's rotated coordinates -- one value each (lo == hi) in a workgroup's own pre-pass, the
+// extremes over the three thetas of a TRIPLE in k6_grid_cost_triple's common pre-pass (fl(p + a) is monotone in p as in a).
+__device__ __forceinline__ void box_term(float pi_lo, float pi_hi, float pj_lo, float pj_hi, float alo, float ahi, float zlo, float zhi,
+                                         float Wh, float Hh, float delta, float& lb) {
+  const float i_lo = pi_lo + alo, i_hi = pi_hi + ahi, j_lo = pj_lo + zlo, j_hi = pj_hi + zhi;
   const float ui_lo = fabsf(i_lo - Wh) - Wh, ui_hi = fabsf(i_hi - Wh) - Wh;
   const float uj_lo = fabsf(j_lo - Hh) - Hh, uj_hi = fabsf(j_hi - Hh) - Hh;
   const bool out_all = fmaxf(fminf(ui_lo, ui_hi), fminf(uj_lo, uj_hi)) >= 0.f;   // out of the board everywhere in the box
@@ -207,9 +209,10 @@ __device__ __forceinline__ Best seed_argmin(const Ctx& c, uint32_t f, uint32_t& 
 template <bool OOB, bool VOLUME, bool LDS_POINTS, bool PRUNE, int THREADS>
 __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, float2* s_ij, float* s_hw, Best* s_best,
                                                uint32_t* s_iters, uint32_t* s_cnt, float* s_ay, float* s_az, uint32_t* s_dead,
-                                               uint32_t* s_next) {
+                                               uint32_t* s_next, const uint32_t kblk) {
+  // kblk: this workgroup's index within the frame (= blockIdx.x)
   const uint32_t f = blockIdx.y;
-  uint32_t k = blockIdx.x;   // theta index (refinement pass: set from the seed below)
+  uint32_t k = kblk;   // theta index (refinement pass: set from the seed below)
   [[maybe_unused]] const unsigned long long t_entry = K6_NOW();
   [[maybe_unused]] unsigned long long t_rej = 0, t_surv = 0, n_rej = 0, n_surv = 0, n_done = 0, p_surv = 0;
   [[maybe_unused]] unsigned long long n_tests = 0, alive_sum = 0, alive_le4 = 0, alive_le2 = 0;   // bound tests after the first one
@@ -217,8 +220,20 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
   const int lane = lane_id();
   const int wid = __builtin_amdgcn_readfirstlane(wave_id());
   constexpr int kBoxShift = (THREADS == kGridThreadsLarge && kGridThreadsLarge != kGridThreads) ? ILCC_BOX_SHIFT_LARGE : ILCC_BOX_SHIFT;
-  GridPartial* out = &c.partial[(uint64_t)f * c.grid_blocks + blockIdx.x];
-  if (r->status != ILCC_OK) {
+  GridPartial* out = &c.partial[(uint64_t)f * c.grid_blocks + kblk];
+  // full pass behind k6_triple_prepass: tiles the pre-pass common to this theta's triple has already rejected (a bit mask in
+  // global memory), or nothing at all to do when it rejected them all
+  const uint32_t* s_dead0 = nullptr;
+  bool triple_dead = false;
+  if constexpr (PRUNE && OOB && LDS_POINTS && !VOLUME) {
+    if (c.tri_alive != nullptr) {
+      const uint32_t tr = (uint32_t)f * c.tri_count + kblk / 3u;
+      const uint32_t st = c.tri_alive[tr];   // 0: every tile dead, 1: mask valid, 2: no common pre-pass ran for this triple
+      triple_dead = st == 0u;
+      if (st == 1u) s_dead0 = c.tri_mask + (uint64_t)tr * c.tri_words;
+    }
+  }
+  if (r->status != ILCC_OK || triple_dead) {
     if (threadIdx.x == 0) {
       out->cost = __builtin_inff();
       out->d2 = 0xFFFFFFFFu;
@@ -252,7 +267,7 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
         // refinement pass: every candidate within +-radius theta steps and the 8 x 8 (ty, tz) window
         // around the seed argmin -> the frame's bound is (nearly always) the true minimum before the
         // full pass starts, which is what lets the full pass cut almost every tile after 8 points
-        const int kc = c.seed_off_th + k2 * c.seed_stride_th + (int)blockIdx.x - c.refine_radius_th;
+        const int kc = c.seed_off_th + k2 * c.seed_stride_th + (int)kblk - c.refine_radius_th;
         k = (uint32_t)__builtin_amdgcn_readfirstlane(min(max(kc, 0), c.p.n_th - 1));
         if (c.refine_window == 1) {        // 8 x 8 translations around the argmin
           a_org = __builtin_amdgcn_readfirstlane(min(max(sa - kTile, 0), max(n_ty - 2 * kTile, 0)));
@@ -343,7 +358,7 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
   if constexpr (PRUNE && LDS_POINTS && OOB) {
     use_box = c.box_points != 0u && n_tiles <= kBoxTilesMax && M > Mi;
     if (use_box) {
-      for (int w = threadIdx.x; w < (n_tiles + 31) / 32; w += THREADS) s_dead[w] = 0u;
+      for (int w = threadIdx.x; w < (n_tiles + 31) / 32; w += THREADS) s_dead[w] = s_dead0 ? s_dead0[w] : 0u;
       if (threadIdx.x == 0) s_cnt[0] = 0u;   // "a tile of this workgroup is still alive" (s_cnt is free until the epilogue)
       __syncthreads();
       const uint32_t n_pre = min(max(c.box_points, Mfull >> kBoxShift), M - Mi);   // the frame's bound grows with its point count: so must the sample that has to exceed it
@@ -366,21 +381,23 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
         // (the sum only grows: a wavefront whose 32 tiles are all beaten already stops looking at further points -- most
         // wavefronts, far from the minimum, after the first few)
         float lb = 0.f, both = 0.f;
-        const uint32_t wave_tiles = (uint32_t)max(0, min(ILCC_WAVE / 2, n_tiles - (q0 + wid * (ILCC_WAVE / 2))));
-        for (uint32_t u0 = 0; u0 < n_pre; u0 += 2u * kBoxCheck) {
+        // tiles the triple's common pre-pass has rejected are not looked at again (a tile's bit is only ever set by its own lane)
+        const bool todo = q < n_tiles && !((s_dead[q >> 5] >> (q & 31)) & 1u);
+        const uint32_t wave_tiles = (uint32_t)__popcll(__ballot(todo && half == 0));
+        for (uint32_t u0 = 0; wave_tiles != 0u && u0 < n_pre; u0 += 2u * kBoxCheck) {
           wave_evals += wave_tiles * min(2u * kBoxCheck, n_pre - u0);
 #pragma unroll
           for (uint32_t d = 0; d < (uint32_t)kBoxCheck; ++d) {
             const uint32_t u = u0 + 2u * d + (uint32_t)half;
-            if (u < n_pre) {
+            if (u < n_pre && todo) {
               const float2 v = s_ij[Mi + u];
-              box_term(v.x, v.y, alo, ahi, zlo, zhi, Wh, Hh, delta2, lb);
+              box_term(v.x, v.x, v.y, v.y, alo, ahi, zlo, zhi, Wh, Hh, delta2, lb);
             }
           }
           both = lb + __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(lb), 0xB1 /*quad_perm [1,0,3,2]*/, 0xf, 0xf, false));
-          if (__ballot(q < n_tiles && !(both * kBoxSafety > lim_box)) == 0ull) break;
+          if (__ballot(todo && !(both * kBoxSafety > lim_box)) == 0ull) break;
         }
-        if (half == 0 && q < n_tiles) {
+        if (half == 0 && todo) {
           if (both * kBoxSafety > lim_box)
             atomicOr(&s_dead[q >> 5], 1u << (q & 31));
           else
@@ -851,7 +868,7 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
 #ifdef ILCC_K6_TIMING
   if (lane == 0 && c.tie_count != nullptr) {   // the full pass only
     const unsigned long long t_end = K6_NOW();
-    const uint32_t w = ((f * c.grid_blocks + blockIdx.x) * (THREADS / ILCC_WAVE) + (uint32_t)wid) & (kProfWaves - 1);
+    const uint32_t w = ((f * c.grid_blocks + kblk) * (THREADS / ILCC_WAVE) + (uint32_t)wid) & (kProfWaves - 1);
     unsigned long long* o = k6_prof + (size_t)w * kProfWords;
     o[0] = 1ull;
     o[1] = t_end - t_entry;
@@ -894,9 +911,136 @@ __global__ __launch_bounds__(THREADS) void k6_grid_cost(Ctx c, float* volume) {
   const uint32_t M = c.walk_limit ? min(Mall, max(c.walk_limit, Mall >> ILCC_SEED_SHIFT)) : Mall;
   (void)M;
   if (Mall <= c.grid_lds_points)   // (k5w_walk_order has laid out every frame of at most kGridLdsPointsMax points)
-    grid_cost_body<OOB, VOLUME, true, PRUNE, THREADS>(c, volume, s_ij, s_hw, s_best, s_iters, s_cnt, s_ay, s_az, s_dead, &s_next);
+    grid_cost_body<OOB, VOLUME, true, PRUNE, THREADS>(c, volume, s_ij, s_hw, s_best, s_iters, s_cnt, s_ay, s_az, s_dead, &s_next, blockIdx.x);
   else
-    grid_cost_body<OOB, VOLUME, false, PRUNE, THREADS>(c, volume, s_ij, s_hw, s_best, s_iters, s_cnt, s_ay, s_az, s_dead, &s_next);
+    grid_cost_body<OOB, VOLUME, false, PRUNE, THREADS>(c, volume, s_ij, s_hw, s_best, s_iters, s_cnt, s_ay, s_az, s_dead, &s_next, blockIdx.x);
+}
+
+// k6_triple_prepass (round 4): ONE box pre-pass for three consecutive thetas, in front of the full pass.  71 % of the (frame,
+// theta) workgroups of the full pass die in their own box pre-pass -- staging, tables, three barriers, ~450 instructions per
+// wavefront each: 30 % of the kernel -- and a theta step moves a point by less than a third of a tile's width.  Every pre-pass
+// point is rotated by all three thetas (the term's own fp32 expressions) and the box bound takes the extremes: i_lo from the
+// smallest rotated coordinate and the box's lowest translation, i_hi from the largest and the highest.  fl(p + a) is monotone
+// in p as in a, so [i_lo, i_hi] contains the interval each theta's own pre-pass uses: the bound is a lower bound for all 3 x 16
+// candidates by box_term's argument unchanged (a point whose three images lie more than half a square apart on an axis is left
+// out; the interval stays far narrower than a board).  Output per (frame, triple): a state word -- 0: every tile rejected (the
+// three full-pass workgroups exit on their first instructions), 1: a bit mask of the rejected tiles follows (their own
+// pre-pass starts from it and only looks at the rest), 2: no common pre-pass (conditions not met) -- and the mask.
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k6_triple_prepass(Ctx c, uint32_t* tri_alive, uint32_t* tri_mask) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  __shared__ uint32_t s_iters[THREADS / ILCC_WAVE];
+  __shared__ uint32_t s_dead3[kBoxTilesMax / 32];
+  __shared__ uint32_t s_any;
+  constexpr int kBoxShift = (THREADS == kGridThreadsLarge && kGridThreadsLarge != kGridThreads) ? ILCC_BOX_SHIFT_LARGE : ILCC_BOX_SHIFT;
+  const uint32_t f = blockIdx.y;
+  const int k0 = 3 * (int)blockIdx.x, nk = min(3, c.p.n_th - k0);
+  const uint32_t tr = f * c.tri_count + blockIdx.x;
+  const uint32_t Mall = c.n_lab[f];
+  const bool lds = Mall <= c.grid_lds_points;
+  const int n_ty = c.p.n_ty, n_tz = c.p.n_tz;
+  const int nta = (n_ty + kTile - 1) / kTile, ntb = (n_tz + kTile - 1) / kTile, n_tiles = nta * ntb;
+  const uint32_t Mi = lds ? c.walk_mi[f] : 0u;
+  // (every condition is uniform over the workgroup)
+  if (!(c.res[f].status == ILCC_OK && lds && nk > 1 && c.box_points != 0u && n_tiles <= kBoxTilesMax && Mall > Mi)) {
+    if (threadIdx.x == 0) tri_alive[tr] = 2u;
+    return;
+  }
+  const int lane = lane_id();
+  const int wid = __builtin_amdgcn_readfirstlane(wave_id());
+  const uint32_t n_pre = min(max(c.box_points, Mall >> kBoxShift), Mall - Mi);
+  float4* s_w4 = reinterpret_cast<float4*>(smem);   // n_pre x (pi_lo, pi_hi, pj_lo, pj_hi)
+  float* s_ay = reinterpret_cast<float*>(s_w4 + n_pre);
+  float* s_az = s_ay + n_ty;
+  const float2* __restrict__ wyz = c.walk_yz + c.off[f];
+  float cth[3], sth[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    cth[t] = c.cth[k0 + min(t, nk - 1)];
+    sth[t] = c.sth[k0 + min(t, nk - 1)];
+  }
+  for (uint32_t sl = threadIdx.x; sl < n_pre; sl += THREADS) {
+    const float2 v = wyz[Mi + sl];   // the rim-first border-class part of the walk layout: what each theta's own pre-pass looks at
+    float ilo = __builtin_inff(), ihi = -__builtin_inff(), jlo = __builtin_inff(), jhi = -__builtin_inff();
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const float pi = fmaf(-sth[t], v.y, cth[t] * v.x), pj = fmaf(cth[t], v.y, sth[t] * v.x);   // = the full pass's staging
+      ilo = fminf(ilo, pi);
+      ihi = fmaxf(ihi, pi);
+      jlo = fminf(jlo, pj);
+      jhi = fmaxf(jhi, pj);
+    }
+    // a point far from the rotation centre: leave it out (as a point at the board's centre, in the board under every
+    // translation of the tables -- the host launches this kernel only then -- it contributes nothing to any bound)
+    const bool wide = !(ihi - ilo <= 0.5f && jhi - jlo <= 0.5f);
+    s_w4[sl] = wide ? make_float4(0.f, 0.f, 0.f, 0.f) : make_float4(ilo, ihi, jlo, jhi);
+  }
+  for (int i = threadIdx.x; i < n_ty; i += THREADS) s_ay[i] = c.ay[i];
+  for (int i = threadIdx.x; i < n_tz; i += THREADS) s_az[i] = c.az[i];
+  for (int w = threadIdx.x; w < (n_tiles + 31) / 32; w += THREADS) s_dead3[w] = 0u;
+  if (threadIdx.x == 0) s_any = 0u;
+  __syncthreads();
+  const float Wh = 0.5f * (float)c.p.board_w, Hh = 0.5f * (float)c.p.board_h, delta2 = (float)c.p.huber_delta;
+  const float lim_box = 0.5f * (1.f + kTieEps) * __uint_as_float(__hip_atomic_load(c.grid_bound + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  const int half = (int)(threadIdx.x & 1u);
+  uint32_t wave_evals = 0;
+  for (int q0 = 0; q0 < n_tiles; q0 += THREADS / 2) {
+    const int q = q0 + (int)(threadIdx.x >> 1);
+    const int qc = min(q, n_tiles - 1);
+    const int qa = qc / ntb, qb = qc - qa * ntb;
+    float alo = __builtin_inff(), ahi = -__builtin_inff(), zlo = __builtin_inff(), zhi = -__builtin_inff();
+#pragma unroll
+    for (int d = 0; d < kTile; ++d) {
+      const float va = s_ay[min(qa * kTile + d, n_ty - 1)], vz = s_az[min(qb * kTile + d, n_tz - 1)];
+      alo = fminf(alo, va);
+      ahi = fmaxf(ahi, va);
+      zlo = fminf(zlo, vz);
+      zhi = fmaxf(zhi, vz);
+    }
+    float lb = 0.f, both = 0.f;
+    const bool todo = q < n_tiles;
+    const uint32_t wave_tiles = (uint32_t)__popcll(__ballot(todo && half == 0));
+    for (uint32_t u0 = 0; wave_tiles != 0u && u0 < n_pre; u0 += 2u * kBoxCheck) {
+      wave_evals += wave_tiles * min(2u * kBoxCheck, n_pre - u0);
+#pragma unroll
+      for (uint32_t d = 0; d < (uint32_t)kBoxCheck; ++d) {
+        const uint32_t u = u0 + 2u * d + (uint32_t)half;
+        if (u < n_pre && todo) {
+          const float4 v = s_w4[u];
+          box_term(v.x, v.y, v.z, v.w, alo, ahi, zlo, zhi, Wh, Hh, delta2, lb);
+        }
+      }
+      both = lb + __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(lb), 0xB1 /*quad_perm [1,0,3,2]*/, 0xf, 0xf, false));
+      if (__ballot(todo && !(both * kBoxSafety > lim_box)) == 0ull) break;
+    }
+    if (half == 0 && todo) {
+      if (both * kBoxSafety > lim_box)
+        atomicOr(&s_dead3[q >> 5], 1u << (q & 31));
+      else
+        s_any = 1u;
+    }
+  }
+  if (lane == 0) s_iters[wid] = wave_evals;
+  __syncthreads();
+  const bool any_alive = s_any != 0u;
+  if (any_alive)
+    for (int w = threadIdx.x; w < (n_tiles + 31) / 32; w += THREADS) tri_mask[(uint64_t)tr * c.tri_words + w] = s_dead3[w];
+  if (threadIdx.x == 0) {
+    unsigned long long box_evals = 0;
+    for (int w = 0; w < THREADS / ILCC_WAVE; ++w) box_evals += s_iters[w];
+    atomicAdd(c.grid_iters + 2 * kIterSlots + (f & (kIterSlots - 1)), box_evals);
+    tri_alive[tr] = any_alive ? 1u : 0u;
+  }
+}
+
+void launch_triple_prepass(const Ctx& c, hipStream_t s, uint32_t* tri_alive, uint32_t* tri_mask) {
+  const dim3 grid(c.tri_count, c.n_frames);
+  // LDS: the widened pre-pass points (16 B each: at most a quarter of the frame's labelled points) and the (ty, tz) tables
+  const size_t lds = sizeof(float4) * ((size_t)c.grid_lds_points / 2 + 64) + sizeof(float) * (size_t)(c.p.n_ty + c.p.n_tz);
+  if (c.grid_lds_points > (uint32_t)kGridLargeFrom)
+    hipLaunchKernelGGL((k6_triple_prepass<kGridThreadsLarge>), grid, dim3(kGridThreadsLarge), lds, s, c, tri_alive, tri_mask);
+  else
+    hipLaunchKernelGGL((k6_triple_prepass<kGridThreads>), grid, dim3(kGridThreads), lds, s, c, tri_alive, tri_mask);
 }
 
 // K5w walk order: the frame's labelled points in the layout k6_grid_cost stages -- [interior | rim | other border], each part
@@ -1055,7 +1199,7 @@ __global__ void k6_isa_probe_box(const float* __restrict__ pts, float alo, float
   float lb = 0.f;
   const float t = (float)threadIdx.x;
 #pragma unroll
-  for (int k = 0; k < N; ++k) box_term(pts[2 * k], pts[2 * k + 1], alo + t, ahi + t, zlo - t, zhi - t, Wh, Hh, delta, lb);
+  for (int k = 0; k < N; ++k) box_term(pts[2 * k], pts[2 * k], pts[2 * k + 1], pts[2 * k + 1], alo + t, ahi + t, zlo - t, zhi - t, Wh, Hh, delta, lb);
   out[threadIdx.x] = lb;
 }
 template __global__ void k6_isa_probe_box<1>(const float*, float, float, float, float, float, float, float, float*);
@@ -1090,7 +1234,8 @@ hipError_t set_kernel_attributes_k6() {
   const void* fns[] = {(const void*)k6_grid_cost<true, true, false, kGridThreads>,  (const void*)k6_grid_cost<true, false, false, kGridThreads>,
                        (const void*)k6_grid_cost<false, true, false, kGridThreads>, (const void*)k6_grid_cost<false, false, false, kGridThreads>,
                        (const void*)k6_grid_cost<true, false, true, kGridThreads>,  (const void*)k6_grid_cost<false, false, true, kGridThreads>,
-                       (const void*)k6_grid_cost<true, false, true, kGridThreadsLarge>};
+                       (const void*)k6_grid_cost<true, false, true, kGridThreadsLarge>,
+                       (const void*)k6_triple_prepass<kGridThreads>, (const void*)k6_triple_prepass<kGridThreadsLarge>};
   const int cap = (int)((sizeof(float2) + sizeof(float)) * (size_t)kGridLdsPointsMax + sizeof(float) * (size_t)kGridTableMax);
   for (const void* fn : fns) {
     const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
