@@ -618,8 +618,8 @@ int32_t enqueue_impl(ilcc_handle* h, int si, const float4* d_xyzi, const uint64_
       const bool centre_in = h->p.ty_min > -0.45 * h->p.board_w * g && ty_hi < 0.45 * h->p.board_w * g && h->p.tz_min > -0.45 * h->p.board_h * g &&
                              tz_hi < 0.45 * h->p.board_h * g;
       const uint32_t n_tiles = (uint32_t)(((h->p.n_ty + 3) / 4) * ((h->p.n_tz + 3) / 4));
-      if (ILCC_K6_TRIPLE && full.box_points != 0u && h->p.n_th >= 3 && centre_in && n_tiles <= 4096u) {
-        full.tri_count = (uint32_t)((h->p.n_th + 2) / 3);
+      if (ILCC_K6_TRIPLE && full.box_points != 0u && h->p.n_th >= kThetaGroup && centre_in && n_tiles <= 4096u) {
+        full.tri_count = (uint32_t)((h->p.n_th + kThetaGroup - 1) / kThetaGroup);
         full.tri_words = (n_tiles + 31u) / 32u;
         const size_t need_alive = (size_t)n_frames * full.tri_count, need_mask = need_alive * full.tri_words;
         if (need_alive > sl.tri_alive_cap) {

@@ -48,6 +48,10 @@ constexpr int kTileA = 4;              // K6 candidate tile: ty values per wavef
 #define ILCC_TILE_B 4
 #endif
 constexpr int kTileB = ILCC_TILE_B;    // K6 candidate tile: tz values per wavefront pass (4 or 8)
+#ifndef ILCC_K6_GROUP
+#define ILCC_K6_GROUP 5   // measured (config 2 / config 5, k frames/s): 2: 821 / 50.9, 3: 837 / 54.5, 4: 837 / 55.1, 5: 842 / 56.2, 7: 841 / 56.3
+#endif
+constexpr int kThetaGroup = ILCC_K6_GROUP;   // K6: consecutive thetas that share one common box pre-pass (k6_triple_prepass)
 constexpr int kGridLdsPointsMax = 8192;   // K6 LDS staging upper bound (12 B per point -> 96 KiB)
 constexpr int kGridTableMax = 8192;       // K6: n_ty + n_tz bound (their tables sit in LDS behind the points: 32 KiB)
 #ifndef ILCC_K7_THREADS

@@ -227,7 +227,7 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
   bool triple_dead = false;
   if constexpr (PRUNE && OOB && LDS_POINTS && !VOLUME) {
     if (c.tri_alive != nullptr) {
-      const uint32_t tr = (uint32_t)f * c.tri_count + kblk / 3u;
+      const uint32_t tr = (uint32_t)f * c.tri_count + kblk / (uint32_t)kThetaGroup;
       const uint32_t st = c.tri_alive[tr];   // 0: every tile dead, 1: mask valid, 2: no common pre-pass ran for this triple
       triple_dead = st == 0u;
       if (st == 1u) s_dead0 = c.tri_mask + (uint64_t)tr * c.tri_words;
@@ -934,7 +934,7 @@ __global__ __launch_bounds__(THREADS) void k6_triple_prepass(Ctx c, uint32_t* tr
   __shared__ uint32_t s_any;
   constexpr int kBoxShift = (THREADS == kGridThreadsLarge && kGridThreadsLarge != kGridThreads) ? ILCC_BOX_SHIFT_LARGE : ILCC_BOX_SHIFT;
   const uint32_t f = blockIdx.y;
-  const int k0 = 3 * (int)blockIdx.x, nk = min(3, c.p.n_th - k0);
+  const int k0 = kThetaGroup * (int)blockIdx.x, nk = min(kThetaGroup, c.p.n_th - k0);
   const uint32_t tr = f * c.tri_count + blockIdx.x;
   const uint32_t Mall = c.n_lab[f];
   const bool lds = Mall <= c.grid_lds_points;
@@ -948,14 +948,17 @@ __global__ __launch_bounds__(THREADS) void k6_triple_prepass(Ctx c, uint32_t* tr
   }
   const int lane = lane_id();
   const int wid = __builtin_amdgcn_readfirstlane(wave_id());
-  const uint32_t n_pre = min(max(c.box_points, Mall >> kBoxShift), Mall - Mi);
+#ifndef ILCC_GROUP_SHIFT_DELTA
+#define ILCC_GROUP_SHIFT_DELTA (-1)   // the common pre-pass looks at (labelled points) >> (kBoxShift + delta): twice each theta's own sample.  delta +1 / 0 / -1 / -2 / -3: config 2 824 / 842 / 858 / 845 / 841 k, config 5 53.8 / 56.2 / 59.4 / 58.9 k frames/s
+#endif
+  const uint32_t n_pre = min(max(c.box_points, Mall >> (kBoxShift + ILCC_GROUP_SHIFT_DELTA)), Mall - Mi);
   float4* s_w4 = reinterpret_cast<float4*>(smem);   // n_pre x (pi_lo, pi_hi, pj_lo, pj_hi)
   float* s_ay = reinterpret_cast<float*>(s_w4 + n_pre);
   float* s_az = s_ay + n_ty;
   const float2* __restrict__ wyz = c.walk_yz + c.off[f];
-  float cth[3], sth[3];
+  float cth[kThetaGroup], sth[kThetaGroup];
 #pragma unroll
-  for (int t = 0; t < 3; ++t) {
+  for (int t = 0; t < kThetaGroup; ++t) {
     cth[t] = c.cth[k0 + min(t, nk - 1)];
     sth[t] = c.sth[k0 + min(t, nk - 1)];
   }
@@ -963,7 +966,7 @@ __global__ __launch_bounds__(THREADS) void k6_triple_prepass(Ctx c, uint32_t* tr
     const float2 v = wyz[Mi + sl];   // the rim-first border-class part of the walk layout: what each theta's own pre-pass looks at
     float ilo = __builtin_inff(), ihi = -__builtin_inff(), jlo = __builtin_inff(), jhi = -__builtin_inff();
 #pragma unroll
-    for (int t = 0; t < 3; ++t) {
+    for (int t = 0; t < kThetaGroup; ++t) {
       const float pi = fmaf(-sth[t], v.y, cth[t] * v.x), pj = fmaf(cth[t], v.y, sth[t] * v.x);   // = the full pass's staging
       ilo = fminf(ilo, pi);
       ihi = fmaxf(ihi, pi);
