@@ -3,10 +3,11 @@
 
 A "step" is one pass of the whole hot path (K1 crop -> K2 cluster -> K3 RANSAC plane -> K4/K5 plane frame + gray
 zone -> K6 exhaustive (theta,ty,tz) x phase grid cost -> K7r monotone refinement + basin check -> K7b corners) over
-configs[3]'s 1024 synthetic frames PER GPU, fed as 2 DISTINCT batches of 512 frames (configs[1] frames: 16 rings x
+configs[3]'s 1024 synthetic frames PER GPU, fed as ONE batch of 1024 frames (configs[1] frames: 16 rings x
 1800 azimuths = 28 800 XYZI points, 7x5-corner board @0.15 m, one random board pose per frame) through the
-library's submit/wait pipeline (up to 4 batches in flight).  The 2 batches are 472 MB of distinct input per GPU --
-more than the 256 MB Infinity Cache -- so K1 reads HBM, not cache.  Inputs are resident in HBM when the timed region
+library's submit/wait pipeline (up to 4 batches = 4 steps in flight).  The batch is 472 MB of input per GPU --
+more than the 256 MB Infinity Cache -- so K1 reads HBM, not cache.  (Rounds 3 and 4 until the common pre-pass: 2 batches of
+512; since K6's share fell, larger batches pay: 855 k frames/s at 2 x 512, 925 k at 1 x 1024.)  Inputs are resident in HBM when the timed region
 starts (the bench contract: `value` is never a PCIe-inclusive rate); the same pipeline with every batch starting in
 pinned HOST memory is timed right after, on every rank, and reported at top level as `value_h2d_inclusive` with the
 link's own rate beside it (`link_GBps_achieved`, `link_bound_frames_per_s`, `link_frac`) -- SURVEY.md 8(d)'s metric as
@@ -71,7 +72,8 @@ K6_VALU_OPS_INTERIOR = 15.0
 K6_VALU_OPS_BOX = 24.0
 # PMC passes of the K6 stage at the batch sizes this bench runs (tools/gpu_pmc.sh -> profiles/): per-launch counters of one
 # batch alone on the chip.  roofline.traffic and roofline.issued_vs_credited are computed from these files at run time.
-PMC_FILES = {(2, 512): ("profiles/r04_pmc_cfg2_512f.csv", "profiles/r03_pmc_cfg2_512f.csv"),
+PMC_FILES = {(2, 1024): ("profiles/r04_pmc_cfg2_1024f.csv",),
+             (2, 512): ("profiles/r04_pmc_cfg2_512f.csv", "profiles/r03_pmc_cfg2_512f.csv"),
              (5, 64): ("profiles/r04_pmc_cfg5_64f.csv",)}   # (round 3's config-5 file averaged a cold first dispatch in: not used)
 # rocprofv3 --kernel-trace --stats of this bench's own command (tools/gpu_profile.sh): pipelined (4 batches in flight) and
 # --in-flight 1 (one batch alone on the chip).  roofline.rocprof recomputes `frac` from their per-kernel averages.
@@ -80,15 +82,15 @@ KSTATS_FILES = {2: ("profiles/r04_kernel_stats_bench_20_5.csv", "profiles/r04_ke
 
 
 def k6_pmc(config, frames_per_batch):
-    """Counters of the K6 launches (seed, refinement, anchor, full pass) of ONE batch from the committed PMC summary:
+    """Counters of the K6 launches (seed, refinement, anchor, common pre-pass, full pass) of ONE batch from the committed PMC summary:
     HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (MI355X_MICROARCH.md: FETCH_SIZE counts half the bytes of wide reads on
     gfx950; separate passes), issued VALU wavefront-instructions, busy cycles.  None when no file matches this run."""
     import csv
     path = next((q for q in PMC_FILES.get((config, frames_per_batch), ()) if os.path.exists(os.path.join(ROOT, q))), None)
     if not path:
         return None
-    rows = [r for r in csv.DictReader(open(os.path.join(ROOT, path))) if "k6_grid_cost" in r["kernel"]]
-    if len(rows) not in (3, 4):    # seed, refinement, (anchor,) full pass: one summary row per distinct launch size
+    rows = [r for r in csv.DictReader(open(os.path.join(ROOT, path))) if "k6_grid_cost" in r["kernel"] or "k6_triple_prepass" in r["kernel"]]
+    if len(rows) not in (3, 4, 5):    # seed, refinement, (anchor,) (common pre-pass,) full pass: one summary row per distinct launch
         return None
     f = lambda r, k: float(r[k]) if r.get(k) not in (None, "") else 0.0
     full = max(rows, key=lambda r: f(r, "SQ_INSTS_VALU"))
@@ -100,22 +102,26 @@ def k6_pmc(config, frames_per_batch):
 
 
 def k6_rocprof(config, credited_lane_instr_per_batch, launches_per_batch=4):
-    """roofline.frac recomputed from the committed rocprofv3 kernel-stats CSVs of this bench's command: K6's average
-    kernel duration x its launches per batch, pipelined and with one batch alone on the chip."""
+    """roofline.frac recomputed from the committed rocprofv3 kernel-stats CSVs of this bench's command: per batch K6's average
+    kernel duration x its four launches (seed, refinement, anchor, full pass) + the common pre-pass kernel's (k6_triple_prepass),
+    pipelined and with one batch alone on the chip."""
     import csv
     out = {}
     for tag, path in zip(("pipelined", "in_flight_1"), KSTATS_FILES.get(config, ())):
         full = os.path.join(ROOT, path)
         if not os.path.exists(full):
             continue
-        for r in csv.DictReader(open(full)):
-            if "k6_grid_cost" in r.get("Name", ""):
-                avg_us = float(r["AverageNs"]) / 1e3
-                ms = launches_per_batch * avg_us / 1e3
-                rate = credited_lane_instr_per_batch / (ms * 1e-3) / 1e12
-                out[tag] = {"file": path, "k6_calls": int(r["Calls"]), "k6_average_us": avg_us, "k6_ms_per_batch": ms,
-                            "achieved": rate, "frac": rate / VALU_ISSUE_PEAK_T}
-                break
+        rows = list(csv.DictReader(open(full)))
+        k6 = max((r for r in rows if "k6_grid_cost" in r.get("Name", "")), key=lambda r: int(r["Calls"]), default=None)
+        pre = next((r for r in rows if "k6_triple_prepass" in r.get("Name", "")), None)
+        if k6 is None:
+            continue
+        avg_us = float(k6["AverageNs"]) / 1e3
+        pre_us = float(pre["AverageNs"]) / 1e3 if pre else 0.0
+        ms = (launches_per_batch * avg_us + pre_us) / 1e3
+        rate = credited_lane_instr_per_batch / (ms * 1e-3) / 1e12
+        out[tag] = {"file": path, "k6_calls": int(k6["Calls"]), "k6_average_us": avg_us, "k6_triple_prepass_average_us": pre_us,
+                    "k6_ms_per_batch": ms, "achieved": rate, "frac": rate / VALU_ISSUE_PEAK_T}
     return out or None
 
 
@@ -148,8 +154,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", type=int, default=2, choices=(2, 5),
                     help="2: BASELINE configs[1] frames (the headline); 5: configs[4], the dense-cloud fine-grid run")
-    ap.add_argument("--frames-per-batch", type=int, default=0, help="default 512 (config 2) / 64 (config 5)")
-    ap.add_argument("--batches-per-step", type=int, default=0, help="distinct batches per step and GPU: default 2 (config 2) / 2 (config 5)")
+    ap.add_argument("--frames-per-batch", type=int, default=0, help="default 1024 (config 2) / 64 (config 5)")
+    ap.add_argument("--batches-per-step", type=int, default=0, help="distinct batches per step and GPU: default 1 (config 2) / 2 (config 5)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline time budget (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the H2D-inclusive / reference-mode legs (profiling runs)")
@@ -166,9 +172,12 @@ def main():
     # 384: 269 k, 512: 273 k, 1024: 269 k frames/s (config 5: 16: 2.87 k, 32: 3.30 k, 64: 3.54 k) -- 128 per-frame
     # workgroups fill only half of the 256 CUs.  Measured again once the grid search had its box pre-pass (round 3, the path no
     # longer VALU-saturated): 128 x 8: 405 k, 192 x 6: 487 k, 256 x 4: 542 k, 384 x 4: 559 k, 512 x 2: 571 k, 1024 x 1: 577 k
-    # frames/s -- 512 x 2 (four batches = 2048 frames in flight) is the default
-    F = args.frames_per_batch or (512 if args.config == 2 else 64)
-    B = max(1, args.batches_per_step or 2)
+    # frames/s -- 512 x 2 (four batches = 2048 frames in flight) was the default until round 4's common pre-pass (k6_triple_prepass) halved
+    # the grid search's share of the step; measured then: 256 x 4: 738 k, 384 x 2: 819 k, 512 x 2: 853 k, 768 x 2: 922 k, 1024 x 1: 923-928 k
+    # frames/s resident (H2D-inclusive: 117.6-119.7 k at 512 x 2, 115.9 k at 1024 x 1: the link either way).  Config 5: 32 x 4: 46.4 k,
+    # 64 x 2: 59.0 k (H2D-inclusive 23.8 k), 128 x 1: 61.9 k (22.6 k): 64 x 2 stays, its contract metric is the one still short of the link
+    F = args.frames_per_batch or (1024 if args.config == 2 else 64)
+    B = max(1, args.batches_per_step or (1 if args.config == 2 else 2))
     FS = F * B                                        # frames per step and GPU
 
     # synthetic inputs first (forked workers; nothing has touched the HIP runtime yet).  Weak scaling: every rank

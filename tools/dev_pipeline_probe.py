@@ -1,4 +1,4 @@
-"""Sensitivity probe: the bench's 4-deep pipeline (2 distinct 512-frame batches per step) with parameter overrides, to see
+"""Sensitivity probe: the bench's 4-deep pipeline (one 1024-frame batch per step) with parameter overrides, to see
 what a stage is worth: e.g. `refine_div=0` (K7r keeps the grid argmin: no pattern search), `ransac_hyp=8`, `n_th=31` ...
 usage: python tools/dev_pipeline_probe.py [steps=20] [name=value ...]"""
 import os, sys, time
@@ -10,7 +10,7 @@ import bench
 steps = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 20
 over = [a.split("=") for a in sys.argv[1:] if "=" in a and not a.startswith("depth=")]
 DEPTH = int(([a.split("=")[1] for a in sys.argv[1:] if a.startswith("depth=")] or ["4"])[0])
-F, B, n_points = 512, 2, 28800
+F, B, n_points = 1024, 1, 28800
 clouds, clicks, gts = bench.generate(2, F * B, 0xC0FFEE, 16)
 import torch
 from lidar_camera_calibration_amd import LidarCornersBatch

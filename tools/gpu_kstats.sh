@@ -1,5 +1,5 @@
 # rocprofv3 kernel stats of tools/pmc_target.py (synchronous batches, one alone on the chip): tools/gpu_kstats.sh TAG [FRAMES] [CONFIG]
-TAG=${1:-r04}; CFG=${3:-2}; F=${2:-$([ "$CFG" = 5 ] && echo 64 || echo 512)}
+TAG=${1:-r04}; CFG=${3:-2}; F=${2:-$([ "$CFG" = 5 ] && echo 64 || echo 1024)}
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 D=$R/gpurun_out/prof_${TAG}_kstats_cfg${CFG}_${F}f

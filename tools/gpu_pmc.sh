@@ -3,7 +3,7 @@
 # other trace domains) of tools/pmc_target.py, summarised per kernel into gpurun_out/<TAG>_pmc_cfg<CONFIG>_<FRAMES>f.csv
 TAG=${1:-r04}
 CFG=${3:-2}
-F=${2:-$([ "$CFG" = 5 ] && echo 64 || echo 512)}
+F=${2:-$([ "$CFG" = 5 ] && echo 64 || echo 1024)}
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp

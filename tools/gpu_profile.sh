@@ -28,6 +28,7 @@ for MODE in "config5:" "config5_inflight1:--in-flight 1"; do
 import json; d=json.load(open('$R/gpurun_out/prof_${TAG}_bench_$N.json')); print('BENCH under rocprof ($N)', round(d['value']), d['ms_per_step'], d['roofline']['launch_ms'])"
 done
 if [ "$2" = "pmc" ]; then
+  tools/gpu_pmc.sh $TAG 1024 2 | tail -14 | cut -c1-220
   tools/gpu_pmc.sh $TAG 512 2 | tail -14 | cut -c1-220
   tools/gpu_pmc.sh $TAG 64 5 | tail -16 | cut -c1-220
 fi
