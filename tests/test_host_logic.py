@@ -102,7 +102,7 @@ def test_bench_reads_its_roofline_inputs_from_committed_profiles():
         pmc = bench.k6_pmc(config, frames)
         assert pmc is not None and pmc["file"] == have[0]          # the newest committed pass of that configuration
         assert pmc["traffic_bytes"] > 1e6 and pmc["valu_wave_instr"] > pmc["full_pass"]["valu_wave_instr"] > 1e7
-        assert 0.3 < pmc["full_pass"]["valu_busy_quad_cycles"] / (pmc["full_pass"]["gui_active_cycles_per_xcd"] * 256.0) < 1.2
+        assert 0.15 < pmc["full_pass"]["valu_busy_quad_cycles"] / (pmc["full_pass"]["gui_active_cycles_per_xcd"] * 256.0) < 1.2
         # a batch alone on the chip cannot take longer than the same kernel does with three other batches beside it
         # (round 3's config-5 file failed this: a cold first dispatch was averaged in)
         alone_ms = pmc["full_pass"]["gui_active_cycles_per_xcd"] / 2.4e6
