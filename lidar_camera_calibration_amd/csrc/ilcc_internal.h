@@ -153,10 +153,10 @@ struct Ctx {
   GridPartial* tie_list;     // n_frames x kTieCap: cost (fp32), d2, flat
   unsigned long long* grid_iters;  // executed K6 work in counts of grid_cost_evals_per_count() evaluations, for the VALU rate
   uint32_t box_points;             // K6 full pass: border-class walk positions the box pre-pass looks at per tile (0: no pre-pass)
-  // K6 full pass behind k6_triple_prepass (nullptr: no common pre-pass): per (frame, triple of thetas) a state word and a bit mask
+  // K6 full pass behind k6_triple_prepass (nullptr: no common pre-pass): per (frame, group of kThetaGroup thetas) a state word and a bit mask
   const uint32_t* tri_alive;
   const uint32_t* tri_mask;
-  uint32_t tri_count, tri_words;   // triples per frame = ceil(n_th / 3); mask words per triple = ceil(tiles / 32)
+  uint32_t tri_count, tri_words;   // theta groups per frame = ceil(n_th / kThetaGroup); mask words per group = ceil(tiles / 32)
   // seeding pass of the branch-and-bound (a decimated subset of the same grid, evaluated first)
   const GridPartial* seed_partial; // n_frames x seed_blocks, nullptr when this launch is the seed pass / unused
   uint32_t seed_blocks;

@@ -5,6 +5,8 @@
 // for EVERY candidate of an exhaustive (theta, ty, tz) x colour-phase grid (the reference only
 // walks this surface locally with Ceres from (0,0,0)).
 //
+// (Round 4: k6_triple_prepass, further down, runs ONE such pre-pass for five consecutive thetas in front of the full pass; a
+// full-pass workgroup starts from its group's rejected-tile mask, or exits at once when the group left no tile.)
 // Mapping (gfx950): workgroup = (frame, theta index), 4 wavefronts (8 on frames staged above 2048 points).  The frame's
 // labelled points are rotated by the workgroup's theta and staged ONCE into LDS.  A wavefront owns a tile of
 // 4 x 4 (ty, tz) candidates; lane = candidate * 4 + slice: the four lanes of a quad evaluate the SAME
@@ -916,15 +918,16 @@ __global__ __launch_bounds__(THREADS) void k6_grid_cost(Ctx c, float* volume) {
     grid_cost_body<OOB, VOLUME, false, PRUNE, THREADS>(c, volume, s_ij, s_hw, s_best, s_iters, s_cnt, s_ay, s_az, s_dead, &s_next, blockIdx.x);
 }
 
-// k6_triple_prepass (round 4): ONE box pre-pass for three consecutive thetas, in front of the full pass.  71 % of the (frame,
+// k6_triple_prepass (round 4): ONE box pre-pass for a GROUP of kThetaGroup consecutive thetas, in front of the full pass (the name
+// is from its first version, three thetas; five measured best: ilcc_internal.h).  71 % of the (frame,
 // theta) workgroups of the full pass die in their own box pre-pass -- staging, tables, three barriers, ~450 instructions per
 // wavefront each: 30 % of the kernel -- and a theta step moves a point by less than a third of a tile's width.  Every pre-pass
-// point is rotated by all three thetas (the term's own fp32 expressions) and the box bound takes the extremes: i_lo from the
+// point is rotated by all thetas of the group (the term's own fp32 expressions) and the box bound takes the extremes: i_lo from the
 // smallest rotated coordinate and the box's lowest translation, i_hi from the largest and the highest.  fl(p + a) is monotone
-// in p as in a, so [i_lo, i_hi] contains the interval each theta's own pre-pass uses: the bound is a lower bound for all 3 x 16
-// candidates by box_term's argument unchanged (a point whose three images lie more than half a square apart on an axis is left
-// out; the interval stays far narrower than a board).  Output per (frame, triple): a state word -- 0: every tile rejected (the
-// three full-pass workgroups exit on their first instructions), 1: a bit mask of the rejected tiles follows (their own
+// in p as in a, so [i_lo, i_hi] contains the interval each theta's own pre-pass uses: the bound is a lower bound for all group x 16
+// candidates by box_term's argument unchanged (a point whose images lie more than half a square apart on an axis is left
+// out; the interval stays far narrower than a board).  Output per (frame, group): a state word -- 0: every tile rejected (the
+// group's full-pass workgroups exit on their first instructions), 1: a bit mask of the rejected tiles follows (their own
 // pre-pass starts from it and only looks at the rest), 2: no common pre-pass (conditions not met) -- and the mask.
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void k6_triple_prepass(Ctx c, uint32_t* tri_alive, uint32_t* tri_mask) {
