@@ -560,6 +560,39 @@ def test_box_prepass_on_other_grids_matches_the_oracle(ob, frames, grid):
     e.close()
 
 
+def test_common_prepass_leaves_out_points_far_from_the_rotation_centre(ob):
+    """k6_triple_prepass bounds five thetas at once from the extremes of a point's five rotated images; a point whose images lie
+    more than half a square apart (further than ~2 m from the plane frame's origin on the default grid) is left out of that
+    bound.  A 5 m wide 'board' -- a wall patch with a chequered intensity -- puts a third of the labelled points there: grid
+    argmin, theta_t, costs and corners must still be the oracle's."""
+    rng = np.random.default_rng(9)
+    yy, zz = np.meshgrid(np.arange(-2.5, 2.5, 0.04), np.arange(-1.0, 1.0, 0.04), indexing="ij")
+    y, z = yy.ravel() + rng.normal(0, 0.002, yy.size), zz.ravel() + rng.normal(0, 0.002, yy.size)
+    th = 0.07                                                      # the pattern is turned against the wall's principal axes
+    u, v = np.cos(th) * y - np.sin(th) * z + 0.031, np.sin(th) * y + np.cos(th) * z - 0.022
+    white = ((np.floor(u / 0.15) + np.floor(v / 0.15)) % 2) == 0
+    inten = np.where(white, 100.0, 12.0) + rng.normal(0, 4.0, y.size)
+    cloud = np.stack([np.full(y.size, 3.0) + rng.normal(0, 0.003, y.size), y, z, inten], 1).astype(np.float32)
+    click = np.array([3.0, 0.0, 0.0], np.float32)
+    p = N.default_params()
+    p.roi_half[0], p.roi_half[1], p.roi_half[2] = 1.0, 3.0, 2.0
+    e = LidarCornersBatch(1, len(cloud), p)
+    e.reserve(8192, 8192)
+    r = e.extract(cloud[None], click[None])[0]
+    tm = e.timing()
+    e.close()
+    op = _oparams(ob, N.SOLVER_GRID)
+    op.roi_half[0], op.roi_half[1], op.roi_half[2] = 1.0, 3.0, 2.0
+    o = ob.extract(cloud, click, op)
+    assert 4096 < r.n_black + r.n_white <= 8192                     # staged in LDS: the pre-passes run
+    assert tm.grid_cost_box_evals_sum > 0
+    assert (r.status, r.n_roi, r.n_cluster, r.n_plane) == (o.status, o.n_roi, o.n_cluster, o.n_plane)
+    assert r.status in (N.OK, N.AMBIGUOUS)
+    assert r.grid_index == o.grid_index and tuple(r.theta_t) == tuple(o.theta_t)
+    assert (r.iters_a, r.iters_b, r.sel_cost, r.basin_margin) == (o.iters_a, o.iters_b, o.sel_cost, o.basin_margin)
+    assert np.abs(r.corners_array() - ob.result_corners(o)).max() < 1e-6
+
+
 def test_async_submit_wait_matches_synchronous_calls(frames):
     """Four batches in flight (submit/wait) return exactly what four synchronous calls return."""
     import torch
