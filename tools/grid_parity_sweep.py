@@ -14,16 +14,32 @@ from oracle import binding as ob
 
 F = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 seed = int(sys.argv[2], 0) if len(sys.argv) > 2 else 0xBEEF
-mode = sys.argv[3] if len(sys.argv) > 3 else "grid"   # "grid" or "local" (the reference trajectory)
-board, lidar = synth.Board(), synth.vlp16()
-clouds, clicks, gts, _ = synth.make_batch(F, lidar, board, seed=seed)
+mode = sys.argv[3] if len(sys.argv) > 3 else "grid"   # "grid", "grid5" (BASELINE config 5's frames and grid) or "local" (the reference trajectory)
+def config5(p):   # BASELINE configs[4]: 11 x 8 corners @0.10 m, the 129 x 129 x 129 x 2 grid
+    p.board_w, p.board_h, p.grid_length = 9, 12, 0.10
+    p.n_th = p.n_ty = p.n_tz = 129
+    p.th_min, p.th_step = -16.0 * np.pi / 180.0, 0.25 * np.pi / 180.0
+    p.ty_min = p.tz_min = -0.10
+    p.ty_step = p.tz_step = 0.10 / 64
+    return p
+
+
 gp = N.default_params()
+if mode == "grid5":      # "grid5": the grid mode on BASELINE config 5's dense 64-ring frames
+    board, lidar = synth.Board(9, 12, 0.10), synth.hdl64()
+    clouds, clicks, gts, _ = synth.make_batch(F, lidar, board, seed=seed, range_m=(2.0, 3.0), yaw_deg=25.0, pitch_deg=15.0, roll_deg=30.0)
+    config5(gp)
+else:
+    board, lidar = synth.Board(), synth.vlp16()
+    clouds, clicks, gts, _ = synth.make_batch(F, lidar, board, seed=seed)
 if mode == "local":
     gp.solver = N.SOLVER_REFERENCE_LOCAL
 est = LidarCornersBatch(F, lidar.n_points, gp, device=0)
 res = est.extract(clouds, clicks)
 p = ob.default_params()
-p.solver = ob.SOLVER_GRID if mode == "grid" else ob.SOLVER_REFERENCE_LOCAL
+p.solver = ob.SOLVER_GRID if mode in ("grid", "grid5") else ob.SOLVER_REFERENCE_LOCAL
+if mode == "grid5":
+    config5(p)
 p.phase_mode = 2
 p.accum_float = 0
 t0 = time.perf_counter()
@@ -35,7 +51,7 @@ both = [f for f in range(F) if res[f].status in (0, 11) and ref[f].status in (0,
 same_idx = sum(int(res[f].grid_index == ref[f].grid_index) for f in both)
 # GRID mode refines on integer sums: theta_t, costs and margin must be the oracle's bit for bit
 same_theta = sum(int(tuple(res[f].theta_t) == tuple(ref[f].theta_t) and res[f].sel_cost == ref[f].sel_cost
-                     and res[f].basin_margin == ref[f].basin_margin) for f in both) if mode == "grid" else -1
+                     and res[f].basin_margin == ref[f].basin_margin) for f in both) if mode in ("grid", "grid5") else -1
 flagged = sum(int(res[f].status == 11) for f in range(F))
 overflow = sum(int(res[f].flags & N.FLAG_TIE_OVERFLOW != 0) for f in range(F))
 same_conf = sum(int((res[f].cells_hit, res[f].n_oob, res[f].flags & ~N.FLAG_TIE_OVERFLOW) == (ref[f].cells_hit, ref[f].n_oob, ref[f].flags))
