@@ -22,13 +22,16 @@ Warm-up: W steps, then blocks of 5 steps until the median step time of a block i
 0.3 s have passed (clock ramp and pipeline fill are not steady state); exactly K steps are then timed between barriers.
 
 Rank 0 prints ONE JSON line (contract in the task statement) with extra objects:
-  roofline     -- the dominant kernel (k6_grid_cost).  `launch_ms` = the summed durations of its four launches per
-                  batch (seed, refinement, anchor, full pass), each bracketed by HIP events on the batch's own stream --
-                  what a rocprofv3 kernel trace of the same run adds up to (profiles/r04_kernel_stats_*.csv, read back
-                  at run time as `rocprof`).  It is VALU-bound (points live in LDS, no MFMA): `bound: "valu"`,
-                  achieved = executed point-candidate evaluations x VALU instructions each / duration vs the VALU
-                  issue peak; the algorithmic HBM figure BASELINE.json asks for (16 N + 12 corners + 64 bytes per
-                  frame) is under `hbm`, the H2D link's under `h2d_link`.
+  roofline     -- the dominant kernel (k6_grid_cost: five launches per batch -- seed, refinement, anchor, common pre-pass,
+                  full pass -- each bracketed by HIP events on the batch's own stream).  VALU-bound (points live in LDS,
+                  no MFMA): `bound: "valu"`, achieved = (executed point-candidate evaluations x VALU instructions each)
+                  / k6_ms_alone, the launches' summed duration with ONE batch in flight (a short leg right after the timed
+                  region: the only exclusive durations; a rocprofv3 trace of `--in-flight 1` adds up to the same).  The
+                  timed region's own event spans (four batches sharing the chip) are `k6_ms_pipelined` / `frac_pipelined`;
+                  `frac_rocprof_*` price the same work on the committed rocprofv3 kernel stats.  All scalars: the
+                  algorithmic HBM figure BASELINE.json asks for (`hbm_frac`: 16 N + 12 corners + 64 bytes per frame over
+                  the whole step; `k1_hbm_frac`: K1's count pass alone), SURVEY.md 8(d)'s H2D-inclusive rate and the
+                  link's (`h2d_inclusive_frames_per_s`, `link_frac`).
   cpu_baseline -- the CPU oracle's reference-faithful path (crop, cluster, RANSAC, PCA, histogram, two-pass
                   Ceres-style local solve for both colour phases), one host thread, median of 5 runs on a bounded
                   sample of the same frames.  A port (the reference cannot be built here: PCL/Eigen/Ceres/ROS
@@ -89,7 +92,8 @@ def k6_pmc(config, frames_per_batch):
     path = next((q for q in PMC_FILES.get((config, frames_per_batch), ()) if os.path.exists(os.path.join(ROOT, q))), None)
     if not path:
         return None
-    rows = [r for r in csv.DictReader(open(os.path.join(ROOT, path))) if "k6_grid_cost" in r["kernel"] or "k6_triple_prepass" in r["kernel"]]
+    rows = [r for r in csv.DictReader(open(os.path.join(ROOT, path))) if "k6_grid_cost" in r["kernel"] or "k6_triple_prepass" in r["kernel"] or "k6_group_prepass" in r["kernel"]
+            or "k6_locate" in r["kernel"]]
     if len(rows) not in (3, 4, 5):    # seed, refinement, (anchor,) (common pre-pass,) full pass: one summary row per distinct launch
         return None
     f = lambda r, k: float(r[k]) if r.get(k) not in (None, "") else 0.0
@@ -113,15 +117,16 @@ def k6_rocprof(config, credited_lane_instr_per_batch, launches_per_batch=4):
             continue
         rows = list(csv.DictReader(open(full)))
         k6 = max((r for r in rows if "k6_grid_cost" in r.get("Name", "")), key=lambda r: int(r["Calls"]), default=None)
-        pre = next((r for r in rows if "k6_triple_prepass" in r.get("Name", "")), None)
+        pre = next((r for r in rows if "k6_triple_prepass" in r.get("Name", "") or "k6_group_prepass" in r.get("Name", "")), None)
         if k6 is None:
             continue
         avg_us = float(k6["AverageNs"]) / 1e3
         pre_us = float(pre["AverageNs"]) / 1e3 if pre else 0.0
         ms = (launches_per_batch * avg_us + pre_us) / 1e3
         rate = credited_lane_instr_per_batch / (ms * 1e-3) / 1e12
-        out[tag] = {"file": path, "k6_calls": int(k6["Calls"]), "k6_average_us": avg_us, "k6_triple_prepass_average_us": pre_us,
-                    "k6_ms_per_batch": ms, "achieved": rate, "frac": rate / VALU_ISSUE_PEAK_T}
+        out[tag] = {"file": path, "k6_calls": int(k6["Calls"]), "k6_average_us": avg_us, "k6_group_prepass_average_us": pre_us,
+                    "k6_ms_per_batch": ms, "achieved_this_run": rate, "frac_this_run": rate / VALU_ISSUE_PEAK_T,
+                    "what": "THIS run's credited work over the committed profile's per-batch K6 time"}
     return out or None
 
 
@@ -147,6 +152,40 @@ def generate(kind, n_frames, seed, workers):
     return tuple(np.concatenate([p[k] for p in parts]) for k in range(3))
 
 
+def ensure_world(args):
+    """`--gpus N` means N ranks, one per device -- or the run fails.  Under a launcher (WORLD_SIZE set: the driver's
+    `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`) the two numbers must agree.  A plain
+    `python bench.py --gpus N` with N > 1 replaces itself with that launcher command (rendezvous on 127.0.0.1), so the
+    flag can never silently run one rank and report n_gpus 1.  N ranks need N devices; ILCC_BENCH_SINGLE_DEVICE (the 1-GPU
+    test hook that puts every rank on device 0) lifts that."""
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    single = bool(os.environ.get("ILCC_BENCH_SINGLE_DEVICE"))
+    ws = os.environ.get("WORLD_SIZE")
+    if ws is not None:
+        if int(ws) != args.gpus:
+            raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks: refusing to report a line whose "
+                             "n_gpus is not what was asked for" % (args.gpus, ws))
+        return
+    if args.gpus == 1:
+        return
+    import socket
+    import torch
+    ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if ndev < args.gpus and not single:
+        raise SystemExit("bench.py: --gpus %d needs %d HIP devices, this node shows %d (one rank per device; "
+                         "ILCC_BENCH_SINGLE_DEVICE=1 is the 1-GPU test hook)" % (args.gpus, args.gpus, ndev))
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = str(sk.getsockname()[1])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: --gpus %d without a launcher: re-executing as `%s`" % (args.gpus, " ".join(cmd[1:9])), file=sys.stderr, flush=True)
+    os.execv(sys.executable, cmd)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -164,6 +203,7 @@ def main():
                     help="frames/s of the N=1 run: rank 0 then prints weak_scaling_efficiency = value / (N x ref)")
     ap.add_argument("--no-noise-floor", action="store_true", help="skip the sensor-noise sweep (noise_floor_mm)")
     args = ap.parse_args()
+    ensure_world(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -210,6 +250,9 @@ def main():
     dist_on = world > 1 or bool(os.environ.get("ILCC_BENCH_FORCE_DIST"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: libilcc_hip has no CPU fallback")
+    if local_world > torch.cuda.device_count() and not os.environ.get("ILCC_BENCH_SINGLE_DEVICE"):
+        raise SystemExit("bench.py: %d ranks on this node but only %d HIP devices (one rank per device)"
+                         % (local_world, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     rec_dev = dev if backend == "nccl" else torch.device("cpu")
@@ -277,7 +320,7 @@ def main():
             side.synchronize()
         return gathered
 
-    def run(n_steps, clouds_ptrs, step_times=None, keep=None, host_clicks=None):
+    def run(n_steps, clouds_ptrs, step_times=None, keep=None, host_clicks=None, depth_override=None):
         """n_steps steps of B batches each, up to `depth` batches in flight (the library's submit/wait pipeline: the
         latency-bound stages of one batch overlap with the grid search of another).  keep: list that receives the
         compact records of the LAST step, batch by batch.  host_clicks: the inputs are pinned HOST buffers and every batch's
@@ -308,7 +351,7 @@ def main():
                     inflight.append((est.submit_host(clouds_ptrs[b], F, n_points, host_clicks[b]), s, b))
                 else:
                     inflight.append((est.submit_device(clouds_ptrs[b], F, n_points, d_clicks[b].data_ptr()), s, b))
-                if len(inflight) == depth:
+                if len(inflight) == (depth_override or depth):
                     finish()
         while inflight:
             finish()
@@ -369,6 +412,13 @@ def main():
             verify_records(gathered.cpu().numpy(), np.arange(world * FS))
     tm = est.timing()
 
+    # ONE batch at a time (in flight 1, nothing else on the chip): the only exclusive launch durations.  roofline.frac is priced
+    # on these; the timed region's own event spans (batches overlapping) are reported beside them
+    est.reset_timing()
+    run(max(3, min(10, args.steps)), dptrs, depth_override=1)
+    torch.cuda.synchronize()
+    tm_alone = est.timing()
+
     # the same pipeline with every batch starting in pinned HOST memory (SURVEY.md 8d counts that copy): every rank, its own link
     h2d = None
     if not args.no_extra_legs:
@@ -392,23 +442,31 @@ def main():
         total_frames = world * FS * args.steps
         fps = total_frames / elapsed
         launches = max(1, tm.grid_cost_launches)
-        # the K6 stage of one batch: its four kernels bracketed one by one (what a kernel trace adds up to), and the span
-        # of the stage on the batch's stream (which, with other batches in flight, also holds the gaps between them)
+        la = max(1, tm_alone.grid_cost_launches)
+        # The K6 stage of one batch, launch by launch (HIP events on the batch's own stream: seed, refinement, anchor, common
+        # pre-pass, full pass).  k6_ms_alone: one batch in flight, nothing else on the chip -- exclusive durations, what a
+        # rocprofv3 kernel trace of `--in-flight 1` adds up to.  k6_ms_pipelined: the same event spans inside the timed region,
+        # where up to four batches share the chip (a span then also holds what a launch waited for a CU).
+        k6_ms_alone = tm_alone.grid_cost_kernel_ms_sum / la
         k6_ms = tm.grid_cost_kernel_ms_sum / launches
         k6_span_ms = tm.grid_cost_ms_sum / launches
         k6_bytes = bytes_per_frame * F
-        achieved = k6_bytes / (k6_ms * 1e-3) / 1e9
         evals_per_launch = tm.grid_cost_evals_sum / launches            # executed (after branch-and-bound cuts)
         evals_nominal = tm.grid_cost_evals_nominal_sum / launches       # what a cut-free exhaustive pass needs
         evals_interior = tm.grid_cost_evals_interior_sum / launches
         valu_ops_per_eval = (K6_VALU_OPS_INTERIOR * evals_interior + K6_VALU_OPS_BORDER * (evals_per_launch - evals_interior)) \
             / max(1.0, evals_per_launch)
-        box_evals = tm.grid_cost_box_evals_sum / launches               # (point, tile) evaluations of the box pre-pass
+        box_evals = tm.grid_cost_box_evals_sum / launches               # (point, tile) evaluations of the box pre-passes
         credited_lane_instr = evals_per_launch * valu_ops_per_eval + box_evals * K6_VALU_OPS_BOX
-        valu_rate = credited_lane_instr / (k6_ms * 1e-3) / 1e12
+        valu_rate = credited_lane_instr / (k6_ms_alone * 1e-3) / 1e12
+        valu_rate_pipe = credited_lane_instr / (k6_ms * 1e-3) / 1e12
         pmc = k6_pmc(args.config, F)
         credited_wave_instr = credited_lane_instr / 64.0
         rocprof = k6_rocprof(args.config, credited_lane_instr)
+        # K1's count pass: the path's HBM-bound kernel (reads every input point exactly once)
+        k1_ms_alone = tm_alone.roi_count_ms_sum / max(1, tm_alone.batches)
+        k1_GBps = 16.0 * n_points * F / (k1_ms_alone * 1e-3) / 1e9 if k1_ms_alone > 0 else None
+        step_ms_alone = tm_alone.stage_ms_sum[6] / max(1, tm_alone.batches)
         low = [bool(res[f].flags & N.FLAG_LOW_COVERAGE) for f in range(FS)]
         acc = [f for f in ok if not low[f]]
         err_acc = np.array([synth.corner_error(res[f].corners_array(), gts[f], board) for f in acc])
@@ -426,18 +484,19 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": ("configs[1]: synthetic VLP-16 cloud (28800 pts, 16 rings), 7x5 board @0.15 m, 1 board pose per "
-                             "frame; one step = configs[3]'s %d frames per GPU as %d distinct batches of %d (%.0f MB of "
-                             "distinct input per GPU, > the 256 MB Infinity Cache)" % (FS, B, F, FS * n_points * 16 / 1e6))
+                # (the driver keeps the first 120 characters of a string: self-contained within that)
+                "workload": ("configs[1] VLP-16 cloud 28800 pts, 7x5 board @0.15 m; step = %d frames/GPU (configs[3] shard) in %d batch(es) of %d"
+                             % (FS, B, F))
                 if args.config == 2 else
-                ("configs[4]: dense 64-ring synthetic cloud (131072 pts), 11x8 board @0.10 m, fine 129x129x129x2 grid; one "
-                 "step = %d frames per GPU as %d distinct batches of %d" % (FS, B, F)),
+                ("configs[4] 64-ring cloud 131072 pts, 11x8 board @0.10 m, 129^3 x 2 grid; step = %d frames/GPU in %d batches of %d"
+                 % (FS, B, F)),
+                "workload_detail": "synthetic frames, one random board pose each; %.0f MB of distinct input per GPU and step%s"
+                                   % (FS * n_points * 16 / 1e6, " (> the 256 MB Infinity Cache)" if FS * n_points * 16 > 256e6 else ""),
                 "frames_per_step_per_gpu": FS,
                 "frames_per_batch": F,
                 "points_per_frame": n_points,
                 "batches_in_flight": depth,
-                "solver": "exhaustive grid %dx%dx%d x 2 phases (%d candidates), then monotone 27-point pattern search on "
-                          "a step/%d lattice + neighbouring-basin check (ILCC_SOLVER_GRID)"
+                "solver": "ILCC_SOLVER_GRID: exhaustive %dx%dx%d x 2 grid (%d candidates) + 27-point pattern search (step/%d) + basin check"
                           % (params.n_th, params.n_ty, params.n_tz, n_cand, params.refine_div),
                 "parallelism": "frames sharded across %d GPU(s), one RCCL gather of corner records per step" % world
                                if world > 1 else "1 GPU",
@@ -473,66 +532,79 @@ def main():
                                                ("roi_crop", "cluster", "ransac_plane", "plane_frame_hist", "grid_cost",
                                                 "refine_corners", "total")},
             "roofline": {
-                "kernel": "k6_grid_cost",
+                "kernel": "k6_grid_cost (5 launches per batch: seed, refinement, anchor, k6_group_prepass, full pass)",
                 "bound": "valu",
                 "achieved": valu_rate,
                 "peak": VALU_ISSUE_PEAK_T,
                 "unit": "T lane-instr/s",
                 "frac": valu_rate / VALU_ISSUE_PEAK_T,
+                "frac_what": "credited lane-instr of one batch's K6 launches / k6_ms_alone (HIP events, ONE batch in flight) / peak",
                 "traffic": pmc["traffic_bytes"] if pmc else None,
-                "traffic_note": "HBM bytes of the stage's launches (seed, refinement, anchor, full pass) of one batch of THIS size alone "
-                                "on the chip: (2 x FETCH_SIZE + WRITE_SIZE) x 1024 from separate rocprofv3 --pmc passes, read at run time "
-                                "from %s (tools/gpu_pmc.sh); null when no committed file matches this config / batch size"
-                                % (pmc["file"] if pmc else "profiles/"),
+                "k6_ms_alone": k6_ms_alone,
+                "k6_ms_pipelined": k6_ms,
+                "launch_ms": k6_ms,                                            # (alias of k6_ms_pipelined: rounds 1-4's name, tools/ read it)
+                "full_pass_ms": tm.grid_cost_full_ms_sum / launches,          # (alias of k6_full_pass_ms_pipelined)
+                "k6_locate_ms_alone": tm_alone.grid_cost_locate_ms_sum / la,
+                "k6_prepass_ms_alone": tm_alone.grid_cost_prepass_ms_sum / la,
+                "k6_full_pass_ms_alone": tm_alone.grid_cost_full_ms_sum / la,
+                "k6_locate_ms_pipelined": tm.grid_cost_locate_ms_sum / launches,
+                "k6_prepass_ms_pipelined": tm.grid_cost_prepass_ms_sum / launches,
+                "k6_full_pass_ms_pipelined": tm.grid_cost_full_ms_sum / launches,
+                "frac_pipelined": valu_rate_pipe / VALU_ISSUE_PEAK_T,
+                "frac_of_stage_span": credited_lane_instr / (k6_span_ms * 1e-3) / 1e12 / VALU_ISSUE_PEAK_T if k6_span_ms > 0 else None,
+                "frac_whole_step": credited_lane_instr * B / (elapsed / args.steps) / 1e12 / VALU_ISSUE_PEAK_T,
+                "frac_rocprof_alone": rocprof["in_flight_1"]["frac_this_run"] if rocprof and "in_flight_1" in rocprof else None,
+                "frac_rocprof_pipelined": rocprof["pipelined"]["frac_this_run"] if rocprof and "pipelined" in rocprof else None,
+                "k6_ms_rocprof_alone": rocprof["in_flight_1"]["k6_ms_per_batch"] if rocprof and "in_flight_1" in rocprof else None,
+                "k6_ms_rocprof_pipelined": rocprof["pipelined"]["k6_ms_per_batch"] if rocprof and "pipelined" in rocprof else None,
+                "rocprof_files": ", ".join(v["file"] for v in rocprof.values()) if rocprof else None,
+                "credited_lane_instr_per_batch": credited_lane_instr,
+                "issued_wave_instr_per_batch": pmc["valu_wave_instr"] if pmc else None,
+                "uncredited_share": 1.0 - credited_wave_instr / pmc["valu_wave_instr"] if pmc else None,
+                "wave_instr_per_frame": pmc["valu_wave_instr"] / F if pmc else None,
+                "issue_utilisation_full_pass_alone": (2.0 * pmc["full_pass"]["valu_wave_instr"] /
+                                                      max(1.0, 1024.0 * pmc["full_pass"]["gui_active_cycles_per_xcd"])) if pmc else None,
+                "pmc_file": pmc["file"] if pmc else None,
+                "evals_executed_per_batch": evals_per_launch,
+                "evals_nominal_per_batch": evals_nominal,
+                "executed_fraction": evals_per_launch / evals_nominal if evals_nominal else None,
+                "valu_instr_per_eval": valu_ops_per_eval,
+                "box_evals_per_batch": box_evals,
+                "valu_instr_per_box_eval": K6_VALU_OPS_BOX,
+                "batches_timed": int(tm.grid_cost_launches),
+                "batches_timed_alone": int(tm_alone.grid_cost_launches),
+                "stage_span_ms": k6_span_ms,
+                "walk_order_k5w_ms": tm.walk_order_ms_sum / launches,
+                "step_ms_alone": step_ms_alone,
+                # HBM (north_star's figure): the algorithmic bytes of SURVEY.md 8(d) over the whole step, and K1's count pass alone
+                "hbm_algorithmic_bytes_per_batch": k6_bytes,
+                "hbm_GBps_whole_path": fps / max(1, world) * bytes_per_frame / 1e9,
+                "hbm_frac": fps / max(1, world) * bytes_per_frame / 1e9 / HBM_PEAK_GBPS,
+                "k1_count_ms_alone": k1_ms_alone,
+                "k1_hbm_GBps": k1_GBps,
+                "k1_hbm_frac": k1_GBps / HBM_PEAK_GBPS if k1_GBps else None,
+                "hbm_peak_GBps": HBM_PEAK_GBPS,
+                # SURVEY.md 8(d)'s metric as written (H2D copy inside), filled in below when that leg runs
+                "h2d_inclusive_frames_per_s": None,
+                "link_GBps_achieved": None,
+                "link_GBps_raw_hipMemcpy": None,
+                "link_bound_frames_per_s": None,
+                "link_frac": None,
+                "note": "VALU-bound by construction (points in LDS, no MFMA).  credited = executed evaluations x %g / %g VALU instr "
+                        "(border / interior class) + box evaluations x %g (tools/k6_isa_count.sh: the terms only).  frac FALLS when "
+                        "pruning removes credited work: track wave_instr_per_frame and k6_ms_alone instead" % (
+                            K6_VALU_OPS_BORDER, K6_VALU_OPS_INTERIOR, K6_VALU_OPS_BOX),
+                "rocprof": rocprof,
                 "issued_vs_credited": {
                     "issued_valu_wave_instr_per_launch": pmc["valu_wave_instr"],
                     "credited_valu_wave_instr_per_launch": credited_wave_instr,
-                    "uncredited_share": 1.0 - credited_wave_instr / pmc["valu_wave_instr"],
                     "what": "issued = SQ_INSTS_VALU of the K6 launches of one batch (PMC file, batch alone on the chip); credited = this "
                             "run's executed evaluations x the term's ISA count / 64 lanes.  The difference is bound tests, tile "
                             "prologues, staging, address arithmetic, idle lanes of tail blocks",
                     "full_pass_alone": dict(pmc["full_pass"],
                                             ms_at_2p4GHz=pmc["full_pass"]["gui_active_cycles_per_xcd"] / 2.4e6,
-                                            valu_busy_share=pmc["full_pass"]["valu_busy_quad_cycles"] / max(1.0, pmc["full_pass"]["gui_active_cycles_per_xcd"] * 256.0),
-                                            issue_utilisation=2.0 * pmc["full_pass"]["valu_wave_instr"] / max(1.0, 1024.0 * pmc["full_pass"]["gui_active_cycles_per_xcd"])),
+                                            valu_busy_share=pmc["full_pass"]["valu_busy_quad_cycles"] / max(1.0, pmc["full_pass"]["gui_active_cycles_per_xcd"] * 256.0)),
                 } if pmc else None,
-                "launch_ms": k6_ms,
-                "launch_ms_what": "sum of the four K6 kernel durations of one batch (seed + refinement + anchor + full pass), each "
-                                  "bracketed by HIP events on the batch's stream; averaged over the timed batches",
-                "full_pass_ms": tm.grid_cost_full_ms_sum / launches,
-                "walk_order_k5w_ms": tm.walk_order_ms_sum / launches,
-                "stage_span_ms": k6_span_ms,
-                "stage_span_what": "first K6-stage event to last (the wait for the previous batch's full pass excluded): contains the "
-                                   "gaps in which the short launches wait for a CU beside other batches; rounds 1-3 divided by this",
-                "frac_of_stage_span": credited_lane_instr / (k6_span_ms * 1e-3) / 1e12 / VALU_ISSUE_PEAK_T if k6_span_ms > 0 else None,
-                "rocprof": rocprof,
-                "issue_utilisation_full_pass_alone": (2.0 * pmc["full_pass"]["valu_wave_instr"] /
-                                                      max(1.0, 1024.0 * pmc["full_pass"]["gui_active_cycles_per_xcd"])) if pmc else None,
-                "wave_instr_per_frame": pmc["valu_wave_instr"] / F if pmc else None,
-                "progress_note": "`frac` credits executed evaluations only, so it FALLS whenever pruning removes credited work "
-                                 "(round 2 -> 3: 0.18 -> 0.15 while frames/s rose 2.5x).  The figures that track progress of this "
-                                 "kernel are wave_instr_per_frame (issued VALU wavefront-instructions of the K6 stage per frame, PMC: "
-                                 "1.90 M in round 2, 0.377 M in round 3) and issue_utilisation_full_pass_alone (issued instructions / "
-                                 "issue slots while the full pass has the chip alone)",
-                "launches_timed": int(tm.grid_cost_launches),
-                "evals_executed_per_launch": evals_per_launch,
-                "evals_nominal_per_launch": evals_nominal,
-                "executed_fraction": evals_per_launch / evals_nominal if evals_nominal else None,
-                "valu_instr_per_eval": valu_ops_per_eval,
-                "box_evals_per_launch": box_evals,
-                "valu_instr_per_box_eval": K6_VALU_OPS_BOX,
-                "evals_executed_per_s": evals_per_launch / (k6_ms * 1e-3),
-                "interior_class_fraction_of_executed_evals": evals_interior / max(1.0, evals_per_launch),
-                "hbm": {"algorithmic_bytes_per_launch": k6_bytes, "achieved_GBps": achieved, "peak_GBps": HBM_PEAK_GBPS,
-                        "frac": achieved / HBM_PEAK_GBPS,
-                        "whole_path_GBps": fps / max(1, world) * bytes_per_frame / 1e9,
-                        "whole_path_frac": fps / max(1, world) * bytes_per_frame / 1e9 / HBM_PEAK_GBPS},
-                "note": "k6_grid_cost is VALU-bound by construction (points staged once in LDS, ~1e8 nominal "
-                        "point-candidate evaluations per frame, no MFMA): achieved = (executed evaluations x their VALU "
-                        "instructions (%g border-class, %g interior-class) + the box pre-pass's (point, tile) evaluations x %g; tools/k6_isa_count.sh: the terms only -- bound tests, prologues and address arithmetic are not credited) / launch duration.  The box pre-pass (round 3) rejects a 16-candidate tile with 32 x %g instructions instead of 16 x 8 x %g: executed_fraction and this rate fall while frames/s rise" % (K6_VALU_OPS_BORDER, K6_VALU_OPS_INTERIOR, K6_VALU_OPS_BOX, K6_VALU_OPS_BOX, K6_VALU_OPS_BORDER) + "  launch = the K6 stage of one batch (seed + refinement + anchor + full "
-                        "launch), timed by HIP events on the library's stream (the wait for the previous batch's full pass "
-                        "between the refinement and the full launch is excluded).  `hbm` holds the algorithmic-bytes "
-                        "fraction of the 8 TB/s peak that BASELINE.json asks for",
             },
         }
         if h2d:
@@ -541,10 +613,10 @@ def main():
             out["link_bound_frames_per_s"] = h2d["link_bound_frames_per_s"]
             out["link_frac"] = h2d["value"] / h2d["link_bound_frames_per_s"]
             out["pcie_inclusive"] = {k: v for k, v in h2d.items() if k not in ("hptrs", "hclicks", "keepalive")}
-            out["roofline"]["h2d_link"] = {"bound": "pcie", "achieved": h2d["link_GBps_achieved_per_gpu"], "peak": h2d["link_GBps_raw_hipMemcpy"],
-                                           "unit": "GB/s per GPU", "frac": h2d["link_GBps_achieved_per_gpu"] / h2d["link_GBps_raw_hipMemcpy"],
-                                           "what": "SURVEY.md 8(d)'s frames/s has the host->device copy of XYZI inside: "
-                                                   "value_h2d_inclusive x 16 N bytes over what hipMemcpy alone moves on this link"}
+            out["roofline"].update({"h2d_inclusive_frames_per_s": h2d["value"], "link_GBps_achieved": h2d["link_GBps_achieved_per_gpu"],
+                                    "link_GBps_raw_hipMemcpy": h2d["link_GBps_raw_hipMemcpy"],
+                                    "link_bound_frames_per_s": h2d["link_bound_frames_per_s"],
+                                    "link_frac": h2d["value"] / h2d["link_bound_frames_per_s"]})
         if args.ref_n1 > 0:
             out["weak_scaling_efficiency"] = fps / (world * args.ref_n1)
             out["weak_scaling_reference_n1"] = args.ref_n1
@@ -563,6 +635,16 @@ def main():
             if not args.no_cpu_baseline and args.config == 2:
                 out["cpu_baseline"] = cpu_baseline(clouds.reshape(FS, n_points, 4), clicks.reshape(FS, 3), gts, board,
                                                    args.cpu_seconds, gpu_ref)
+                cb = out["cpu_baseline"]
+                dv = cb.get("gpu_vs_cpu_corner_deviation_mm") or {}
+                cb.update({"all_cores_value": cb["all_cores"]["value"], "all_cores": cb["all_cores"]["cores"],
+                           "all_cores_sample": cb["all_cores"]["sample"],
+                           "gpu_vs_cpu_max_dev_mm": dv.get("max"), "frames_compared": dv.get("frames_compared"),
+                           "status_agree": dv.get("status_agree"),
+                           "gpu_vs_cpu_what": "GPU ILCC_SOLVER_REFERENCE_LOCAL vs this CPU path, same frames, max |dx| over corners",
+                           "gpu_resident_over_cpu_1core": fps / cb["value"],
+                           "gpu_h2d_inclusive_over_cpu_1core": (h2d["value"] / cb["value"]) if h2d else None,
+                           "gpu_h2d_inclusive_over_cpu_all_cores": (h2d["value"] / cb["all_cores_value"]) if h2d else None})
                 # the mode that meets north_star's "within 1e-3 m of the reference CPU path": say so next to its rates
                 out["reference_local_mode"]["gpu_vs_cpu_port_corner_deviation_mm"] = out["cpu_baseline"]["gpu_vs_cpu_corner_deviation_mm"]
         print(json.dumps(out), flush=True)

@@ -36,7 +36,7 @@ extern "C" {
 #endif
 
 #define ILCC_MAX_CORNERS 256
-#define ILCC_ABI_VERSION 4
+#define ILCC_ABI_VERSION 5
 
 /* per-frame / per-call status */
 enum {
@@ -187,13 +187,20 @@ typedef struct ilcc_timing {
                                             translation of the grid (cheaper term: no out-of-board logic) */
   uint64_t grid_cost_box_evals_sum; /* (point, 16-candidate tile) evaluations of the box pre-pass: a lower bound for a whole
                                        tile at once (not part of grid_cost_evals_sum) */
-  /* ABI 4: the K6 stage kernel by kernel.  grid_cost_ms_sum above is the SPAN of the stage between two HIP events on the
-   * batch's stream -- with other batches in flight it contains the gaps in which the stage's short launches wait for a
-   * CU.  The four kernels are also bracketed one by one (seed, refinement, anchor, full pass): their summed durations are
-   * what a rocprofv3 kernel trace of the same run adds up to. */
-  double grid_cost_kernel_ms_sum;   /* sum over batches of (seed + refinement + anchor + full pass) kernel durations, ms */
+  /* ABI 4/5: the K6 stage launch by launch.  grid_cost_ms_sum above is the SPAN of the stage between two HIP events on the
+   * batch's stream.  The stage's launches are also bracketed one by one -- locate launches (seed, refinement, anchor),
+   * common pre-pass, full pass -- by HIP events on the same stream: EVENT SPANS per launch, i.e. a kernel's duration plus,
+   * with other batches in flight, whatever it waited for a CU behind the event in front of it.  With one batch in flight
+   * (nothing else on the chip) they are what a rocprofv3 kernel trace of the same run adds up to. */
+  double grid_cost_kernel_ms_sum;   /* sum over batches of the event spans of seed + refinement + anchor + common pre-pass + full pass, ms */
   double grid_cost_full_ms_sum;     /* the full pass alone */
   double walk_order_ms_sum;         /* K5w (once per frame, in front of the K6 launches) */
+  double grid_cost_prepass_ms_sum;  /* ABI 5: the common pre-pass (k6_group_prepass) alone; it is part of grid_cost_kernel_ms_sum */
+  double grid_cost_locate_ms_sum;   /* ABI 5: seed + refinement + anchor (the launches that only locate the minimum and publish the bound) */
+  /* ABI 5: every stage accumulated over the batches since ilcc_reset_timing (the float fields above are the LAST batch only) */
+  uint64_t batches;                 /* batches accounted */
+  double stage_ms_sum[7];           /* roi_crop, cluster, ransac_plane, plane_frame_hist, grid_cost, refine_corners, total */
+  double roi_count_ms_sum;          /* K1's count pass alone -- the kernel that reads every input point once (the HBM-bound one) */
 } ilcc_timing;
 
 int32_t ilcc_abi_version(void);
@@ -280,8 +287,12 @@ int32_t ilcc_wait_records_device(ilcc_handle* h, int32_t ticket, ilcc_result* ou
  * synchronous copy inside the wait).  Default: ILCC_RESULTS_FULL. */
 enum { ILCC_RESULTS_FULL = 0, ILCC_RESULTS_COMPACT = 1 };
 int32_t ilcc_set_result_mode(ilcc_handle* h, int32_t mode);   /* no batch may be in flight */
-/* records: n_frames x (ILCC_RECORD_HEADER + 3 * (board_w - 1) * (board_h - 1)) floats, host memory */
-int32_t ilcc_wait_compact(ilcc_handle* h, int32_t ticket, float* records);
+/* records: host memory for n_frames x (ILCC_RECORD_HEADER + 3 * n_corners) floats, n_corners = (board_w - 1) * (board_h - 1) of
+ * the parameters the batch was SUBMITTED with.  capacity_floats (ABI 5) = the floats `records` can hold: the call returns
+ * ILCC_BAD_ARGUMENT (nothing copied, the batch stays waitable) when that is less than the batch needs. */
+int32_t ilcc_wait_compact(ilcc_handle* h, int32_t ticket, float* records, uint64_t capacity_floats);
+/* floats per record of the batch in flight under `ticket` (0: no such batch) */
+uint32_t ilcc_record_floats(const ilcc_handle* h, int32_t ticket);
 /* full records [first, first + n) of the last completed batch, copied from HBM (synchronous) */
 int32_t ilcc_fetch_results(ilcc_handle* h, uint32_t first, uint32_t n, ilcc_result* out);
 

@@ -30,9 +30,9 @@ EXPORTS = [
     "ilcc_extract_batch", "ilcc_extract_batch_device", "ilcc_submit_batch_device", "ilcc_submit_batch", "ilcc_wait", "ilcc_wait_records_device", "ilcc_fetch_cloud", "ilcc_fetch_labelled", "ilcc_fetch_walk", "ilcc_chessboard_by_point_batch", "ilcc_fetch_classes",
     "ilcc_grid_cost", "ilcc_pattern_refine", "ilcc_get_theta_t", "ilcc_get_timing", "ilcc_reset_timing",
     "ilcc_save_corners2txt", "ilcc_read_lidar_corners",
-    "ilcc_set_result_mode", "ilcc_wait_compact", "ilcc_fetch_results",
+    "ilcc_set_result_mode", "ilcc_wait_compact", "ilcc_record_floats", "ilcc_fetch_results",
 ]
-ABI_VERSION = 4            # the layout of Params / Result / Timing below is ILCC_ABI_VERSION 4 of include/ilcc_hip.h
+ABI_VERSION = 5            # the layout of Params / Result / Timing below is ILCC_ABI_VERSION 5 of include/ilcc_hip.h
 RESULTS_FULL, RESULTS_COMPACT = 0, 1
 
 
@@ -111,6 +111,11 @@ class Timing(C.Structure):
         ("grid_cost_kernel_ms_sum", C.c_double),
         ("grid_cost_full_ms_sum", C.c_double),
         ("walk_order_ms_sum", C.c_double),
+        ("grid_cost_prepass_ms_sum", C.c_double),
+        ("grid_cost_locate_ms_sum", C.c_double),
+        ("batches", C.c_uint64),
+        ("stage_ms_sum", C.c_double * 7),
+        ("roi_count_ms_sum", C.c_double),
     ]
 
 
@@ -189,8 +194,10 @@ def lib():
         L.ilcc_read_lidar_corners.restype = C.c_int32
         L.ilcc_set_result_mode.argtypes = [vp, C.c_int32]
         L.ilcc_set_result_mode.restype = C.c_int32
-        L.ilcc_wait_compact.argtypes = [vp, C.c_int32, fp]
+        L.ilcc_wait_compact.argtypes = [vp, C.c_int32, fp, C.c_uint64]
         L.ilcc_wait_compact.restype = C.c_int32
+        L.ilcc_record_floats.argtypes = [vp, C.c_int32]
+        L.ilcc_record_floats.restype = C.c_uint32
         L.ilcc_fetch_results.argtypes = [vp, C.c_uint32, C.c_uint32, rp]
         L.ilcc_fetch_results.restype = C.c_int32
         _lib = L

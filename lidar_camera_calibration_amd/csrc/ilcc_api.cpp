@@ -27,8 +27,8 @@ constexpr int kSlots = ILCC_SLOTS;   // batches in flight per handle (submit/wai
 // One in-flight batch: its own stream, events, stage buffers and pinned result staging.
 struct Slot {
   hipStream_t stream = nullptr;
-  hipEvent_t ev[10]{};   // 0..6 stage boundaries; 7, 8: end of K6's seed + refinement passes / start of its full pass
-  hipEvent_t k6ev[3]{};  // inside the K6 stage: after K5w, after the seed launch, after the refinement launch (kernel-by-kernel durations)
+  hipEvent_t ev[10]{};   // 0..6 stage boundaries; 7, 8: end of K6's seed + refinement passes / start of its full pass; 9: behind K1's count pass
+  hipEvent_t k6ev[4]{};  // inside the K6 stage: after K5w, after the seed launch, after the refinement launch, after the anchor launch (launch-by-launch event spans)
   hipEvent_t k6_done = nullptr;
   bool allocated = false;
   // device buffers
@@ -50,8 +50,8 @@ struct Slot {
   uint32_t* d_tie_count = nullptr;
   GridPartial* d_tie_list = nullptr;
   unsigned long long* d_iters = nullptr;
-  uint32_t *d_tri_alive = nullptr, *d_tri_mask = nullptr;   // K6's common pre-pass per (frame, triple of thetas): state word, rejected-tile mask
-  size_t tri_alive_cap = 0, tri_mask_cap = 0;
+  uint32_t *d_grp_alive = nullptr, *d_grp_mask = nullptr;   // K6's common pre-pass per (frame, group of kThetaGroup thetas): state word, rejected-tile mask
+  size_t grp_alive_cap = 0, grp_mask_cap = 0;   // sized from (max_frames, the handle's grid) in alloc_slot / ilcc_set_params, never in the submit path
   float* d_rec = nullptr;    // K9 records of the batch (ILCC_RESULTS_COMPACT): max_frames x (ILCC_RECORD_HEADER + 3 ILCC_MAX_CORNERS) floats
   // pinned host staging
   float* h_rec = nullptr;
@@ -244,7 +244,7 @@ int32_t upload_tables(ilcc_handle* h) {
 }
 
 void free_slot(Slot& sl) {
-  void* bufs[] = {sl.d_tri_alive, sl.d_tri_mask, sl.d_rec, sl.d_xyzi, sl.d_clicks, sl.d_off, sl.d_res, sl.d_roi, sl.d_cluster, sl.d_board, sl.d_pca, sl.d_optim,
+  void* bufs[] = {sl.d_grp_alive, sl.d_grp_mask, sl.d_rec, sl.d_xyzi, sl.d_clicks, sl.d_off, sl.d_res, sl.d_roi, sl.d_cluster, sl.d_board, sl.d_pca, sl.d_optim,
                   sl.d_yz, sl.d_walk_yz, sl.d_walk_lab, sl.d_walk_mi, sl.d_walk_nrim, sl.d_lab, sl.d_cls, sl.d_nlab, sl.d_walk, sl.d_counts, sl.d_parent, sl.d_count, sl.d_hash_head, sl.d_hash_next, sl.d_big, sl.d_partial, sl.d_partial2, sl.d_partial3, sl.d_partial4, sl.d_masks,
                   sl.d_solverec, sl.d_bound, sl.d_bound_sub, sl.d_iters, sl.d_tie_count, sl.d_tie_list};
   for (void* b : bufs)
@@ -277,6 +277,50 @@ void warn_hw_queues_once(int slot_index) {
                  "queue with another one and serialises; keep at most 3 tickets outstanding or export GPU_MAX_HW_QUEUES=8 "
                  "before the HIP runtime starts (the library does not modify the environment)\n", v ? v : "(unset: HIP's default is 4)");
   });
+}
+
+// K6's common pre-pass: does the handle's grid qualify, and what its output needs per frame
+struct GroupPrepassPlan {
+  bool on = false;
+  uint32_t groups = 0, words = 0;   // theta groups per frame = ceil(n_th / kThetaGroup); mask words per group = ceil(tiles / 32)
+};
+GroupPrepassPlan group_prepass_plan(const ilcc_params& p) {
+  GroupPrepassPlan g;
+  // box pre-pass (k6_grid_cost.hip): its monotonicity argument needs a tile's box narrower than one square on both axes
+  const bool box = p.grid_prune != 0 && 3.0 * p.ty_step < 0.9 * p.grid_length && 3.0 * p.tz_step < 0.9 * p.grid_length;
+  // ... and, for the points the common pre-pass leaves out, every translation of the tables keeping the board's centre inside the board
+  const double gl = p.grid_length;
+  const double ty_hi = p.ty_min + (p.n_ty - 1) * p.ty_step, tz_hi = p.tz_min + (p.n_tz - 1) * p.tz_step;
+  const bool centre_in = p.ty_min > -0.45 * p.board_w * gl && ty_hi < 0.45 * p.board_w * gl && p.tz_min > -0.45 * p.board_h * gl &&
+                         tz_hi < 0.45 * p.board_h * gl;
+  const uint32_t n_tiles = (uint32_t)(((p.n_ty + 3) / 4) * ((p.n_tz + 3) / 4));
+  g.on = box && p.n_th >= kThetaGroup && centre_in && n_tiles <= 4096u;
+  g.groups = (uint32_t)((p.n_th + kThetaGroup - 1) / kThetaGroup);
+  g.words = (n_tiles + 31u) / 32u;
+  return g;
+}
+
+// (re)size a slot's common pre-pass buffers for the handle's current grid.  hipFree synchronises the device, so this runs
+// where no batch can be in flight: alloc_slot (a slot's first use) and ilcc_set_params -- never inside a submit.
+int32_t size_group_prepass(ilcc_handle* h, Slot& sl) {
+  const GroupPrepassPlan g = group_prepass_plan(h->p);
+  if (!g.on) return ILCC_OK;
+  const size_t need_alive = (size_t)h->max_frames * g.groups, need_mask = need_alive * g.words;
+  if (need_alive > sl.grp_alive_cap) {
+    if (sl.d_grp_alive) (void)hipFree(sl.d_grp_alive);
+    sl.d_grp_alive = nullptr;
+    sl.grp_alive_cap = 0;
+    HIP_TRY(h, hipMalloc((void**)&sl.d_grp_alive, sizeof(uint32_t) * need_alive));
+    sl.grp_alive_cap = need_alive;
+  }
+  if (need_mask > sl.grp_mask_cap) {
+    if (sl.d_grp_mask) (void)hipFree(sl.d_grp_mask);
+    sl.d_grp_mask = nullptr;
+    sl.grp_mask_cap = 0;
+    HIP_TRY(h, hipMalloc((void**)&sl.d_grp_mask, sizeof(uint32_t) * need_mask));
+    sl.grp_mask_cap = need_mask;
+  }
+  return ILCC_OK;
 }
 
 int32_t alloc_slot(ilcc_handle* h, Slot& sl) {
@@ -330,6 +374,10 @@ int32_t alloc_slot(ilcc_handle* h, Slot& sl) {
   HIP_TRY(h, hipHostMalloc((void**)&sl.h_rec, sizeof(float) * (size_t)mf * (ILCC_RECORD_HEADER + 3 * ILCC_MAX_CORNERS), hipHostMallocDefault));
   HIP_TRY(h, hipHostMalloc((void**)&sl.h_iters, sizeof(unsigned long long) * kBatchWords, hipHostMallocDefault));
   HIP_TRY(h, hipHostMalloc((void**)&sl.h_off, sizeof(uint64_t) * (mf + 1), hipHostMallocDefault));
+  {
+    const int32_t st = size_group_prepass(h, sl);
+    if (st != ILCC_OK) return st;
+  }
   sl.allocated = true;
   return ILCC_OK;
 }
@@ -494,7 +542,7 @@ int32_t enqueue_impl(ilcc_handle* h, int si, const float4* d_xyzi, const uint64_
   }
 
   HIP_TRY(h, hipEventRecord(sl.ev[0], s));
-  launch_roi_crop(c, s);
+  launch_roi_crop(c, s, sl.ev[9]);   // ev[9]: between the count pass and the scatter
   HIP_TRY(h, hipEventRecord(sl.ev[1], s));
   launch_cluster(c, s);
   HIP_TRY(h, hipEventRecord(sl.ev[2], s));
@@ -603,46 +651,26 @@ int32_t enqueue_impl(ilcc_handle* h, int si, const float4* d_xyzi, const uint64_
 #ifndef ILCC_BOX_POINTS
 #define ILCC_BOX_POINTS 48   // 16: 461 k, 32: 485 k, 48: 487 k, 64: 484 k, 96: 474 k frames/s when it was introduced; with the one-tile anchor 32: 578 k, 48: 590 k
 #endif
+    const GroupPrepassPlan gp = group_prepass_plan(h->p);
     // box pre-pass (k6_grid_cost.hip): its monotonicity argument needs a tile's box narrower than one square on both axes
     full.box_points = (prune && 3.0 * h->p.ty_step < 0.9 * h->p.grid_length && 3.0 * h->p.tz_step < 0.9 * h->p.grid_length) ? (uint32_t)ILCC_BOX_POINTS : 0u;
-#ifndef ILCC_K6_TRIPLE
-#define ILCC_K6_TRIPLE 1
-#endif
-    {
-      // k6_triple_prepass: one box pre-pass for three consecutive thetas, launched HERE -- behind the anchor (it needs the frame's
-      // bound), in front of the wait for the previous batch's full pass, so it runs beside that pass like the other small
-      // launches.  Conditions: the per-theta pre-pass's own and, for the points it leaves out, every translation of the
-      // tables keeping the board's centre inside the board.
-      const double g = h->p.grid_length;
-      const double ty_hi = h->p.ty_min + (h->p.n_ty - 1) * h->p.ty_step, tz_hi = h->p.tz_min + (h->p.n_tz - 1) * h->p.tz_step;
-      const bool centre_in = h->p.ty_min > -0.45 * h->p.board_w * g && ty_hi < 0.45 * h->p.board_w * g && h->p.tz_min > -0.45 * h->p.board_h * g &&
-                             tz_hi < 0.45 * h->p.board_h * g;
-      const uint32_t n_tiles = (uint32_t)(((h->p.n_ty + 3) / 4) * ((h->p.n_tz + 3) / 4));
-      if (ILCC_K6_TRIPLE && full.box_points != 0u && h->p.n_th >= kThetaGroup && centre_in && n_tiles <= 4096u) {
-        full.tri_count = (uint32_t)((h->p.n_th + kThetaGroup - 1) / kThetaGroup);
-        full.tri_words = (n_tiles + 31u) / 32u;
-        const size_t need_alive = (size_t)n_frames * full.tri_count, need_mask = need_alive * full.tri_words;
-        if (need_alive > sl.tri_alive_cap) {
-          if (sl.d_tri_alive) (void)hipFree(sl.d_tri_alive);
-          sl.d_tri_alive = nullptr;
-          sl.tri_alive_cap = 0;
-          HIP_TRY(h, hipMalloc((void**)&sl.d_tri_alive, sizeof(uint32_t) * need_alive));
-          sl.tri_alive_cap = need_alive;
-        }
-        if (need_mask > sl.tri_mask_cap) {
-          if (sl.d_tri_mask) (void)hipFree(sl.d_tri_mask);
-          sl.d_tri_mask = nullptr;
-          sl.tri_mask_cap = 0;
-          HIP_TRY(h, hipMalloc((void**)&sl.d_tri_mask, sizeof(uint32_t) * need_mask));
-          sl.tri_mask_cap = need_mask;
-        }
-        launch_triple_prepass(full, s, sl.d_tri_alive, sl.d_tri_mask);
-        full.tri_alive = sl.d_tri_alive;
-        full.tri_mask = sl.d_tri_mask;
-      }
-    }
     if (!ev1) HIP_TRY(h, hipEventRecord(sl.k6ev[1], s));
     if (!ev2) HIP_TRY(h, hipEventRecord(sl.k6ev[2], s));
+    HIP_TRY(h, hipEventRecord(sl.k6ev[3], s));   // behind the anchor launch: the common pre-pass gets an event span of its own
+#ifndef ILCC_K6_GROUP_PREPASS
+#define ILCC_K6_GROUP_PREPASS 1
+#endif
+    // k6_group_prepass: one box pre-pass for kThetaGroup consecutive thetas, launched HERE -- behind the anchor (it needs the
+    // frame's bound), in front of the wait for the previous batch's full pass, so it runs beside that pass like the other small
+    // launches.  Its buffers were sized for (max_frames, this grid) by alloc_slot / ilcc_set_params.
+    if (ILCC_K6_GROUP_PREPASS && full.box_points != 0u && gp.on && (size_t)n_frames * gp.groups <= sl.grp_alive_cap &&
+        (size_t)n_frames * gp.groups * gp.words <= sl.grp_mask_cap) {
+      full.grp_count = gp.groups;
+      full.grp_words = gp.words;
+      launch_group_prepass(full, s, sl.d_grp_alive, sl.d_grp_mask);
+      full.grp_alive = sl.d_grp_alive;
+      full.grp_mask = sl.d_grp_mask;
+    }
     HIP_TRY(h, hipEventRecord(sl.ev[7], s));
 #ifndef ILCC_K6_CHAIN
 #define ILCC_K6_CHAIN 1   // (A/B builds: 0 lets the full passes of different batches overlap)
@@ -715,7 +743,7 @@ int32_t finish(ilcc_handle* h, int si, ilcc_result* out, float* out_compact = nu
   if (out_compact) std::memcpy(out_compact, sl.h_rec, sizeof(float) * n_frames * rec_w);
   float ms[6];
   for (int k = 0; k < 6; ++k) HIP_TRY(h, hipEventElapsedTime(&ms[k], sl.ev[k], sl.ev[k + 1]));
-  float k6k[5] = {0.f, 0.f, 0.f, 0.f, 0.f};   // K5w, seed, refinement, anchor, full pass
+  float k6k[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // K5w, seed, refinement, anchor, common pre-pass, full pass
   if (sl.grid) {   // K6 = (seed + refinement passes) + (full pass); the wait for the previous batch's full pass in between is not K6 time
     float pre = 0.f, fullp = 0.f;
     HIP_TRY(h, hipEventElapsedTime(&pre, sl.ev[4], sl.ev[7]));
@@ -724,8 +752,9 @@ int32_t finish(ilcc_handle* h, int si, ilcc_result* out, float* out_compact = nu
     HIP_TRY(h, hipEventElapsedTime(&k6k[0], sl.ev[4], sl.k6ev[0]));
     HIP_TRY(h, hipEventElapsedTime(&k6k[1], sl.k6ev[0], sl.k6ev[1]));
     HIP_TRY(h, hipEventElapsedTime(&k6k[2], sl.k6ev[1], sl.k6ev[2]));
-    HIP_TRY(h, hipEventElapsedTime(&k6k[3], sl.k6ev[2], sl.ev[7]));
-    k6k[4] = fullp;
+    HIP_TRY(h, hipEventElapsedTime(&k6k[3], sl.k6ev[2], sl.k6ev[3]));
+    HIP_TRY(h, hipEventElapsedTime(&k6k[4], sl.k6ev[3], sl.ev[7]));
+    k6k[5] = fullp;
   }
   float tot = 0;
   HIP_TRY(h, hipEventElapsedTime(&tot, sl.ev[0], sl.ev[6]));
@@ -737,6 +766,14 @@ int32_t finish(ilcc_handle* h, int si, ilcc_result* out, float* out_compact = nu
   t.grid_cost = ms[4];
   t.refine_corners = ms[5];
   t.total = tot;
+  t.batches += 1;
+  for (int k = 0; k < 6; ++k) t.stage_ms_sum[k] += ms[k];
+  t.stage_ms_sum[6] += tot;
+  {
+    float cnt = 0.f;
+    HIP_TRY(h, hipEventElapsedTime(&cnt, sl.ev[0], sl.ev[9]));
+    t.roi_count_ms_sum += cnt;
+  }
   uint32_t max_lab = 0, max_roi = 0;
   uint64_t evals = 0;
   for (uint32_t f = 0; f < n_frames; ++f) {
@@ -763,8 +800,10 @@ int32_t finish(ilcc_handle* h, int si, ilcc_result* out, float* out_compact = nu
     t.grid_cost_launches += 1;
     t.grid_cost_ms_sum += ms[4];
     t.walk_order_ms_sum += k6k[0];
-    t.grid_cost_kernel_ms_sum += (double)k6k[1] + k6k[2] + k6k[3] + k6k[4];
-    t.grid_cost_full_ms_sum += k6k[4];
+    t.grid_cost_kernel_ms_sum += (double)k6k[1] + k6k[2] + k6k[3] + k6k[4] + k6k[5];
+    t.grid_cost_locate_ms_sum += (double)k6k[1] + k6k[2] + k6k[3];
+    t.grid_cost_prepass_ms_sum += k6k[4];
+    t.grid_cost_full_ms_sum += k6k[5];
     t.grid_cost_evals_nominal_sum += evals;
     // (both colour phases of a (point, candidate) pair = 1 evaluation)
     unsigned long long iters = 0;
@@ -1006,6 +1045,8 @@ int32_t ilcc_set_params(ilcc_handle* h, const ilcc_params* p) {
   const ilcc_params old = h->p;
   h->p = *p;
   st = upload_tables(h);
+  for (Slot& sl : h->slots)   // the common pre-pass's buffers follow the grid (no batch is in flight here)
+    if (st == ILCC_OK && sl.allocated) st = size_group_prepass(h, sl);
   if (st != ILCC_OK) {
     // the device tables may be partly overwritten: put the previous parameter set back on the device as well, and refuse
     // further work if even that fails
@@ -1115,10 +1156,24 @@ int32_t ilcc_set_result_mode(ilcc_handle* h, int32_t mode) {
   return ILCC_OK;
 }
 
-int32_t ilcc_wait_compact(ilcc_handle* h, int32_t ticket, float* records) {
+uint32_t ilcc_record_floats(const ilcc_handle* h, int32_t ticket) {
+  if (!h || ticket < 0 || ticket >= kSlots || !h->slots[ticket].busy) return 0u;
+  return (uint32_t)ILCC_RECORD_HEADER + 3u * h->slots[ticket].rec_corners;
+}
+
+int32_t ilcc_wait_compact(ilcc_handle* h, int32_t ticket, float* records, uint64_t capacity_floats) {
   if (!h || !records || ticket < 0 || ticket >= kSlots || !h->slots[ticket].busy) {
     if (h) h->err = "ilcc_wait_compact: no batch in flight under this ticket";
     return ILCC_BAD_ARGUMENT;
+  }
+  {
+    const Slot& sl = h->slots[ticket];   // the record width was fixed when the batch was submitted
+    const uint64_t need = (uint64_t)sl.n_frames * ((uint64_t)ILCC_RECORD_HEADER + 3ull * sl.rec_corners);
+    if (capacity_floats < need) {
+      h->err = "ilcc_wait_compact: the batch's records need " + std::to_string(need) + " floats, the buffer holds " +
+               std::to_string(capacity_floats) + " (the batch stays in flight)";
+      return ILCC_BAD_ARGUMENT;
+    }
   }
   HIP_TRY(h, hipSetDevice(h->device));
   return finish(h, ticket, nullptr, records);

@@ -51,7 +51,7 @@ constexpr int kTileB = ILCC_TILE_B;    // K6 candidate tile: tz values per wavef
 #ifndef ILCC_K6_GROUP
 #define ILCC_K6_GROUP 5   // measured (config 2 / config 5, k frames/s): 2: 821 / 50.9, 3: 837 / 54.5, 4: 837 / 55.1, 5: 842 / 56.2, 7: 841 / 56.3
 #endif
-constexpr int kThetaGroup = ILCC_K6_GROUP;   // K6: consecutive thetas that share one common box pre-pass (k6_triple_prepass)
+constexpr int kThetaGroup = ILCC_K6_GROUP;   // K6: consecutive thetas that share one common box pre-pass (k6_group_prepass)
 constexpr int kGridLdsPointsMax = 8192;   // K6 LDS staging upper bound (12 B per point -> 96 KiB)
 constexpr int kGridTableMax = 8192;       // K6: n_ty + n_tz bound (their tables sit in LDS behind the points: 32 KiB)
 #ifndef ILCC_K7_THREADS
@@ -153,10 +153,10 @@ struct Ctx {
   GridPartial* tie_list;     // n_frames x kTieCap: cost (fp32), d2, flat
   unsigned long long* grid_iters;  // executed K6 work in counts of grid_cost_evals_per_count() evaluations, for the VALU rate
   uint32_t box_points;             // K6 full pass: border-class walk positions the box pre-pass looks at per tile (0: no pre-pass)
-  // K6 full pass behind k6_triple_prepass (nullptr: no common pre-pass): per (frame, group of kThetaGroup thetas) a state word and a bit mask
-  const uint32_t* tri_alive;
-  const uint32_t* tri_mask;
-  uint32_t tri_count, tri_words;   // theta groups per frame = ceil(n_th / kThetaGroup); mask words per group = ceil(tiles / 32)
+  // K6 full pass behind k6_group_prepass (nullptr: no common pre-pass): per (frame, group of kThetaGroup thetas) a state word and a bit mask
+  const uint32_t* grp_alive;
+  const uint32_t* grp_mask;
+  uint32_t grp_count, grp_words;   // theta groups per frame = ceil(n_th / kThetaGroup); mask words per group = ceil(tiles / 32)
   // seeding pass of the branch-and-bound (a decimated subset of the same grid, evaluated first)
   const GridPartial* seed_partial; // n_frames x seed_blocks, nullptr when this launch is the seed pass / unused
   uint32_t seed_blocks;
@@ -270,14 +270,14 @@ __device__ __forceinline__ uint32_t block_rank(bool flag, uint32_t* scratch, uin
 }
 
 // ---------------------------------------------------------------- launchers (one per stage TU)
-void launch_roi_crop(const Ctx& c, hipStream_t s);
+void launch_roi_crop(const Ctx& c, hipStream_t s, hipEvent_t after_count = nullptr);   // after_count: recorded between the count pass and the scatter
 void launch_cluster(const Ctx& c, hipStream_t s);
 void launch_ransac_plane(const Ctx& c, hipStream_t s);
 void launch_plane_frame_hist(const Ctx& c, hipStream_t s);
 void launch_walk_order(const Ctx& c, hipStream_t s);   // K5w (k6_grid_cost.hip): before any launch_grid_cost on the frames
 void launch_grid_cost(const Ctx& c, hipStream_t s, int32_t use_oob, float* cost_volume /*nullable*/,
                       bool prune);
-void launch_triple_prepass(const Ctx& c, hipStream_t s, uint32_t* tri_alive, uint32_t* tri_mask);   // in front of the full pass (c.tri_count, c.tri_words set)
+void launch_group_prepass(const Ctx& c, hipStream_t s, uint32_t* grp_alive, uint32_t* grp_mask);   // in front of the full pass (c.grp_count, c.grp_words set)
 uint32_t grid_cost_evals_per_count();   // (point, candidate) evaluations behind one count of Ctx::grid_iters
 void launch_refine_corners(const Ctx& c, hipStream_t s);
 void launch_pack_records(const ilcc_result* d_res, uint32_t n_frames, uint32_t n_corners, uint32_t tag_base, float* d_out,

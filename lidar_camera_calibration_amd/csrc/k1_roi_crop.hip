@@ -157,9 +157,10 @@ __global__ __launch_bounds__(kCropThreads) void k1_roi_scatter(Ctx c) {
   }
 }
 
-void launch_roi_crop(const Ctx& c, hipStream_t s) {
+void launch_roi_crop(const Ctx& c, hipStream_t s, hipEvent_t after_count) {
   const dim3 grid(c.crop_chunks, c.n_frames);
   hipLaunchKernelGGL(k1_roi_count, grid, dim3(kCropThreads), 0, s, c);
+  if (after_count) (void)hipEventRecord(after_count, s);
   hipLaunchKernelGGL(k1_roi_scatter, grid, dim3(kCropThreads), 0, s, c);
 }
 

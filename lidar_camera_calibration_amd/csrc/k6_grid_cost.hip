@@ -5,7 +5,7 @@
 // for EVERY candidate of an exhaustive (theta, ty, tz) x colour-phase grid (the reference only
 // walks this surface locally with Ceres from (0,0,0)).
 //
-// (Round 4: k6_triple_prepass, further down, runs ONE such pre-pass for five consecutive thetas in front of the full pass; a
+// (Round 4: k6_group_prepass, further down, runs ONE such pre-pass for five consecutive thetas in front of the full pass; a
 // full-pass workgroup starts from its group's rejected-tile mask, or exits at once when the group left no tile.)
 // Mapping (gfx950): workgroup = (frame, theta index), 4 wavefronts (8 on frames staged above 2048 points).  The frame's
 // labelled points are rotated by the workgroup's theta and staged ONCE into LDS.  A wavefront owns a tile of
@@ -57,37 +57,21 @@ __device__ unsigned long long k6_prof[kProfWaves * kProfWords];   // one record 
 #else
 #define K6_NOW() 0ull
 #endif
-#ifndef ILCC_SEED_SHIFT
-#define ILCC_SEED_SHIFT 3   // subsampled launches walk M >> ILCC_SEED_SHIFT positions (at least Ctx::walk_limit)
-#endif
-#ifndef ILCC_K6_BOUND_REFRESH
-#define ILCC_K6_BOUND_REFRESH 256
-#endif
+// Tuned constants (the measurements behind each value are in DESIGN.md section 4, "K6 tuning record")
+constexpr int kSeedShift = 3;     // subsampled (locate) launches walk M >> kSeedShift positions, at least Ctx::walk_limit
 constexpr int kTile = 4;          // 4 x 4 candidates per wavefront; lane = ((a << 2) | b) << 2 | slice
 constexpr int kSlices = 4;        // lanes (one quad) sharing a candidate, each on every 4th point of the walk
-#ifndef ILCC_K6_UNROLL
-#define ILCC_K6_UNROLL 2
-#endif
-constexpr int kUnroll = ILCC_K6_UNROLL;        // points per lane and block (round 1, one class of points: 2: 179 k, 3: 181 k, 4: 178 k, 6: 167 k
-                                               // frames/s; round 2, two classes, test after every border block only: 2: 245.6 k, 3: 238 k, 4: 227 k)
+constexpr int kUnroll = 2;        // points per lane and block of the generic walk
 constexpr int kStep = kSlices * kUnroll;
-#ifndef ILCC_BOX_SHIFT
-#define ILCC_BOX_SHIFT 3   // box pre-pass: at least 1/8 of the frame's labelled points per tile (and at least Ctx::box_points).  Round 3: 1/32
-                           // (config 5: 1/16: 15.6 k, 1/32: 15.4 k, 1/64: 13.6 k frames/s).  Measured again in round 4, once the rest of
-                           // the path had become cheaper: config 2 (1 007 points, 100 tiles per workgroup) shift 5 / 4 / 3 / 2 / 1 / 0:
-                           // 776 / 792 / 798 / 770 / 690 / 667 k frames/s
-#endif
-#ifndef ILCC_BOX_SHIFT_LARGE
-#define ILCC_BOX_SHIFT_LARGE 2   // the 512-thread instance (config 5: 4 300 points, 1 089 tiles per workgroup) shift 6 / 5 / 4 / 3 / 2 / 1 / 0:
-                                 // 17.3 / 24.2 / 34.7 / 38.6 / 41.9 / 39.3 / 39.3 k frames/s
-#endif
-#ifndef ILCC_BOX_CHECK
-#define ILCC_BOX_CHECK 8   // round 4 (pre-pass over 1/8 of the points): 2: 771 k, 4: 774 k, 8: 785 k frames/s
-#endif
-constexpr int kBoxCheck = ILCC_BOX_CHECK;          // box pre-pass: points per lane between two looks at "is every tile of this wavefront beaten already"
+constexpr int kBoxShiftSmall = 3;   // box pre-pass: at least 1/8 of the frame's labelled points per tile (and at least Ctx::box_points) ...
+constexpr int kBoxShiftLarge = 2;   // ... 1/4 in the 512-thread instance (frames of several thousand labelled points)
+constexpr int kGroupShiftDelta = -1;   // the common pre-pass (k6_group_prepass) looks at M >> (kBoxShift + delta) points: twice each theta's own sample
+static_assert(kBoxShiftSmall + kGroupShiftDelta >= 1 && kBoxShiftLarge + kGroupShiftDelta >= 1,
+              "k6_group_prepass stages M >> (kBoxShift + kGroupShiftDelta) <= M / 2 points: launch_group_prepass sizes its LDS for that");
+constexpr int kBoxCheck = 8;          // box pre-pass: points per lane between two looks at "is every tile of this wavefront beaten already"
 constexpr int kBoxTilesMax = 4096;                 // box pre-pass: tiles per workgroup its LDS bit mask holds
 constexpr float kBoxSafety = 1.f - 0x1p-12f;
-constexpr int kBoundRefresh = ILCC_K6_BOUND_REFRESH; // points between reloads of the frame's shared bound
+constexpr int kBoundRefresh = 256;                  // points between reloads of the frame's shared bound
 
 // sum over the 4 lanes of a quad (every lane gets the total): two DPP adds
 __device__ __forceinline__ float quad_sum(float v) {
@@ -120,22 +104,9 @@ __device__ __forceinline__ void accumulate(const PointTerms& p, float ay, float 
   const float mf = __builtin_amdgcn_fractf(fmaf(0.5f, fi + fj, p.hw));   // 0.5 iff (floor i + floor j + white) odd
   const float nmf = 0.5f - mf;
   const float ui = fabsf(i - Wh) - Wh, uj = fabsf(j - Hh) - Hh; // < 0 inside; |.| = min(|i|, |i-W|)
-#ifndef ILCC_K6_ARITH_SELECT
-#define ILCC_K6_ARITH_SELECT 0   // measured: 385 k (arithmetic) vs 388-391 k (selects) frames/s -- fewer and "faster" instructions, no gain: kept off
-#endif
-  float R, w0, w1;
-  if (OOB && ILCC_K6_ARITH_SELECT) {
-    // out-of-board as a 0 / 1 FACTOR instead of a compare and three selects (v_cmp and v_cndmask issue at half the rate of
-    // v_fma on this part, tools/ubench): t = clamp(m * 2^40 + 1) is 0 for every m < 0 a float of this size can hold
-    // (|m| >= 2^-22) and 1 for m >= 0 -- the in-board side (t = 0) stays bit-identical to accumulate_interior
-    const float m = fmaxf(ui, uj);                               // >= 0: not (0 < i < W and 0 < j < H)
-    const float t = __builtin_fminf(__builtin_fmaxf(fmaf(m, 0x1p40f, 1.f), 0.f), 1.f);
-    R = fmaf(t, (fabsf(ui) + fabsf(uj)) - Rin, Rin);
-    w0 = fmaf(t, nmf, mf);                                       // 0.5 when out of board
-    w1 = fmaf(t, mf, nmf);
-  } else {
   const bool oob = fmaxf(ui, uj) >= 0.f;                         // not (0 < i < W and 0 < j < H)
   auto sel = [&](float if_oob, float otherwise) -> float { return oob ? if_oob : otherwise; };
+  float R, w0, w1;
   if (OOB) {
     R = sel(fabsf(ui) + fabsf(uj), Rin);
     w0 = sel(0.5f, mf);
@@ -144,7 +115,6 @@ __device__ __forceinline__ void accumulate(const PointTerms& p, float ay, float 
     R = sel(0.f, Rin);
     w0 = mf;
     w1 = nmf;
-  }
   }
   const float Q = fminf(R, delta);
   const float T = Q * fmaf(-0.5f, Q, R);    // q (r - q/2) = 1/2 rho(r^2)
@@ -172,7 +142,7 @@ __device__ __forceinline__ void accumulate_interior(const PointTerms& p, float a
 // Box pre-pass, one point against one tile: adds to lb a lower bound of the point's term (cost / 2, either colour phase) for
 // EVERY translation in [alo, ahi] x [zlo, zhi] -- see the pre-pass in grid_cost_body for the argument.
 // (pi_lo, pi_hi), (pj_lo, pj_hi): the point's rotated coordinates -- one value each (lo == hi) in a workgroup's own pre-pass, the
-// extremes over the three thetas of a TRIPLE in k6_grid_cost_triple's common pre-pass (fl(p + a) is monotone in p as in a).
+// extremes over the thetas of a group in k6_group_prepass's common pre-pass (fl(p + a) is monotone in p as in a).
 __device__ __forceinline__ void box_term(float pi_lo, float pi_hi, float pj_lo, float pj_hi, float alo, float ahi, float zlo, float zhi,
                                          float Wh, float Hh, float delta, float& lb) {
   const float i_lo = pi_lo + alo, i_hi = pi_hi + ahi, j_lo = pj_lo + zlo, j_hi = pj_hi + zhi;
@@ -185,10 +155,6 @@ __device__ __forceinline__ void box_term(float pi_lo, float pi_hi, float pj_lo, 
   const float T = Q * fmaf(-0.5f, Q, R);
   lb = out_all ? fmaf(T, 0.5f, lb) : lb;
 }
-
-#ifndef ILCC_K6_SPLIT
-#define ILCC_K6_SPLIT 1   // (A/B builds: 0 = one class of points, every point takes the full accumulate<>)
-#endif
 
 // the seed pass's best candidate of frame f and the seed workgroup (= seed theta index) that found it; wave-uniform.
 // A handful of records: every lane reads them all (uniform addresses, scalar-cache loads) -- no cross-lane reduction.
@@ -221,21 +187,21 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
   const ilcc_result* r = &c.res[f];
   const int lane = lane_id();
   const int wid = __builtin_amdgcn_readfirstlane(wave_id());
-  constexpr int kBoxShift = (THREADS == kGridThreadsLarge && kGridThreadsLarge != kGridThreads) ? ILCC_BOX_SHIFT_LARGE : ILCC_BOX_SHIFT;
+  constexpr int kBoxShift = (THREADS == kGridThreadsLarge && kGridThreadsLarge != kGridThreads) ? kBoxShiftLarge : kBoxShiftSmall;
   GridPartial* out = &c.partial[(uint64_t)f * c.grid_blocks + kblk];
-  // full pass behind k6_triple_prepass: tiles the pre-pass common to this theta's triple has already rejected (a bit mask in
+  // full pass behind k6_group_prepass: tiles the pre-pass common to this theta's group has already rejected (a bit mask in
   // global memory), or nothing at all to do when it rejected them all
   const uint32_t* s_dead0 = nullptr;
-  bool triple_dead = false;
+  bool group_dead = false;
   if constexpr (PRUNE && OOB && LDS_POINTS && !VOLUME) {
-    if (c.tri_alive != nullptr) {
-      const uint32_t tr = (uint32_t)f * c.tri_count + kblk / (uint32_t)kThetaGroup;
-      const uint32_t st = c.tri_alive[tr];   // 0: every tile dead, 1: mask valid, 2: no common pre-pass ran for this triple
-      triple_dead = st == 0u;
-      if (st == 1u) s_dead0 = c.tri_mask + (uint64_t)tr * c.tri_words;
+    if (c.grp_alive != nullptr) {
+      const uint32_t tr = (uint32_t)f * c.grp_count + kblk / (uint32_t)kThetaGroup;
+      const uint32_t st = c.grp_alive[tr];   // 0: every tile dead, 1: mask valid, 2: no common pre-pass ran for this group
+      group_dead = st == 0u;
+      if (st == 1u) s_dead0 = c.grp_mask + (uint64_t)tr * c.grp_words;
     }
   }
-  if (r->status != ILCC_OK || triple_dead) {
+  if (r->status != ILCC_OK || group_dead) {
     if (threadIdx.x == 0) {
       out->cost = __builtin_inff();
       out->d2 = 0xFFFFFFFFu;
@@ -248,7 +214,7 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
   // uniform sample of the board -- to find WHERE the minimum is; their sums are not costs of complete candidates and go to
   // a bound word of their own.  The anchor launch then evaluates the found neighbourhood on every point: that is the bound.
   const uint32_t Mfull = c.n_lab[f];
-  const uint32_t M = c.walk_limit ? min(Mfull, max(c.walk_limit, Mfull >> ILCC_SEED_SHIFT)) : Mfull;   // an eighth of the points (measured: 1/2: 323 k, 1/4: 331 k, 1/8: 335 k, 1/16: 329 k frames/s), at least walk_limit
+  const uint32_t M = c.walk_limit ? min(Mfull, max(c.walk_limit, Mfull >> kSeedShift)) : Mfull;   // an eighth of the points (measured: 1/2: 323 k, 1/4: 331 k, 1/8: 335 k, 1/16: 329 k frames/s), at least walk_limit
   const uint64_t beg = c.off[f];
   const float2* __restrict__ gyz = c.yz + beg;
   const uint8_t* __restrict__ glab = c.lab + beg;
@@ -383,7 +349,7 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
         // (the sum only grows: a wavefront whose 32 tiles are all beaten already stops looking at further points -- most
         // wavefronts, far from the minimum, after the first few)
         float lb = 0.f, both = 0.f;
-        // tiles the triple's common pre-pass has rejected are not looked at again (a tile's bit is only ever set by its own lane)
+        // tiles the group's common pre-pass has rejected are not looked at again (a tile's bit is only ever set by its own lane)
         const bool todo = q < n_tiles && !((s_dead[q >> 5] >> (q & 31)) & 1u);
         const uint32_t wave_tiles = (uint32_t)__popcll(__ballot(todo && half == 0));
         for (uint32_t u0 = 0; wave_tiles != 0u && u0 < n_pre; u0 += 2u * kBoxCheck) {
@@ -431,13 +397,7 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
   const int my_a = my_c >> 2, my_b = my_c & 3;
 
   // first block of each class in registers (see run_tile); needs a full block of both classes
-#ifndef ILCC_K6_FIRST_IN
-#define ILCC_K6_FIRST_IN 0   // interior- / border-class points per lane in the first (register-resident) block
-#endif
-#ifndef ILCC_K6_FIRST_BD
-#define ILCC_K6_FIRST_BD 2   // border-class (rim-first) points per lane before the first test: 1: 369 k, 2: 379 k, 3: 379 k, 4: 357 k frames/s (loop 1+3)
-#endif
-  constexpr int kFirstIn = ILCC_K6_FIRST_IN, kFirstBd = ILCC_K6_FIRST_BD;
+  constexpr int kFirstIn = 0, kFirstBd = 2;   // interior- / border-class (rim-first) points per lane in the first, register-resident block
   const bool first_block = LDS_POINTS && Mi >= (uint32_t)(kFirstIn * kSlices) && M - Mi >= (uint32_t)(kFirstBd * kSlices);
   PointTerms first_in[kFirstIn > 0 ? kFirstIn : 1], first_bd[kFirstBd > 0 ? kFirstBd : 1];
   if (LDS_POINTS && first_block) {
@@ -554,13 +514,7 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
       // other wavefronts, and the registers of a second block in flight cost a wavefront of occupancy (measured with two
       // named register sets: 83 VGPRs, 267 k instead of 281 k frames/s).
       if (!(PRUNE && pruned)) {
-#ifndef ILCC_K6_LOOP_IN
-#define ILCC_K6_LOOP_IN 0   // interior- / border-class points per lane and trip of this loop
-#endif
-#ifndef ILCC_K6_LOOP_BD
-#define ILCC_K6_LOOP_BD 3   // (rim-first, 0+2 first block) loop in+bd 0+2: 388 k, 1+2: 383 k, 0+3: 383 k frames/s; with the box pre-pass 0+1: 501 k, 0+2: 513 k, 0+3: 523 k, 1+2: 508 k
-#endif
-        constexpr int kLoopIn = ILCC_K6_LOOP_IN, kLoopBd = ILCC_K6_LOOP_BD;
+        constexpr int kLoopIn = 0, kLoopBd = 3;   // interior- / border-class points per lane and trip of this loop
         constexpr uint32_t kStepIn = kLoopIn * kSlices, kStepBd = kLoopBd * kSlices;
         uint32_t both = (uint32_t)__builtin_amdgcn_readfirstlane(
             (int)min(kLoopIn ? (Mi - min(pin, Mi)) / (kLoopIn ? kStepIn : 1u) : 0x7FFFFFFFu, kLoopBd ? (M - pbd) / (kLoopBd ? kStepBd : 1u) : 0x7FFFFFFFu));
@@ -728,10 +682,7 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
     // so neighbouring tiles -- the expensive ones are neighbours -- sit in different chunks, and chunk 0 starts with the tile of
     // the seed's best translation.  The lanes look their slots up in the pre-pass's bit mask, a ballot gives the ones still
     // alive, and only those are visited.  The order never changes the result.
-#ifndef ILCC_K6_CHUNK
-#define ILCC_K6_CHUNK 8   // tile slots per claim
-#endif
-    constexpr int kChunk = ILCC_K6_CHUNK;
+    constexpr int kChunk = 8;   // tile slots per claim
     static_assert(kChunk >= 1 && kChunk <= ILCC_WAVE, "a chunk is looked up by the lanes of one wavefront");
     const int n_chunks = __builtin_amdgcn_readfirstlane((n_tiles + kChunk - 1) / kChunk);
     const int ntb_s = __builtin_amdgcn_readfirstlane(ntb);
@@ -910,7 +861,7 @@ __global__ __launch_bounds__(THREADS) void k6_grid_cost(Ctx c, float* volume) {
   float* s_ay = s_hw + c.grid_lds_points;   // n_ty floats
   float* s_az = s_ay + c.p.n_ty;            // n_tz floats
   const uint32_t Mall = c.n_lab[blockIdx.y];
-  const uint32_t M = c.walk_limit ? min(Mall, max(c.walk_limit, Mall >> ILCC_SEED_SHIFT)) : Mall;
+  const uint32_t M = c.walk_limit ? min(Mall, max(c.walk_limit, Mall >> kSeedShift)) : Mall;
   (void)M;
   if (Mall <= c.grid_lds_points)   // (k5w_walk_order has laid out every frame of at most kGridLdsPointsMax points)
     grid_cost_body<OOB, VOLUME, true, PRUNE, THREADS>(c, volume, s_ij, s_hw, s_best, s_iters, s_cnt, s_ay, s_az, s_dead, &s_next, blockIdx.x);
@@ -918,8 +869,7 @@ __global__ __launch_bounds__(THREADS) void k6_grid_cost(Ctx c, float* volume) {
     grid_cost_body<OOB, VOLUME, false, PRUNE, THREADS>(c, volume, s_ij, s_hw, s_best, s_iters, s_cnt, s_ay, s_az, s_dead, &s_next, blockIdx.x);
 }
 
-// k6_triple_prepass (round 4): ONE box pre-pass for a GROUP of kThetaGroup consecutive thetas, in front of the full pass (the name
-// is from its first version, three thetas; five measured best: ilcc_internal.h).  71 % of the (frame,
+// k6_group_prepass: ONE box pre-pass for a GROUP of kThetaGroup consecutive thetas, in front of the full pass.  71 % of the (frame,
 // theta) workgroups of the full pass die in their own box pre-pass -- staging, tables, three barriers, ~450 instructions per
 // wavefront each: 30 % of the kernel -- and a theta step moves a point by less than a third of a tile's width.  Every pre-pass
 // point is rotated by all thetas of the group (the term's own fp32 expressions) and the box bound takes the extremes: i_lo from the
@@ -930,15 +880,15 @@ __global__ __launch_bounds__(THREADS) void k6_grid_cost(Ctx c, float* volume) {
 // group's full-pass workgroups exit on their first instructions), 1: a bit mask of the rejected tiles follows (their own
 // pre-pass starts from it and only looks at the rest), 2: no common pre-pass (conditions not met) -- and the mask.
 template <int THREADS>
-__global__ __launch_bounds__(THREADS) void k6_triple_prepass(Ctx c, uint32_t* tri_alive, uint32_t* tri_mask) {
+__global__ __launch_bounds__(THREADS) void k6_group_prepass(Ctx c, uint32_t* grp_alive, uint32_t* grp_mask) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ uint32_t s_iters[THREADS / ILCC_WAVE];
   __shared__ uint32_t s_dead3[kBoxTilesMax / 32];
   __shared__ uint32_t s_any;
-  constexpr int kBoxShift = (THREADS == kGridThreadsLarge && kGridThreadsLarge != kGridThreads) ? ILCC_BOX_SHIFT_LARGE : ILCC_BOX_SHIFT;
+  constexpr int kBoxShift = (THREADS == kGridThreadsLarge && kGridThreadsLarge != kGridThreads) ? kBoxShiftLarge : kBoxShiftSmall;
   const uint32_t f = blockIdx.y;
   const int k0 = kThetaGroup * (int)blockIdx.x, nk = min(kThetaGroup, c.p.n_th - k0);
-  const uint32_t tr = f * c.tri_count + blockIdx.x;
+  const uint32_t tr = f * c.grp_count + blockIdx.x;
   const uint32_t Mall = c.n_lab[f];
   const bool lds = Mall <= c.grid_lds_points;
   const int n_ty = c.p.n_ty, n_tz = c.p.n_tz;
@@ -946,15 +896,12 @@ __global__ __launch_bounds__(THREADS) void k6_triple_prepass(Ctx c, uint32_t* tr
   const uint32_t Mi = lds ? c.walk_mi[f] : 0u;
   // (every condition is uniform over the workgroup)
   if (!(c.res[f].status == ILCC_OK && lds && nk > 1 && c.box_points != 0u && n_tiles <= kBoxTilesMax && Mall > Mi)) {
-    if (threadIdx.x == 0) tri_alive[tr] = 2u;
+    if (threadIdx.x == 0) grp_alive[tr] = 2u;
     return;
   }
   const int lane = lane_id();
   const int wid = __builtin_amdgcn_readfirstlane(wave_id());
-#ifndef ILCC_GROUP_SHIFT_DELTA
-#define ILCC_GROUP_SHIFT_DELTA (-1)   // the common pre-pass looks at (labelled points) >> (kBoxShift + delta): twice each theta's own sample.  delta +1 / 0 / -1 / -2 / -3: config 2 824 / 842 / 858 / 845 / 841 k, config 5 53.8 / 56.2 / 59.4 / 58.9 k frames/s
-#endif
-  const uint32_t n_pre = min(max(c.box_points, Mall >> (kBoxShift + ILCC_GROUP_SHIFT_DELTA)), Mall - Mi);
+  const uint32_t n_pre = min(max(c.box_points, Mall >> (kBoxShift + kGroupShiftDelta)), Mall - Mi);
   float4* s_w4 = reinterpret_cast<float4*>(smem);   // n_pre x (pi_lo, pi_hi, pj_lo, pj_hi)
   float* s_ay = reinterpret_cast<float*>(s_w4 + n_pre);
   float* s_az = s_ay + n_ty;
@@ -1030,23 +977,24 @@ __global__ __launch_bounds__(THREADS) void k6_triple_prepass(Ctx c, uint32_t* tr
   __syncthreads();
   const bool any_alive = s_any != 0u;
   if (any_alive)
-    for (int w = threadIdx.x; w < (n_tiles + 31) / 32; w += THREADS) tri_mask[(uint64_t)tr * c.tri_words + w] = s_dead3[w];
+    for (int w = threadIdx.x; w < (n_tiles + 31) / 32; w += THREADS) grp_mask[(uint64_t)tr * c.grp_words + w] = s_dead3[w];
   if (threadIdx.x == 0) {
     unsigned long long box_evals = 0;
     for (int w = 0; w < THREADS / ILCC_WAVE; ++w) box_evals += s_iters[w];
     atomicAdd(c.grid_iters + 2 * kIterSlots + (f & (kIterSlots - 1)), box_evals);
-    tri_alive[tr] = any_alive ? 1u : 0u;
+    grp_alive[tr] = any_alive ? 1u : 0u;
   }
 }
 
-void launch_triple_prepass(const Ctx& c, hipStream_t s, uint32_t* tri_alive, uint32_t* tri_mask) {
-  const dim3 grid(c.tri_count, c.n_frames);
-  // LDS: the widened pre-pass points (16 B each: at most a quarter of the frame's labelled points) and the (ty, tz) tables
-  const size_t lds = sizeof(float4) * ((size_t)c.grid_lds_points / 2 + 64) + sizeof(float) * (size_t)(c.p.n_ty + c.p.n_tz);
+void launch_group_prepass(const Ctx& c, hipStream_t s, uint32_t* grp_alive, uint32_t* grp_mask) {
+  const dim3 grid(c.grp_count, c.n_frames);
+  // LDS: the widened pre-pass points (16 B each: at most M >> 1 of the frame's M <= grid_lds_points labelled points, or box_points of
+  // them when that is more -- the static_assert next to kGroupShiftDelta) and the (ty, tz) tables
+  const size_t lds = sizeof(float4) * std::max<size_t>((size_t)c.grid_lds_points / 2 + 64, (size_t)c.box_points) + sizeof(float) * (size_t)(c.p.n_ty + c.p.n_tz);
   if (c.grid_lds_points > (uint32_t)kGridLargeFrom)
-    hipLaunchKernelGGL((k6_triple_prepass<kGridThreadsLarge>), grid, dim3(kGridThreadsLarge), lds, s, c, tri_alive, tri_mask);
+    hipLaunchKernelGGL((k6_group_prepass<kGridThreadsLarge>), grid, dim3(kGridThreadsLarge), lds, s, c, grp_alive, grp_mask);
   else
-    hipLaunchKernelGGL((k6_triple_prepass<kGridThreads>), grid, dim3(kGridThreads), lds, s, c, tri_alive, tri_mask);
+    hipLaunchKernelGGL((k6_group_prepass<kGridThreads>), grid, dim3(kGridThreads), lds, s, c, grp_alive, grp_mask);
 }
 
 // K5w walk order: the frame's labelled points in the layout k6_grid_cost stages -- [interior | rim | other border], each part
@@ -1057,15 +1005,10 @@ void launch_triple_prepass(const Ctx& c, hipStream_t s, uint32_t* tri_alive, uin
 //             and found 7 % more points): |i| <= |y| max|cos| + |z| max|sin|, with a margin far above fp32 rounding; the
 //             decimated tables of the seed launch are subsets of the full ones -> accumulate_interior is exact for these
 //             points in every launch;
-//   rim:      border-class and within ILCC_K6_RIM thousandths of a square of the outline at the grid's centre candidate:
+//   rim:      border-class and within kRimMilli thousandths of a square of the outline at the grid's centre candidate:
 //             walked first, they are the points that leave the board when the translation is wrong (ordering only).
-#ifndef ILCC_K6_RIM
-#define ILCC_K6_RIM 300   // rim 0: 350 k, 150: 355 k, 300: 357 k, 500: 351 k frames/s (first block 0+4); with a 0+2 first block 200: 385 k, 300: 388 k, 400: 384 k
-#endif
-#ifndef ILCC_K5W_THREADS
-#define ILCC_K5W_THREADS 1024
-#endif
-constexpr int kWalkThreads = ILCC_K5W_THREADS;
+constexpr int kRimMilli = 300;   // rim = within 0.3 square of the outline
+constexpr int kWalkThreads = 1024;
 __global__ __launch_bounds__(kWalkThreads) void k5w_walk_order(Ctx c) {
   __shared__ uint8_t s_cls[kGridLdsPointsMax];
   __shared__ uint32_t s_in[kWalkThreads / ILCC_WAVE], s_rim[kWalkThreads / ILCC_WAVE], s_oth[kWalkThreads / ILCC_WAVE];
@@ -1088,7 +1031,7 @@ __global__ __launch_bounds__(kWalkThreads) void k5w_walk_order(Ctx c) {
   const float Wh = 0.5f * (float)c.p.board_w, Hh = 0.5f * (float)c.p.board_h;
   const float ay_lo = c.ay[0], ay_hi = c.ay[c.p.n_ty - 1], az_lo = c.az[0], az_hi = c.az[c.p.n_tz - 1];
   const float ay_c = c.ay[c.c_ty], az_c = c.az[c.c_tz];
-  const float rim_thr = -(float)ILCC_K6_RIM * 1e-3f;
+  const float rim_thr = -(float)kRimMilli * 1e-3f;
   const int n_th = c.p.n_th;
   float cmax = 0.f, smax = 0.f;   // (uniform: the tables are a few dozen values)
   for (int k = 0; k < n_th; ++k) {
@@ -1106,11 +1049,11 @@ __global__ __launch_bounds__(kWalkThreads) void k5w_walk_order(Ctx c) {
     const float bi = fmaf(fabsf(v.y), smax, fabsf(v.x) * cmax), bj = fmaf(fabsf(v.y), cmax, fabsf(v.x) * smax);
     const bool inside_always = bi + 1e-4f < room_i && bj + 1e-4f < room_j;
     int cl = 0;
-    if (!inside_always || !ILCC_K6_SPLIT) {
+    if (!inside_always) {
       const float cth = c.cth[c.c_th], sth = c.sth[c.c_th];
       const float pi = fmaf(-sth, v.y, cth * v.x), pj = fmaf(cth, v.y, sth * v.x);
       const float uc = fabsf((pi + ay_c) - Wh) - Wh, wc = fabsf((pj + az_c) - Hh) - Hh;
-      cl = (ILCC_K6_RIM && fmaxf(uc, wc) > rim_thr) ? 2 : 1;
+      cl = (fmaxf(uc, wc) > rim_thr) ? 2 : 1;
     }
     s_cls[sl] = (uint8_t)cl;
     cnt_in += cl == 0;
@@ -1241,7 +1184,7 @@ hipError_t set_kernel_attributes_k6() {
                        (const void*)k6_grid_cost<false, true, false, kGridThreads>, (const void*)k6_grid_cost<false, false, false, kGridThreads>,
                        (const void*)k6_grid_cost<true, false, true, kGridThreads>,  (const void*)k6_grid_cost<false, false, true, kGridThreads>,
                        (const void*)k6_grid_cost<true, false, true, kGridThreadsLarge>,
-                       (const void*)k6_triple_prepass<kGridThreads>, (const void*)k6_triple_prepass<kGridThreadsLarge>};
+                       (const void*)k6_group_prepass<kGridThreads>, (const void*)k6_group_prepass<kGridThreadsLarge>};
   const int cap = (int)((sizeof(float2) + sizeof(float)) * (size_t)kGridLdsPointsMax + sizeof(float) * (size_t)kGridTableMax);
   for (const void* fn : fns) {
     const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
@@ -1252,11 +1195,7 @@ hipError_t set_kernel_attributes_k6() {
 
 void launch_grid_cost(const Ctx& c, hipStream_t s, int32_t use_oob, float* cost_volume, bool prune) {
   const dim3 grid(c.grid_blocks, c.n_frames), block(kGridThreads);
-#ifndef ILCC_K6_LDS_PAD
-#define ILCC_K6_LDS_PAD 0   // experiment: extra dynamic LDS per workgroup of the FULL pass, to cap its workgroups per CU and leave room for the per-frame kernels of other batches
-#endif
-  const size_t lds = (sizeof(float2) + sizeof(float)) * (size_t)c.grid_lds_points + sizeof(float) * (size_t)(c.p.n_ty + c.p.n_tz) +
-                     (c.tie_count != nullptr ? (size_t)ILCC_K6_LDS_PAD : 0);
+  const size_t lds = (sizeof(float2) + sizeof(float)) * (size_t)c.grid_lds_points + sizeof(float) * (size_t)(c.p.n_ty + c.p.n_tz);
   // the diagnostic volume is always a complete evaluation (no pruning)
   if (cost_volume) {
     if (use_oob)

@@ -250,9 +250,12 @@ class LidarCornersBatch:
         """The batch's compact records: [n_frames, RECORD_HEADER + 3 * board corners] float32 (layout:
         ``sharding.pack_records``; tag = frame index within the batch)."""
         t, n_frames = ticket
-        nc = (self.params.board_w - 1) * (self.params.board_h - 1)
-        rec = np.empty((n_frames, N.RECORD_HEADER + 3 * nc), dtype=np.float32)
-        st = self._lib.ilcc_wait_compact(self._h, t, N.fptr(rec))
+        # the record width was fixed when the batch was submitted: ask the library, not self.params (a mutable struct)
+        width = int(self._lib.ilcc_record_floats(self._h, t))
+        if width == 0:
+            raise IlccError(N.BAD_ARGUMENT, "wait_compact: no batch in flight under this ticket")
+        rec = np.empty((n_frames, width), dtype=np.float32)
+        st = self._lib.ilcc_wait_compact(self._h, t, N.fptr(rec), rec.size)
         if st != N.OK:
             raise IlccError(st, self._err())
         return rec

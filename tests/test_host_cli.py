@@ -184,14 +184,16 @@ def test_cpp_multi_gpu_driver_gathers_with_rccl(tmp_path, golden_dir):
     assert r.returncode == 1 and "rank %d (device %d) failed" % (ndev - 1, ndev - 1) in r.stderr, r.stdout + r.stderr
 
 
-def _bench(env_extra, args, launcher=None, timeout=300):
+def _bench(env_extra, args, launcher=None, timeout=300, with_stderr=False):
     env = dict(os.environ, **env_extra)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE"):   # a plain invocation must look like one
+        env.pop(k, None)
     cmd = (launcher or [sys.executable]) + [os.path.join(ROOT, "bench.py")] + args
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
-    return json.loads(lines[0])
+    return (json.loads(lines[0]), r.stderr) if with_stderr else json.loads(lines[0])
 
 
 def test_bench_multi_rank_path_with_one_rccl_rank():
@@ -213,3 +215,29 @@ def test_bench_two_ranks_on_one_device_over_gloo():
                  ["--gpus", "2", "--steps", "2", "--warmup", "1", "--batches-per-step", "2", "--frames-per-batch", "64"],
                  launcher=launcher)
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 500
+
+
+def test_bench_plain_invocation_with_gpus_2_launches_two_ranks():
+    """`python bench.py --gpus 2` WITHOUT a launcher (no WORLD_SIZE): the flag itself must produce two ranks -- bench.py
+    re-executes under torch.distributed.run -- and the line must say n_gpus 2 (round 4: the flag was parsed and ignored, a plain
+    `--gpus 8` ran one rank and printed n_gpus 1).  Both ranks on device 0, records over gloo (the 1-GPU test hooks)."""
+    out, err = _bench({"ILCC_BENCH_BACKEND": "gloo", "ILCC_BENCH_SINGLE_DEVICE": "1", "ILCC_BENCH_MAX_DEPTH": "2"},
+                      ["--gpus", "2", "--steps", "2", "--warmup", "1", "--batches-per-step", "2", "--frames-per-batch", "64"],
+                      with_stderr=True)
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 500
+    assert "bench preflight: backend gloo, world 2; ranks [0, 1]" in err, err[-2000:]
+    assert "re-executing as" in err
+
+
+def test_bench_refuses_more_ranks_than_devices():
+    """--gpus N on a node with fewer than N devices exits non-zero with a clear message (no silent 1-rank run), and so does a
+    launcher whose WORLD_SIZE disagrees with --gpus."""
+    import torch
+    n = torch.cuda.device_count() + 1
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "ILCC_BENCH_SINGLE_DEVICE")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(max(2, n))], capture_output=True, text=True,
+                       timeout=300, env=env, cwd=ROOT)
+    assert r.returncode != 0 and "HIP devices" in r.stderr and not r.stdout.strip()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], capture_output=True, text=True, timeout=300,
+                       env=dict(env, WORLD_SIZE="2", RANK="0"), cwd=ROOT)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr and not r.stdout.strip()

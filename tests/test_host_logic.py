@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     lib = N.lib()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.ilcc_abi_version() == N.ABI_VERSION == 4
+    assert lib.ilcc_abi_version() == N.ABI_VERSION == 5
 
 
 def test_calib_library_exports_every_declared_symbol():
@@ -54,7 +54,7 @@ def test_struct_layouts_match_the_library():
     assert (p.refine_div, p.refine_max_rounds, p.refine_th_margin) == (16, 64, 32)
     assert p.ambiguity_eps == 1.0 and p.online_cluster_tol == 0.10     # LidarCornersEst.cpp:80
     assert p.min_cell_coverage == 0.9
-    assert C.sizeof(N.Timing) == 7 * 4 + 4 + 8 + 4 * 8 + 3 * 8            # ABI 4: three doubles appended
+    assert C.sizeof(N.Timing) == 7 * 4 + 4 + 8 + 4 * 8 + 5 * 8 + 8 + 8 * 8   # ABI 4: three doubles appended; ABI 5: two more, the batch count, the stage sums
     assert C.sizeof(N.Result) == 14 * 4 + 4 + 16 + 64 + 4 + 16 + 24 + 24 + 8 + 8 + 8 + 3 * 4 * 256  # no hidden padding surprises
 
 
@@ -314,3 +314,16 @@ def test_four_rank_gather_with_an_uneven_shard(tmp_path):
     assert np.array_equal(got[:, N.RECORD_HEADER], np.arange(10, dtype=np.float32))
     sharding.verify_records(got, np.arange(10))
 
+
+def test_bench_gpus_flag_never_silently_runs_one_rank():
+    """`python bench.py --gpus 8` on a box with fewer devices exits non-zero with a clear message and prints no JSON line; a
+    launcher whose WORLD_SIZE disagrees with --gpus is refused too (the flag was parsed and ignored)."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "ILCC_BENCH_SINGLE_DEVICE")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64"], capture_output=True, text=True, timeout=300,
+                       env=env, cwd=ROOT)
+    assert r.returncode != 0 and "needs 64 HIP devices" in r.stderr and not r.stdout.strip()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], capture_output=True, text=True, timeout=300,
+                       env=dict(env, WORLD_SIZE="2", RANK="0"), cwd=ROOT)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr and not r.stdout.strip()

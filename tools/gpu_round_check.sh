@@ -13,7 +13,7 @@ for n in ("20_5","200_20"):
         d=json.load(open('gpurun_out/bench_${TAG}_%s.json'%n))
         print('BENCH',n, round(d['value']), round(d['ms_per_step'],3), 'h2d', d.get('value_h2d_inclusive'), 'k6 ms', round(d['roofline']['launch_ms'],4), 'valu frac', round(d['roofline']['frac'],4), 'exec', d['roofline']['executed_fraction'], d['frames_ok'], 'amb', d['frames_flagged_ambiguous'], 'max', d['max_corner_error_mm_vs_ground_truth'], 'med', d['median_corner_error_mm_vs_ground_truth'], 'stages', d['stage_ms_last_batch_overlapped'])
         if 'grid_vs_reference_path_mm' in d: print('   GRIDvsREF', {k:v for k,v in d['grid_vs_reference_path_mm'].items() if k!='what'})
-        if 'cpu_baseline' in d: print('   CPU', d['cpu_baseline']['value'], d['cpu_baseline']['runs_frames_per_s'], d['cpu_baseline']['all_cores']['value'], d['cpu_baseline']['gpu_vs_cpu_corner_deviation_mm'])
+        if 'cpu_baseline' in d: print('   CPU', d['cpu_baseline']['value'], d['cpu_baseline']['runs_frames_per_s'], d['cpu_baseline']['all_cores_value'], d['cpu_baseline']['gpu_vs_cpu_corner_deviation_mm'])
         if 'pcie_inclusive' in d: print('   PCIE', {k:(v if not isinstance(v,dict) else {kk:vv for kk,vv in v.items() if kk!='how'}) for k,v in d['pcie_inclusive'].items()})
     except Exception as e: print('BENCH',n,'failed',e)
 PY

@@ -1,5 +1,8 @@
 """GRID-mode parity sweep: HIP path vs the CPU oracle's exhaustive grid search on N seeded frames
-(argmin index, corners).  The oracle side runs on all host threads (ctypes releases the GIL)."""
+(argmin index, corners).  The oracle side runs on all host threads (ctypes releases the GIL).
+    python tools/grid_parity_sweep.py N SEED [grid|grid5|local] [OUT.json]
+OUT.json (default gpurun_out/parity_sweep_<mode>_<N>_<seed>.json): the counts below as one JSON object -- the committed copies
+under profiles/ are the evidence for the argmin parity, which is empirical by construction."""
 import concurrent.futures as cf
 import os
 import sys
@@ -65,6 +68,27 @@ print("frames %d  status agree %d  both with corners %d  grid argmin identical %
       "frames above 1e-6 m: %d  cells_hit/n_oob/flags identical %d  flagged low coverage %d"
       % (F, same_status, len(both), same_idx, it, same_theta, flagged, overflow, max(dev) if dev else 0.0, sum(d > 1e-6 for d in dev),
          same_conf, low_cov))
+import json
+import subprocess
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+out_path = sys.argv[4] if len(sys.argv) > 4 else os.path.join(root, "gpurun_out", "parity_sweep_%s_%d_%#x.json" % (mode, F, seed))
+summary = {
+    "tool": "tools/grid_parity_sweep.py %d %#x %s" % (F, seed, mode), "mode": mode, "frames": F, "seed": "%#x" % seed,
+    "sensor": "hdl64 131072 pts, 11x8 board @0.10 m, 129^3 x 2 grid" if mode == "grid5" else "vlp16 28800 pts, 7x5 board @0.15 m, 61x40x40 x 2 grid",
+    "status_agree": same_status, "frames_with_corners_on_both_sides": len(both), "grid_argmin_identical": same_idx,
+    "rounds_hops_identical": it, "theta_t_cost_margin_bit_identical": same_theta, "cells_hit_n_oob_flags_identical": same_conf,
+    "tie_list_overflows": overflow, "flagged_ambiguous": flagged, "flagged_low_coverage": low_cov,
+    "max_corner_deviation_m": max(dev) if dev else 0.0, "frames_above_1e-6_m": int(sum(d > 1e-6 for d in dev)),
+    "mismatching_frames": [int(f) for f in both if res[f].grid_index != ref[f].grid_index][:64],
+    "library": os.path.basename(N.LIB_PATH),
+}
+try:
+    os.makedirs(os.path.dirname(out_path), exist_ok=True)
+    with open(out_path, "w") as fh:
+        json.dump(summary, fh, indent=1)
+    print("wrote", out_path)
+except OSError as e:
+    print("could not write", out_path, e)
 for f in both:
     if res[f].grid_index != ref[f].grid_index:
         print("  frame", f, "gpu", res[f].grid_index, res[f].grid_cost, "oracle", ref[f].grid_index, ref[f].grid_cost)
