@@ -199,6 +199,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the H2D-inclusive / reference-mode legs (profiling runs)")
     ap.add_argument("--in-flight", type=int, default=4, help="batches in flight per GPU (1 = fully synchronous)")
+    ap.add_argument("--no-alone-leg", action="store_true",
+                    help="skip the in-flight-1 leg behind the timed region (profiling runs: a kernel trace then holds the pipelined "
+                         "launches only); roofline.frac is then priced on the timed region's own event spans")
     ap.add_argument("--ref-n1", type=float, default=0.0,
                     help="frames/s of the N=1 run: rank 0 then prints weak_scaling_efficiency = value / (N x ref)")
     ap.add_argument("--no-noise-floor", action="store_true", help="skip the sensor-noise sweep (noise_floor_mm)")
@@ -414,10 +417,12 @@ def main():
 
     # ONE batch at a time (in flight 1, nothing else on the chip): the only exclusive launch durations.  roofline.frac is priced
     # on these; the timed region's own event spans (batches overlapping) are reported beside them
-    est.reset_timing()
-    run(max(3, min(10, args.steps)), dptrs, depth_override=1)
-    torch.cuda.synchronize()
-    tm_alone = est.timing()
+    tm_alone = tm
+    if not args.no_alone_leg and depth > 1:
+        est.reset_timing()
+        run(max(3, min(10, args.steps)), dptrs, depth_override=1)
+        torch.cuda.synchronize()
+        tm_alone = est.timing()
 
     # the same pipeline with every batch starting in pinned HOST memory (SURVEY.md 8d counts that copy): every rank, its own link
     h2d = None
@@ -538,7 +543,10 @@ def main():
                 "peak": VALU_ISSUE_PEAK_T,
                 "unit": "T lane-instr/s",
                 "frac": valu_rate / VALU_ISSUE_PEAK_T,
-                "frac_what": "credited lane-instr of one batch's K6 launches / k6_ms_alone (HIP events, ONE batch in flight) / peak",
+                "frac_what": "credited lane-instr of one batch's K6 launches / k6_ms_alone (HIP events, ONE batch in flight) / peak"
+                             if tm_alone is not tm or depth == 1 else
+                             "credited lane-instr of one batch's K6 launches / the timed region's event spans (--no-alone-leg) / peak",
+                "alone_leg": tm_alone is not tm or depth == 1,
                 "traffic": pmc["traffic_bytes"] if pmc else None,
                 "k6_ms_alone": k6_ms_alone,
                 "k6_ms_pipelined": k6_ms,

@@ -341,6 +341,15 @@ int32_t ilcc_get_theta_t(ilcc_handle* h, const float* yz, const uint8_t* label, 
                          int32_t topleft_white, int32_t use_oob, double theta_t[3], double* cost,
                          int32_t* iterations);
 
+/* Diagnostic (ABI 5): the real timeline of the batches, without a profiler.  While enabled, every completed batch appends one row
+ * of ILCC_TIMELINE_COLS doubles: slot, then the times in ms -- relative to a reference event recorded when the timeline was
+ * enabled -- of the batch's HIP events: start, after K1's count pass, after K1, K2, K3, K4/K5, K5w, seed, refinement, anchor,
+ * common pre-pass (= ready for the full pass), full pass start (behind the wait for the previous batch's full pass), full pass
+ * end, end of K7.  ilcc_debug_timeline_fetch copies up to cap_rows rows (oldest first) and clears the log; returns the rows. */
+#define ILCC_TIMELINE_COLS 15
+int32_t ilcc_debug_timeline_enable(ilcc_handle* h, int32_t on);
+int32_t ilcc_debug_timeline_fetch(ilcc_handle* h, double* rows, uint32_t cap_rows);
+
 void ilcc_get_timing(const ilcc_handle* h, ilcc_timing* t);
 void ilcc_reset_timing(ilcc_handle* h);
 

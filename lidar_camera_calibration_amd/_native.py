@@ -19,6 +19,7 @@ OK, NO_ROI_POINTS, NO_CLUSTER, NO_PLANE, DEGENERATE_HIST, TOO_FEW_POINTS, BAD_AR
     HIP_ERROR, IO_ERROR, BOARD_NOT_FOUND, AMBIGUOUS = range(12)
 FLAG_TIE_OVERFLOW, FLAG_REFINE_CAPPED, FLAG_LOW_COVERAGE = 1, 2, 4
 RECORD_HEADER = 20
+TIMELINE_COLS = 15
 COST_Q_ONE = float(1 << 40)
 SOLVER_REFERENCE_LOCAL, SOLVER_GRID = 0, 1
 CLOUD_ROI, CLOUD_CLUSTER, CLOUD_CHESSBOARD, CLOUD_PCA, CLOUD_OPTIM = range(5)
@@ -31,6 +32,7 @@ EXPORTS = [
     "ilcc_grid_cost", "ilcc_pattern_refine", "ilcc_get_theta_t", "ilcc_get_timing", "ilcc_reset_timing",
     "ilcc_save_corners2txt", "ilcc_read_lidar_corners",
     "ilcc_set_result_mode", "ilcc_wait_compact", "ilcc_record_floats", "ilcc_fetch_results",
+    "ilcc_debug_timeline_enable", "ilcc_debug_timeline_fetch",
 ]
 ABI_VERSION = 5            # the layout of Params / Result / Timing below is ILCC_ABI_VERSION 5 of include/ilcc_hip.h
 RESULTS_FULL, RESULTS_COMPACT = 0, 1
@@ -198,6 +200,10 @@ def lib():
         L.ilcc_wait_compact.restype = C.c_int32
         L.ilcc_record_floats.argtypes = [vp, C.c_int32]
         L.ilcc_record_floats.restype = C.c_uint32
+        L.ilcc_debug_timeline_enable.argtypes = [vp, C.c_int32]
+        L.ilcc_debug_timeline_enable.restype = C.c_int32
+        L.ilcc_debug_timeline_fetch.argtypes = [vp, C.POINTER(C.c_double), C.c_uint32]
+        L.ilcc_debug_timeline_fetch.restype = C.c_int32
         L.ilcc_fetch_results.argtypes = [vp, C.c_uint32, C.c_uint32, rp]
         L.ilcc_fetch_results.restype = C.c_int32
         _lib = L

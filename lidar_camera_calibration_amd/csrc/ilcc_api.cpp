@@ -97,6 +97,9 @@ struct ilcc_handle {
   bool big_armed = false;            // K2's multi-workgroup kernels are launched: set once a frame above the LDS capacity was seen (finish()) or by ilcc_reserve
   int32_t result_mode = ILCC_RESULTS_FULL;
   ilcc_timing timing{};
+  hipEvent_t tl_ref = nullptr;       // ilcc_debug_timeline_*: reference event, rows of ILCC_TIMELINE_COLS doubles
+  bool tl_on = false;
+  std::vector<double> tl_rows;
   std::string err;
 };
 
@@ -758,6 +761,16 @@ int32_t finish(ilcc_handle* h, int si, ilcc_result* out, float* out_compact = nu
   }
   float tot = 0;
   HIP_TRY(h, hipEventElapsedTime(&tot, sl.ev[0], sl.ev[6]));
+  if (h->tl_on && h->tl_ref && sl.grid) {
+    const hipEvent_t evs[ILCC_TIMELINE_COLS - 1] = {sl.ev[0], sl.ev[9], sl.ev[1], sl.ev[2], sl.ev[3], sl.ev[4], sl.k6ev[0], sl.k6ev[1],
+                                                    sl.k6ev[2], sl.k6ev[3], sl.ev[7], sl.ev[8], sl.ev[5], sl.ev[6]};
+    h->tl_rows.push_back((double)si);
+    for (hipEvent_t e : evs) {
+      float t = 0.f;
+      HIP_TRY(h, hipEventElapsedTime(&t, h->tl_ref, e));
+      h->tl_rows.push_back((double)t);
+    }
+  }
   ilcc_timing& t = h->timing;
   t.roi_crop = ms[0];
   t.cluster = ms[1];
@@ -1025,6 +1038,7 @@ void ilcc_destroy(ilcc_handle* h) {
                   h->d_th_lattice};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
+  if (h->tl_ref) (void)hipEventDestroy(h->tl_ref);
   delete h;
 }
 
@@ -1467,6 +1481,28 @@ int32_t ilcc_pattern_refine(ilcc_handle* h, const float* yz, const uint8_t* labe
   if (rounds) *rounds = io.rounds;
   if (hops) *hops = io.hops;
   return ILCC_OK;
+}
+
+int32_t ilcc_debug_timeline_enable(ilcc_handle* h, int32_t on) {
+  if (!h) return ILCC_BAD_ARGUMENT;
+  HIP_TRY(h, hipSetDevice(h->device));
+  h->tl_rows.clear();
+  h->tl_on = on != 0;
+  if (h->tl_on) {
+    if (!h->tl_ref) HIP_TRY(h, hipEventCreate(&h->tl_ref));
+    HIP_TRY(h, hipEventRecord(h->tl_ref, h->slots[0].stream));
+    HIP_TRY(h, hipEventSynchronize(h->tl_ref));
+  }
+  return ILCC_OK;
+}
+
+int32_t ilcc_debug_timeline_fetch(ilcc_handle* h, double* rows, uint32_t cap_rows) {
+  if (!h || (!rows && cap_rows)) return -ILCC_BAD_ARGUMENT;
+  const size_t have = h->tl_rows.size() / ILCC_TIMELINE_COLS;
+  const size_t n = std::min<size_t>(have, cap_rows);
+  if (n) std::memcpy(rows, h->tl_rows.data(), sizeof(double) * n * ILCC_TIMELINE_COLS);
+  h->tl_rows.clear();
+  return (int32_t)n;
 }
 
 void ilcc_get_timing(const ilcc_handle* h, ilcc_timing* t) {
