@@ -201,6 +201,8 @@ typedef struct ilcc_timing {
   uint64_t batches;                 /* batches accounted */
   double stage_ms_sum[7];           /* roi_crop, cluster, ransac_plane, plane_frame_hist, grid_cost, refine_corners, total */
   double roi_count_ms_sum;          /* K1's count pass alone -- the kernel that reads every input point once (the HBM-bound one) */
+  uint64_t online_second_tier_frames; /* ilcc_chessboard_by_point_batch: frames whose answer needed the whole cloud clustered (the first
+                                         tier answers from a window around the predicted point and verifies it) */
 } ilcc_timing;
 
 int32_t ilcc_abi_version(void);

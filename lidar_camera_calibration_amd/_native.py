@@ -118,6 +118,7 @@ class Timing(C.Structure):
         ("batches", C.c_uint64),
         ("stage_ms_sum", C.c_double * 7),
         ("roi_count_ms_sum", C.c_double),
+        ("online_second_tier_frames", C.c_uint64),
     ]
 
 

@@ -43,7 +43,11 @@ struct Slot {
   uint8_t *d_lab = nullptr, *d_cls = nullptr;
   uint32_t *d_nlab = nullptr, *d_walk = nullptr, *d_counts = nullptr, *d_parent = nullptr, *d_count = nullptr;
   unsigned long long* d_masks = nullptr;
-  uint32_t *d_hash_head = nullptr, *d_hash_next = nullptr, *d_big = nullptr;   // d_big: [0] count, [1..] listed frames
+  uint32_t *d_hash_head = nullptr, *d_hash_next = nullptr;
+  uint32_t *d_flags = nullptr, *d_nfinite = nullptr, *d_counts_fin = nullptr;   // the online caller's two tiers (Ctx::frame_flags, n_finite, crop_fin)
+  uint32_t* h_online = nullptr;   // pinned: flags then finite counts of the last online batch
+  uint32_t* d_list = nullptr;     // tier 2: [0] count, [1..] listed frames
+  void* d_list_frames = nullptr;  // tier 2: 64 bytes per frame
   GridPartial *d_partial = nullptr, *d_partial2 = nullptr, *d_partial3 = nullptr, *d_partial4 = nullptr;
   SolveRec* d_solverec = nullptr;
   uint32_t *d_bound = nullptr, *d_bound_sub = nullptr;
@@ -92,9 +96,8 @@ struct ilcc_handle {
   uint32_t grid_lds_points = 1024;   // grows with the frames seen (finish()); frames above it take the global-memory path
   uint32_t cluster_lds_points = 2048;   // K2's LDS capacity for cell-sorted ROI points per frame: grows likewise (<= 4096); larger frames sort into HBM
   uint32_t cluster_cells_cap = kClusterCellsMin;   // K2's LDS capacity in occupied cells per frame: grows with what the batches needed
-  uint32_t big_grid = 1024;          // workgroups of K2's persistent kernels (4 x the device's CUs)
+  uint32_t list_grid = 1024;         // workgroups of the online caller's second-tier kernels (4 x the device's CUs)
   bool poisoned = false;             // a failed ilcc_set_params could not restore the device tables: every later call fails
-  bool big_armed = false;            // K2's multi-workgroup kernels are launched: set once a frame above the LDS capacity was seen (finish()) or by ilcc_reserve
   int32_t result_mode = ILCC_RESULTS_FULL;
   ilcc_timing timing{};
   hipEvent_t tl_ref = nullptr;       // ilcc_debug_timeline_*: reference event, rows of ILCC_TIMELINE_COLS doubles
@@ -248,7 +251,7 @@ int32_t upload_tables(ilcc_handle* h) {
 
 void free_slot(Slot& sl) {
   void* bufs[] = {sl.d_grp_alive, sl.d_grp_mask, sl.d_rec, sl.d_xyzi, sl.d_clicks, sl.d_off, sl.d_res, sl.d_roi, sl.d_cluster, sl.d_board, sl.d_pca, sl.d_optim,
-                  sl.d_yz, sl.d_walk_yz, sl.d_walk_lab, sl.d_walk_mi, sl.d_walk_nrim, sl.d_lab, sl.d_cls, sl.d_nlab, sl.d_walk, sl.d_counts, sl.d_parent, sl.d_count, sl.d_hash_head, sl.d_hash_next, sl.d_big, sl.d_partial, sl.d_partial2, sl.d_partial3, sl.d_partial4, sl.d_masks,
+                  sl.d_yz, sl.d_walk_yz, sl.d_walk_lab, sl.d_walk_mi, sl.d_walk_nrim, sl.d_lab, sl.d_cls, sl.d_nlab, sl.d_walk, sl.d_counts, sl.d_parent, sl.d_count, sl.d_hash_head, sl.d_hash_next, sl.d_flags, sl.d_nfinite, sl.d_counts_fin, sl.d_list, sl.d_list_frames, sl.d_partial, sl.d_partial2, sl.d_partial3, sl.d_partial4, sl.d_masks,
                   sl.d_solverec, sl.d_bound, sl.d_bound_sub, sl.d_iters, sl.d_tie_count, sl.d_tie_list};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -256,6 +259,7 @@ void free_slot(Slot& sl) {
   if (sl.h_rec) (void)hipHostFree(sl.h_rec);
   if (sl.h_iters) (void)hipHostFree(sl.h_iters);
   if (sl.h_off) (void)hipHostFree(sl.h_off);
+  if (sl.h_online) (void)hipHostFree(sl.h_online);
   for (auto& ev : sl.ev)
     if (ev) (void)hipEventDestroy(ev);
   for (auto& ev : sl.k6ev)
@@ -356,12 +360,16 @@ int32_t alloc_slot(ilcc_handle* h, Slot& sl) {
   ALLOC(sl.d_nlab, sizeof(uint32_t) * mf);
   ALLOC(sl.d_walk, sizeof(uint32_t) * mf);
   ALLOC(sl.d_counts, sizeof(uint32_t) * h->crop_chunks_cap);
+  ALLOC(sl.d_counts_fin, sizeof(uint32_t) * h->crop_chunks_cap);
+  ALLOC(sl.d_flags, sizeof(uint32_t) * mf);
+  ALLOC(sl.d_nfinite, sizeof(uint32_t) * mf);
+  ALLOC(sl.d_list, sizeof(uint32_t) * ((size_t)mf + 1));
+  ALLOC(sl.d_list_frames, (size_t)64 * mf);
   ALLOC(sl.d_masks, sizeof(unsigned long long) * (size_t)h->crop_chunks_cap * (kCropChunk / 64));
   ALLOC(sl.d_parent, sizeof(uint32_t) * np);
   ALLOC(sl.d_count, sizeof(uint32_t) * np);
   ALLOC(sl.d_hash_head, sizeof(uint32_t) * (size_t)mf * kClusterHashSize);
   ALLOC(sl.d_hash_next, sizeof(uint32_t) * np);
-  ALLOC(sl.d_big, sizeof(uint32_t) * ((size_t)mf + 1));
   ALLOC(sl.d_partial, sizeof(GridPartial) * (size_t)mf * h->max_theta);
   ALLOC(sl.d_partial2, sizeof(GridPartial) * (size_t)mf * h->max_theta);
   ALLOC(sl.d_partial3, sizeof(GridPartial) * (size_t)mf * h->max_theta);
@@ -377,6 +385,7 @@ int32_t alloc_slot(ilcc_handle* h, Slot& sl) {
   HIP_TRY(h, hipHostMalloc((void**)&sl.h_rec, sizeof(float) * (size_t)mf * (ILCC_RECORD_HEADER + 3 * ILCC_MAX_CORNERS), hipHostMallocDefault));
   HIP_TRY(h, hipHostMalloc((void**)&sl.h_iters, sizeof(unsigned long long) * kBatchWords, hipHostMallocDefault));
   HIP_TRY(h, hipHostMalloc((void**)&sl.h_off, sizeof(uint64_t) * (mf + 1), hipHostMallocDefault));
+  HIP_TRY(h, hipHostMalloc((void**)&sl.h_online, sizeof(uint32_t) * 2 * (size_t)mf, hipHostMallocDefault));
   {
     const int32_t st = size_group_prepass(h, sl);
     if (st != ILCC_OK) return st;
@@ -416,10 +425,17 @@ Ctx make_ctx(ilcc_handle* h, Slot& sl, const float4* d_xyzi, const float* d_clic
   c.uf_hash_next = sl.d_hash_next;
   c.cluster_lds_points = h->cluster_lds_points;
   c.cluster_cells_cap = h->cluster_cells_cap;
-  c.big_count = sl.d_big;
-  c.big_list = sl.d_big + 1;
-  c.big_grid = h->big_grid;
-  c.big_armed = h->big_armed ? 1u : 0u;
+  c.wide = 0u;
+  c.cluster_bits = cluster_bits_default();
+  c.online_tier = 0u;
+  c.online_window = 0.f;
+  c.frame_flags = sl.d_flags;
+  c.n_finite = sl.d_nfinite;
+  c.crop_fin = sl.d_counts_fin;
+  c.list_count = sl.d_list;
+  c.list = sl.d_list + 1;
+  c.list_frames = sl.d_list_frames;
+  c.list_grid = h->list_grid;
   c.partial = sl.d_partial;
   c.solve_rec = sl.d_solverec;
   c.grid_blocks = (uint32_t)h->p.n_th;
@@ -487,7 +503,7 @@ int32_t enqueue_impl(ilcc_handle* h, int si, const float4* d_xyzi, const uint64_
 // K2's workgroup keeps bitmap + per-cell arrays + (up to cluster_lds_points) sorted points in LDS: when the cell arrays have
 // grown large (dense clouds), give up LDS points first -- frames of that size sort into HBM anyway
 void fit_cluster_lds(ilcc_handle* h) {
-  while (cluster_lds_bytes(h->cluster_lds_points, h->cluster_cells_cap) > 150u * 1024u && h->cluster_lds_points > 0)
+  while (cluster_lds_bytes(h->cluster_lds_points, h->cluster_cells_cap, cluster_bits_online()) > 156u * 1024u && h->cluster_lds_points > 0)
     h->cluster_lds_points = h->cluster_lds_points > 512u ? h->cluster_lds_points - 512u : 0u;
 }
 
@@ -539,15 +555,35 @@ int32_t enqueue_impl(ilcc_handle* h, int si, const float4* d_xyzi, const uint64_
   HIP_TRY(h, hipMemcpyAsync(sl.d_off, sl.h_off, sizeof(uint64_t) * (n_frames + 1), hipMemcpyHostToDevice, s));
   // (result records, component counters, K6 counters and near-tie counters are reset inside K1 / K2)
   Ctx c = make_ctx(h, sl, d_xyzi, d_clicks, n_frames, chunks);
-  if (no_crop) {   // get_chessboard_by_point clusters the whole cloud: an unbounded box only drops non-finite points
-    c.p.roi_half[0] = c.p.roi_half[1] = c.p.roi_half[2] = (double)INFINITY;
-    c.p.cluster_tol = c.p.online_cluster_tol;   // setClusterTolerance(0.1), LidarCornersEst.cpp:80 (EuclideanCluster(): 0.12, :131)
-  }
-
   HIP_TRY(h, hipEventRecord(sl.ev[0], s));
-  launch_roi_crop(c, s, sl.ev[9]);   // ev[9]: between the count pass and the scatter
-  HIP_TRY(h, hipEventRecord(sl.ev[1], s));
-  launch_cluster(c, s);
+  if (!no_crop) {
+    launch_roi_crop(c, s, sl.ev[9]);   // ev[9]: between the count pass and the scatter
+    HIP_TRY(h, hipEventRecord(sl.ev[1], s));
+    launch_cluster(c, s);
+  } else {
+    // get_chessboard_by_point clusters the WHOLE cloud (no ROI; setClusterTolerance(0.1), LidarCornersEst.cpp:80 -- EuclideanCluster()
+    // uses 0.12, :131) and keeps the cluster around the predicted point.  Two tiers, identical results:
+    //   1. K1 crops a +-1.25 m window around the point, K2 clusters it on the LDS cell grid -- the ROI pipeline's fast path -- and
+    //      verifies that the whole cloud gives the same cluster (fine_cluster_frame: nearest point, admissible, complete);
+    //   2. the frames it could not vouch for: K1 with an unbounded box (only non-finite points go), K2 on hashed cells.
+    c.p.cluster_tol = c.p.online_cluster_tol;
+    c.wide = 1u;   // a synchronous call: latency is all that counts
+    Ctx t1 = c;
+    t1.online_tier = 1u;
+    t1.online_window = 1.25f;
+    t1.p.roi_half[0] = t1.p.roi_half[1] = t1.p.roi_half[2] = (double)t1.online_window;
+    t1.cluster_bits = cluster_bits_online();
+    launch_roi_crop(t1, s, sl.ev[9]);
+    HIP_TRY(h, hipEventRecord(sl.ev[1], s));
+    launch_cluster(t1, s);
+    Ctx t2 = c;
+    t2.online_tier = 2u;
+    t2.p.roi_half[0] = t2.p.roi_half[1] = t2.p.roi_half[2] = (double)INFINITY;
+    launch_roi_crop(t2, s, nullptr);
+    launch_cluster(t2, s);
+    HIP_TRY(h, hipMemcpyAsync(sl.h_online, sl.d_flags, sizeof(uint32_t) * n_frames, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipMemcpyAsync(sl.h_online + h->max_frames, sl.d_nfinite, sizeof(uint32_t) * n_frames, hipMemcpyDeviceToHost, s));
+  }
   HIP_TRY(h, hipEventRecord(sl.ev[2], s));
   launch_ransac_plane(c, s);
   HIP_TRY(h, hipEventRecord(sl.ev[3], s));
@@ -839,13 +875,12 @@ int32_t finish(ilcc_handle* h, int si, ilcc_result* out, float* out_compact = nu
   // is room for K6 workgroups of other batches
   want = std::min<uint32_t>((uint32_t)kClusterLdsPointsMax, (max_roi + 511u) & ~511u);
   if (want > h->cluster_lds_points) h->cluster_lds_points = want;
-  // ... and for its per-cell arrays: the most occupied cells a frame of this batch needed (+ 1/8), steps of 256.  Frames the
-  // cell grid cannot hold at any capacity (bounding grid too large: un-cropped clouds; more cells than the largest capacity)
-  // arm the multi-workgroup point-level kernels for the batches that follow.
-  const uint64_t cells_needed = sl.h_iters[3 * kIterSlots], ungridded = sl.h_iters[3 * kIterSlots + 1];
+  // ... and for its per-cell arrays: the most occupied cells a frame of this batch needed (+ 1/8), steps of 256.  Frames the LDS
+  // cell grid cannot hold at any capacity (bounding grid too large: un-cropped clouds; more cells than the largest capacity) take
+  // the hashed-cell path of their own workgroup (k2_cluster.hip).
+  const uint64_t cells_needed = sl.h_iters[3 * kIterSlots];
   want = (uint32_t)std::min<uint64_t>((uint64_t)kClusterCellsMax, (cells_needed + cells_needed / 8 + 255u) & ~255ull);
   if (want > h->cluster_cells_cap) h->cluster_cells_cap = want;
-  if (ungridded > 0 || cells_needed > (uint64_t)kClusterCellsMax) h->big_armed = true;
   fit_cluster_lds(h);
   return ILCC_OK;
 }
@@ -1010,7 +1045,7 @@ ilcc_handle* ilcc_create(int32_t device, const ilcc_params* p, uint32_t max_fram
   {
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess && cus > 0)
-      h->big_grid = (uint32_t)(4 * cus);
+      h->list_grid = (uint32_t)(4 * cus);
   }
   // dynamic-LDS limits are kept per (function, device): raise them for THIS device, and say so when that fails
   if ((e = set_kernel_attributes_k2()) != hipSuccess || (e = set_kernel_attributes_k6()) != hipSuccess ||
@@ -1087,9 +1122,6 @@ int32_t ilcc_reserve(ilcc_handle* h, uint32_t labelled_points_per_frame, uint32_
   // points is a safe capacity (a frame above it takes the slower point-level path once and the handle grows)
   const uint32_t cells = std::min<uint32_t>((uint32_t)kClusterCellsMax, (roi_points_per_frame / 4u + 255u) & ~255u);
   h->cluster_cells_cap = std::max(h->cluster_cells_cap, std::max((uint32_t)kClusterCellsMin, cells));
-  // above 32768 points per frame the caller is describing un-cropped clouds (the online caller): their bounding grid does not
-  // fit the cell bitmap -> the multi-workgroup point-level kernels
-  if (roi_points_per_frame > 4u * (uint32_t)kClusterCellsMax) h->big_armed = true;
   fit_cluster_lds(h);
   return ILCC_OK;
 }
@@ -1265,6 +1297,11 @@ int32_t ilcc_chessboard_by_point_batch(ilcc_handle* h, const float* xyzi, const 
   if (st != ILCC_OK) return st;
   st = finish(h, 0, out);
   if (st != ILCC_OK) return st;
+  // frames the first tier answered from a window of the cloud: n_roi is what the clustering of the WHOLE cloud runs on -- its
+  // finite points (K1 counted them on the way); the handle's own copy keeps the window's count, which is what ILCC_CLOUD_ROI holds
+  for (uint32_t f = 0; f < n_frames; ++f)
+    if (sl.h_online[f] == 0u && out[f].status != ILCC_NO_ROI_POINTS) out[f].n_roi = (int32_t)sl.h_online[h->max_frames + f];
+  for (uint32_t f = 0; f < n_frames; ++f) h->timing.online_second_tier_frames += sl.h_online[f] != 0u ? 1u : 0u;
   // `if(outcloud->size() < 500 || find_board == false) return false;` (LidarCornersEst.cpp:111-112)
   for (uint32_t f = 0; f < n_frames; ++f)
     if (out[f].status == ILCC_OK && (out[f].n_plane < min_plane_points || !out[f].found_board)) {

@@ -69,7 +69,7 @@ constexpr int kTieCap = 256;           // K6 -> K7a: near-tie candidates kept pe
 constexpr float kTieEps = 2e-5f;       // relative cost window of a near-tie (fp32 sums of ~1e3 terms agree to ~1e-6)
 constexpr int kCoverageCellsMax = 1024;   // K7b: board squares tracked by the coverage mask (board_w x board_h)
 constexpr int kIterSlots = 64;         // K6 executed-iteration counters (spread to avoid one hot atomic); [0,64): all points, [64,128): interior-class points, [128,192): (point, tile) evaluations of the box pre-pass
-constexpr int kBatchWords = 3 * kIterSlots + 2;   // Ctx::grid_iters: the K6 counters, then K2's two: [192] most occupied cells a frame needed, [193] frames its cell grid could not hold
+constexpr int kBatchWords = 3 * kIterSlots + 2;   // Ctx::grid_iters: the K6 counters, then K2's: [192] most occupied cells a frame's LDS cell grid needed ([193] spare)
 #ifndef ILCC_K2_ALLPAIRS_MAX
 #define ILCC_K2_ALLPAIRS_MAX 256
 #endif
@@ -134,10 +134,21 @@ struct Ctx {
   uint32_t* uf_hash_next;    // K2 spatial hash: chain links, one per point
   uint32_t cluster_lds_points;   // K2: ROI points per frame whose cell-sorted copy fits the workgroup's LDS; larger frames sort into HBM
   uint32_t cluster_cells_cap;    // K2: occupied cells per frame the workgroup's LDS arrays hold; frames with more take the point-level path
-  uint32_t* big_count;       // K2: number of listed frames of this batch (reset by K1)
-  uint32_t* big_list;        // K2: their frame indices
-  uint32_t big_grid;         // K2: workgroups of the persistent multi-workgroup kernels
-  uint32_t big_armed;        // K2: 1 = those kernels are launched for this batch and large frames are left to them
+  uint32_t wide;             // per-frame kernels at their small-batch (latency) widths whatever the batch size: synchronous calls nothing overlaps with (the online caller)
+  uint32_t cluster_bits;     // K2: cells of the padded bounding grid the LDS bitmap holds (a multiple of 64)
+  // The online caller (get_chessboard_by_point on un-cropped clouds) in two tiers.  online_tier 1: K1 crops a window of
+  // +-online_window around the predicted point, K2 clusters it on the LDS cell grid and VERIFIES that the result is the one the
+  // whole cloud gives (see fine_cluster_frame); frames it cannot vouch for get frame_flags[f] = 1.  online_tier 2: K1 (unbounded
+  // box) and K2 (hashed cells) run on the flagged frames only.  0: the ROI pipeline.
+  uint32_t online_tier;
+  float online_window;
+  uint32_t* frame_flags;     // n_frames
+  uint32_t* n_finite;        // n_frames: finite points of the frame (tier 1; what an unbounded crop would keep)
+  uint32_t* crop_fin;        // n_frames x crop_chunks: finite points per K1 chunk (tier 1)
+  uint32_t* list_count;      // tier 2: number of listed (flagged) frames ...
+  uint32_t* list;            // ... and their indices
+  void* list_frames;         // tier 2: one 64-byte ListedFrame (k2_cluster.hip) per frame
+  uint32_t list_grid;        // tier 2: workgroups of the kernels over (listed frame, chunk) items
   GridPartial* partial;      // n_frames x grid_blocks
   SolveRec* solve_rec;       // n_frames x 2
   uint32_t grid_blocks;      // K6 workgroups per frame
@@ -288,7 +299,9 @@ void launch_pattern_refine_corners(const Ctx& c, hipStream_t s);
 void launch_pattern_refine_test(const Ctx& c, hipStream_t s, RefineOut* d_io);
 // once per (process, device): raise the dynamic-LDS limits of the kernels that need more than 64 KiB
 hipError_t set_kernel_attributes_k2();
-size_t cluster_lds_bytes(uint32_t pts_cap, uint32_t cells_cap);   // K2's dynamic LDS for these capacities
+size_t cluster_lds_bytes(uint32_t pts_cap, uint32_t cells_cap, uint32_t bits);   // K2's dynamic LDS for these capacities (bits: cells the bitmap holds)
+uint32_t cluster_bits_default();
+uint32_t cluster_bits_online();
 hipError_t set_kernel_attributes_k6();
 hipError_t set_kernel_attributes_k7();
 // stand-alone local solve on the labelled points of frame 0 (test entry)

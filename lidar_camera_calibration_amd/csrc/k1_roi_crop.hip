@@ -41,6 +41,7 @@ __device__ __forceinline__ bool keep_point(const float4 q, const Box& b) {
 
 __global__ __launch_bounds__(kCropThreads) void k1_roi_count(Ctx c) {
   const uint32_t f = blockIdx.y, s = blockIdx.x;
+  if (c.online_tier == 2u && c.frame_flags[f] == 0u) return;   // second tier of the online caller: the frames the first could not vouch for
   const uint64_t beg = c.off[f], end = c.off[f + 1];
   const uint64_t n = end - beg;
   // the batch's scratch words are reset here instead of by separate memset launches (each costs ~5 us plus a
@@ -49,7 +50,7 @@ __global__ __launch_bounds__(kCropThreads) void k1_roi_count(Ctx c) {
   if (s == 0) {
     uint32_t* w = reinterpret_cast<uint32_t*>(&c.res[f]);
     for (uint32_t k = threadIdx.x; k < sizeof(ilcc_result) / 4; k += kCropThreads) w[k] = 0u;
-    if (f == 0 && threadIdx.x < kBatchWords) c.grid_iters[threadIdx.x] = 0ull;   // (kBatchWords <= kCropThreads)
+    if (f == 0 && threadIdx.x < kBatchWords && c.online_tier != 2u) c.grid_iters[threadIdx.x] = 0ull;   // (kBatchWords <= kCropThreads)
     __syncthreads();
   }
   if (s == 0 && threadIdx.x == 0) {
@@ -71,10 +72,10 @@ __global__ __launch_bounds__(kCropThreads) void k1_roi_count(Ctx c) {
     c.n_lab[f] = 0;
     c.grid_bound[f] = 0x7f800000u;   // +inf
     c.grid_bound_sub[f] = 0x7f800000u;
-    if (f == 0) *c.big_count = 0u;   // K2's list of frames above its LDS capacity
+    if (c.online_tier == 1u) c.frame_flags[f] = 0u;
   }
   const uint64_t cbeg = (uint64_t)s * kCropChunk;
-  uint32_t cnt = 0;
+  uint32_t cnt = 0, fin = 0;
   unsigned long long* masks = c.crop_masks + ((uint64_t)f * c.crop_chunks + s) * (kCropChunk / ILCC_WAVE);
   if (cbeg < n) {
     const Box b = make_box(c, f);
@@ -99,15 +100,21 @@ __global__ __launch_bounds__(kCropThreads) void k1_roi_count(Ctx c) {
       const unsigned long long m = __ballot(keep);
       if (lane_id() == 0) masks[k * (kCropThreads / ILCC_WAVE) + wave_id()] = m;   // order (trip, wavefront) = input order
       cnt += keep ? 1u : 0u;
+      fin += ((i < cend) && isfinite(q[k].x) && isfinite(q[k].y) && isfinite(q[k].z)) ? 1u : 0u;
     }
   }
   __shared__ uint32_t sc[17];
   const uint32_t total = block_sum<uint32_t>(cnt, sc);
   if (threadIdx.x == 0) c.crop_counts[(uint64_t)f * c.crop_chunks + s] = total;
+  if (c.online_tier == 1u) {   // (uniform) what an unbounded crop would keep: the online caller's n_roi
+    const uint32_t total_fin = block_sum<uint32_t>(fin, sc);
+    if (threadIdx.x == 0) c.crop_fin[(uint64_t)f * c.crop_chunks + s] = total_fin;
+  }
 }
 
 __global__ __launch_bounds__(kCropThreads) void k1_roi_scatter(Ctx c) {
   const uint32_t f = blockIdx.y, s = blockIdx.x;
+  if (c.online_tier == 2u && c.frame_flags[f] == 0u) return;
   const uint64_t beg = c.off[f], end = c.off[f + 1];
   const uint64_t n = end - beg;
   const uint32_t* counts = c.crop_counts + (uint64_t)f * c.crop_chunks;
@@ -117,9 +124,19 @@ __global__ __launch_bounds__(kCropThreads) void k1_roi_scatter(Ctx c) {
     if (k < s) base += v;
     all += v;
   }
+  if (s == 0 && threadIdx.x == 0 && c.online_tier == 1u) {
+    uint32_t nf = 0;
+    for (uint32_t k = 0; k < c.crop_chunks; ++k) nf += c.crop_fin[(uint64_t)f * c.crop_chunks + k];
+    c.n_finite[f] = nf;
+  }
   if (s == 0 && threadIdx.x == 0) {
     c.res[f].n_roi = (int32_t)all;
-    if (all == 0) c.res[f].status = ILCC_NO_ROI_POINTS;
+    if (all == 0) {
+      if (c.online_tier == 1u)
+        c.frame_flags[f] = 1u;   // nothing in the window says nothing about the cloud: second tier
+      else
+        c.res[f].status = ILCC_NO_ROI_POINTS;
+    }
   }
   const uint64_t cbeg = (uint64_t)s * kCropChunk;
   if (cbeg >= n || counts[s] == 0) return;

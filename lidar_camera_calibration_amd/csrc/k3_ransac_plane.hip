@@ -219,7 +219,7 @@ __global__ __launch_bounds__(kPlaneThreadsSmallBatch) void k3_ransac_plane(Ctx c
 }
 
 void launch_ransac_plane(const Ctx& c, hipStream_t s) {
-  const int threads = c.n_frames <= (uint32_t)kSmallBatchFrames ? kPlaneThreadsSmallBatch : kPlaneThreads;
+  const int threads = (c.n_frames <= (uint32_t)kSmallBatchFrames || c.wide) ? kPlaneThreadsSmallBatch : kPlaneThreads;
   hipLaunchKernelGGL(k3_ransac_plane, dim3(c.n_frames), dim3(threads), 0, s, c);
 }
 

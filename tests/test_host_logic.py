@@ -54,7 +54,7 @@ def test_struct_layouts_match_the_library():
     assert (p.refine_div, p.refine_max_rounds, p.refine_th_margin) == (16, 64, 32)
     assert p.ambiguity_eps == 1.0 and p.online_cluster_tol == 0.10     # LidarCornersEst.cpp:80
     assert p.min_cell_coverage == 0.9
-    assert C.sizeof(N.Timing) == 7 * 4 + 4 + 8 + 4 * 8 + 5 * 8 + 8 + 8 * 8   # ABI 4: three doubles appended; ABI 5: two more, the batch count, the stage sums
+    assert C.sizeof(N.Timing) == 7 * 4 + 4 + 8 + 4 * 8 + 5 * 8 + 8 + 8 * 8 + 8   # ABI 4: three doubles appended; ABI 5: two more, the batch count, the stage sums
     assert C.sizeof(N.Result) == 14 * 4 + 4 + 16 + 64 + 4 + 16 + 24 + 24 + 8 + 8 + 8 + 3 * 4 * 256  # no hidden padding surprises
 
 
