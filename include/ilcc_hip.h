@@ -98,7 +98,8 @@ typedef struct ilcc_params {
   double cluster_tol;
   int32_t cluster_min;
   int32_t cluster_max;
-  /* getPlane (LidarCornersEst.cpp:201); hypotheses of the counter-based sampler */
+  /* getPlane (LidarCornersEst.cpp:201); ransac_hyp = SACSegmentation::max_iterations_ (PCL default 50) of the counter-based
+   * sampler's hypotheses (with ransac_probability <= 0: their fixed number, as in ABI <= 4) */
   double ransac_thresh;
   int32_t ransac_hyp;
   uint32_t ransac_seed;
@@ -133,6 +134,9 @@ typedef struct ilcc_params {
   /* get_chessboard_by_point hard-codes its own tolerance: setClusterTolerance(0.1), LidarCornersEst.cpp:80 */
   double online_cluster_tol;
   double min_cell_coverage;  /* ILCC_FLAG_LOW_COVERAGE below this fraction of occupied board squares (default 0.9; <= 0: never) */
+  double ransac_probability; /* ABI 5: SACSegmentation::probability_ (PCL default 0.99): the plane RANSAC stops once its iterations reach
+                                log(1 - p) / log(1 - w^3), w = the best hypothesis' inlier share -- pcl::RandomSampleConsensus's rule,
+                                3-5 hypotheses on a board cluster; <= 0: ransac_hyp hypotheses, no early stop */
 } ilcc_params;
 
 /* Accepting a frame.  The reference leaves the decision to the operator, who looks at the virtual board drawn over the

@@ -66,6 +66,7 @@ class Params(C.Structure):
         ("ambiguity_eps", C.c_double),
         ("online_cluster_tol", C.c_double),
         ("min_cell_coverage", C.c_double),
+        ("ransac_probability", C.c_double),
     ]
 
 

@@ -137,6 +137,7 @@ bool params_ok(const ilcc_params& p, std::string& why) {
   if (p.hist_bins < 1 || p.hist_bins > 4096) return bad("hist_bins out of range");
   if (!(p.gray_rate > 0) || !(p.huber_delta > 0)) return bad("gray_rate / huber_delta must be > 0");
   if (p.ransac_hyp < 1 || p.ransac_hyp > 65536) return bad("ransac_hyp out of range");
+  if (!(p.ransac_probability == p.ransac_probability) || p.ransac_probability >= 1.0) return bad("ransac_probability must be < 1");
   if (!(p.cluster_tol > 0) || p.cluster_min < 1 || p.cluster_max < p.cluster_min) return bad("cluster params");
   if (p.solver != ILCC_SOLVER_REFERENCE_LOCAL && p.solver != ILCC_SOLVER_GRID) return bad("solver");
   if (p.phase_mode < 0 || p.phase_mode > 2) return bad("phase_mode");
@@ -925,7 +926,8 @@ void ilcc_default_params(ilcc_params* p) {
   p->cluster_min = 100;
   p->cluster_max = 25000;
   p->ransac_thresh = 0.03;
-  p->ransac_hyp = 128;
+  p->ransac_hyp = 50;            // SACSegmentation: max_iterations_
+  p->ransac_probability = 0.99;  // SACSegmentation: probability_
   p->ransac_seed = 12345u;
   p->hist_bins = 100;
   p->gray_rate = 2.5;

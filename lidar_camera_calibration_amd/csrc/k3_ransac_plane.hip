@@ -2,10 +2,11 @@
 // 0.03 m, optimize coefficients) of LidarCornersEst::getPlane
 // (/root/reference/ilcc2/src/LidarCornersEst.cpp:190-221).
 //
-// One 1024-thread workgroup per frame (16 wavefronts).  Each wavefront scores whole
+// One workgroup per frame (4 wavefronts; 16 in small batches).  Each wavefront scores whole
 // hypotheses: the three sample indices come from a counter-based hash (PCL's boost::mt19937
 // stream cannot be reproduced without PCL), every lane strides over the cluster points and
 // the inlier count (|n.p+d| < thr, strict, float, unfused) is reduced with ballot/popcount.
+// How many hypotheses: PCL's own rule (RandomSampleConsensus: k = log(1 - p) / log(1 - w^3), round 5).
 // Winner = most inliers, ties -> lowest hypothesis index.  Then PCL's refinement:
 // PCA plane of the inliers (double accumulation, Jacobi eigen-solver) and re-selection of
 // the inliers with the refined plane, emitted in input order (= m_cloud_chessboard).
@@ -94,48 +95,125 @@ __global__ __launch_bounds__(kPlaneThreadsSmallBatch) void k3_ransac_plane(Ctx c
   }
 
   // ---- score hypotheses, one per wavefront pass
-  uint32_t best_cnt = 0, best_h = 0xFFFFFFFFu;
-  for (uint32_t h = (uint32_t)wid; h < (uint32_t)c.p.ransac_hyp; h += kThreads / ILCC_WAVE) {
+  const uint32_t n_waves = kThreads / ILCC_WAVE;
+  auto score = [&](uint32_t h, uint32_t beat, uint32_t& cnt) -> bool {   // false: degenerate sample.  cnt is exact whenever it exceeds `beat`
     const uint32_t i0 = sample_index(c.p.ransac_seed, h, 0, M);
     const uint32_t i1 = sample_index(c.p.ransac_seed, h, 1, M);
     const uint32_t i2 = sample_index(c.p.ransac_seed, h, 2, M);
     float pl[4];
-    if (i0 == i1 || i0 == i2 || i1 == i2) continue;
-    if (!plane_from_3(P[i0], P[i1], P[i2], pl)) continue;
-    uint32_t cnt = 0;
+    cnt = 0;
+    if (i0 == i1 || i0 == i2 || i1 == i2) return false;
+    if (!plane_from_3(P[i0], P[i1], P[i2], pl)) return false;
     for (uint32_t base = 0; base < M; base += ILCC_WAVE) {
       const uint32_t i = base + lane;
       const bool in = (i < M) && plane_dist(pl, P[i]) < thr;
       cnt += (uint32_t)__popcll(__ballot(in));
-      // exact early exit: even if every point still to come were an inlier, this hypothesis could not beat (>) the best one
-      // this wavefront has already counted in full (wave-uniform: a scalar branch)
-      if (cnt + (M - min(M, base + (uint32_t)ILCC_WAVE)) <= best_cnt) break;
+      // exact early exit: even if every point still to come were an inlier, this hypothesis could not beat (>) a count that
+      // has already been reached in full (wave-uniform: a scalar branch)
+      if (cnt + (M - min(M, base + (uint32_t)ILCC_WAVE)) <= beat) break;
     }
-    if (cnt > best_cnt) {   // h ascending within a wavefront: ties keep the lowest h
-      best_cnt = cnt;
-      best_h = h;
+    return true;
+  };
+  if (c.p.ransac_probability > 0.0) {
+    // pcl::RandomSampleConsensus::computeModel's loop (PCL 1.8 ransac.hpp; SACSegmentation: probability 0.99, max_iterations 50),
+    // operation for operation the oracle's orc_ransac_plane: hypotheses are SCORED a round at a time, one per wavefront, and then
+    // walked in index order by one thread exactly as the serial loop would -- k = log(1 - p) / log(1 - w^3) after every new
+    // best, degenerate samples skipped without counting, stop at iterations >= k.  Hypotheses of the last round that lie behind
+    // the stop are ignored: what was scored beyond PCL's last iteration never counts.  A board cluster stops after 3-5 (rounds
+    // 1-4 scored 128 whatever the data said: 34.5 M of the path's 385 M VALU instructions per 1024 frames).
+    __shared__ uint32_t s_state[5];   // best count, best hypothesis, iterations, skipped, stop
+    __shared__ double s_k;
+    if (tid == 0) {
+      s_state[0] = 0u;
+      s_state[1] = 0xFFFFFFFFu;
+      s_state[2] = s_state[3] = s_state[4] = 0u;
+      s_k = 1.0;
     }
-  }
-  if (lane == 0) {
-    sc[wid] = best_cnt;
-    sc[16 + wid] = best_h;
-  }
-  __syncthreads();
-  if (tid == 0) {
-    uint32_t bc = 0, bh = 0xFFFFFFFFu;
-    for (int w = 0; w < (int)(kThreads / ILCC_WAVE); ++w)
-      if (sc[w] > bc || (sc[w] == bc && sc[w] > 0 && sc[16 + w] < bh)) {
-        bc = sc[w];
-        bh = sc[16 + w];
+    __syncthreads();
+    const double log_probability = log(1.0 - c.p.ransac_probability);
+    const double one_over_indices = 1.0 / (double)M;
+    const uint32_t max_it = (uint32_t)c.p.ransac_hyp, max_skip = max_it * 10u;
+    for (uint32_t h0 = 0;; h0 += n_waves) {
+      uint32_t cnt;
+      const bool valid = score(h0 + (uint32_t)wid, s_state[0], cnt);
+      if (lane == 0) sc[wid] = valid ? cnt : 0xFFFFFFFFu;
+      __syncthreads();
+      if (tid == 0) {
+        uint32_t best = s_state[0], best_h = s_state[1], it = s_state[2], skip = s_state[3], stop = 0u;
+        double k = s_k;
+        for (uint32_t j = 0; j < n_waves; ++j) {
+          if (!((double)it < k && skip < max_skip)) {
+            stop = 1u;
+            break;
+          }
+          const uint32_t v = sc[j];
+          if (v == 0xFFFFFFFFu) {
+            ++skip;
+            continue;
+          }
+          if (v > best) {   // (a count cut short by the early exit is <= the best of the round's start: never taken)
+            best = v;
+            best_h = h0 + j;
+            const double w = (double)best * one_over_indices;
+            double p_no_outliers = 1.0 - w * w * w;
+            p_no_outliers = fmax(2.220446049250313e-16, p_no_outliers);
+            p_no_outliers = fmin(1.0 - 2.220446049250313e-16, p_no_outliers);
+            k = log_probability / log(p_no_outliers);
+          }
+          ++it;
+          if (it > max_it) {
+            stop = 1u;
+            break;
+          }
+        }
+        if (!((double)it < k && skip < max_skip)) stop = 1u;   // (the serial loop's next test: spares a round)
+        s_state[0] = best;
+        s_state[1] = best_h;
+        s_state[2] = it;
+        s_state[3] = skip;
+        s_state[4] = stop;
+        s_k = k;
       }
-    sc[32] = bc;
-    sc[33] = bh;
-    if (bc > 0) {
-      float pl[4];
-      plane_from_3(P[sample_index(c.p.ransac_seed, bh, 0, M)], P[sample_index(c.p.ransac_seed, bh, 1, M)],
-                   P[sample_index(c.p.ransac_seed, bh, 2, M)], pl);
-      for (int k = 0; k < 4; ++k) s_plane[k] = pl[k];
+      __syncthreads();
+      if (s_state[4] != 0u) break;
     }
+    if (tid == 0) {
+      sc[32] = s_state[0];
+      sc[33] = s_state[1];
+    }
+  } else {
+    // ransac_probability <= 0: a fixed number of hypotheses (rounds 1-4), most inliers, ties -> lowest index
+    uint32_t best_cnt = 0, best_h = 0xFFFFFFFFu;
+    for (uint32_t h = (uint32_t)wid; h < (uint32_t)c.p.ransac_hyp; h += n_waves) {
+      uint32_t cnt;
+      if (!score(h, best_cnt, cnt)) continue;
+      if (cnt > best_cnt) {   // h ascending within a wavefront: ties keep the lowest h
+        best_cnt = cnt;
+        best_h = h;
+      }
+    }
+    if (lane == 0) {
+      sc[wid] = best_cnt;
+      sc[16 + wid] = best_h;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      uint32_t bc = 0, bh = 0xFFFFFFFFu;
+      for (int w = 0; w < (int)n_waves; ++w)
+        if (sc[w] > bc || (sc[w] == bc && sc[w] > 0 && sc[16 + w] < bh)) {
+          bc = sc[w];
+          bh = sc[16 + w];
+        }
+      sc[32] = bc;
+      sc[33] = bh;
+    }
+  }
+  if (tid == 0 && sc[32] > 0u) {
+    const uint32_t bh = sc[33];
+    float pl[4];
+    plane_from_3(P[sample_index(c.p.ransac_seed, bh, 0, M)], P[sample_index(c.p.ransac_seed, bh, 1, M)],
+                 P[sample_index(c.p.ransac_seed, bh, 2, M)], pl);
+    for (int k = 0; k < 4; ++k) s_plane[k] = pl[k];
   }
   __syncthreads();
   const uint32_t bc = sc[32];

@@ -42,6 +42,7 @@ class Params(C.Structure):
         ("refine_th_margin", C.c_int32), ("refine_pad_", C.c_int32),
         ("ambiguity_eps", C.c_double),
         ("min_cell_coverage", C.c_double),
+        ("ransac_probability", C.c_double),
     ]
 
 

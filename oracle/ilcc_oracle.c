@@ -30,7 +30,8 @@ void orc_default_params(orc_params* p) {
   p->cluster_min = 100;  /* :132 */
   p->cluster_max = 25000; /* :133 */
   p->ransac_thresh = 0.03; /* :201 */
-  p->ransac_hyp = 128;
+  p->ransac_hyp = 50;           /* SACSegmentation: max_iterations_ (50) */
+  p->ransac_probability = 0.99; /* SACSegmentation: probability_ (0.99) */
   p->ransac_seed = 12345u; /* PCL seeds its sampler with 12345 when random=false */
   p->hist_bins = 100;      /* :226 */
   p->gray_rate = 2.5;      /* :371 */
@@ -308,9 +309,14 @@ static void eig3_sym(const double a_in[9], double w[3], double v[3][3]) {
  *   hypotheses from 3 sampled points, inlier iff |n.p + d| < thr (strict, float),
  *   best = most inliers; refit = PCA plane of the inliers; inliers re-selected with the
  *   refit plane (SACSegmentation::segment).
- * PCL's sampler (boost mt19937, seed 12345) and its adaptive iteration count (<= 50) cannot
- * be reproduced without PCL.  Restatement: a fixed number of hypotheses from a counter-based
- * hash sampler (same function in the HIP kernel); ties -> lowest hypothesis index. */
+ * PCL's sampler (boost mt19937, seed 12345) cannot be reproduced without PCL: the samples come from a
+ * counter-based hash sampler (same function in the HIP kernel).  The ITERATION RULE is PCL's
+ * (pcl::RandomSampleConsensus::computeModel, PCL 1.8 ransac.hpp): k starts at 1; a hypothesis with more
+ * inliers than the best so far (strict: ties keep the earlier one) becomes the model and sets
+ * k = log(1 - probability) / log(1 - w^3), w = its inlier share, 1 - w^3 clamped to [eps, 1 - eps]; a
+ * degenerate sample is skipped without counting (at most 10 x max_iterations of them); the loop ends when
+ * iterations >= k or iterations > max_iterations.  On a board cluster (w ~ 0.9) that is 3-5 hypotheses.
+ * ransac_probability <= 0 keeps rounds 1-4's fixed number of hypotheses (ransac_hyp, no early stop). */
 static uint32_t hash_u32(uint32_t x) {
   x ^= x >> 16;
   x *= 0x7feb352dU;
@@ -366,19 +372,39 @@ int32_t orc_ransac_plane(const float* pts, int32_t m, const orc_params* p, int32
   const float thr = (float)p->ransac_thresh;
   int32_t best_cnt = 0;
   float best_pl[4] = {0, 0, 0, 0};
-  for (int32_t h = 0; h < p->ransac_hyp; ++h) {
+  const int adaptive = p->ransac_probability > 0.0;
+  const double log_probability = adaptive ? log(1.0 - p->ransac_probability) : 0.0;
+  const double one_over_indices = 1.0 / (double)m;
+  double k_iter = 1.0;
+  int32_t iterations = 0;
+  uint32_t skipped = 0;
+  const uint32_t max_skip = (uint32_t)p->ransac_hyp * 10u;
+  for (uint32_t h = 0;; ++h) {   /* h: samples drawn; iterations: the ones that gave a model */
+    if (adaptive ? !((double)iterations < k_iter && skipped < max_skip) : !(h < (uint32_t)p->ransac_hyp)) break;
     float pl[4];
-    const uint32_t i0 = sample_index(p->ransac_seed, (uint32_t)h, 0, (uint32_t)m);
-    const uint32_t i1 = sample_index(p->ransac_seed, (uint32_t)h, 1, (uint32_t)m);
-    const uint32_t i2 = sample_index(p->ransac_seed, (uint32_t)h, 2, (uint32_t)m);
-    if (!plane_from_3(pts, i0, i1, i2, pl)) continue;
+    const uint32_t i0 = sample_index(p->ransac_seed, h, 0, (uint32_t)m);
+    const uint32_t i1 = sample_index(p->ransac_seed, h, 1, (uint32_t)m);
+    const uint32_t i2 = sample_index(p->ransac_seed, h, 2, (uint32_t)m);
+    if (!plane_from_3(pts, i0, i1, i2, pl)) {
+      ++skipped;
+      continue;
+    }
     int32_t cnt = 0;
     for (int32_t i = 0; i < m; ++i)
       if (plane_dist(pl, pts + 4 * i) < thr) ++cnt;
     if (cnt > best_cnt) {
       best_cnt = cnt;
       memcpy(best_pl, pl, sizeof(pl));
+      if (adaptive) {
+        const double w = (double)best_cnt * one_over_indices;
+        double p_no_outliers = 1.0 - w * w * w; /* (PCL: pow(w, 3)) */
+        if (p_no_outliers < DBL_EPSILON) p_no_outliers = DBL_EPSILON;
+        if (p_no_outliers > 1.0 - DBL_EPSILON) p_no_outliers = 1.0 - DBL_EPSILON;
+        k_iter = log_probability / log(p_no_outliers);
+      }
     }
+    ++iterations;
+    if (adaptive && iterations > p->ransac_hyp) break;
   }
   if (best_cnt == 0) return 0;
 

@@ -65,7 +65,8 @@ typedef struct orc_params {
   int32_t cluster_max;
   /* getPlane, LidarCornersEst.cpp:201 */
   double ransac_thresh;
-  int32_t ransac_hyp;       /* number of 3-point hypotheses (counter-based sampler, see .c) */
+  int32_t ransac_hyp;       /* SACSegmentation::max_iterations_ (PCL default 50): bound on the 3-point hypotheses that count as iterations;
+                               with ransac_probability <= 0: their fixed number (rounds 1-4) */
   uint32_t ransac_seed;
   /* calHist / get_gray_zone, LidarCornersEst.cpp:226,371 */
   int32_t hist_bins;
@@ -93,6 +94,8 @@ typedef struct orc_params {
   int32_t refine_pad_;
   double ambiguity_eps;      /* ORC_AMBIGUOUS when (best neighbouring basin - cost) / cost < eps (default 1.0: an alternative must cost at least twice as much; <= 0: never) */
   double min_cell_coverage;  /* ORC_FLAG_LOW_COVERAGE when fewer than this fraction of the board's squares hold a labelled point under the final pose (default 0.9; <= 0: never) */
+  double ransac_probability; /* SACSegmentation::probability_ (PCL default 0.99): RANSAC stops once iterations >= log(1 - p) / log(1 - w^3),
+                                w = best inlier share so far (pcl::RandomSampleConsensus::computeModel); <= 0: ransac_hyp hypotheses, no early stop */
 } orc_params;
 
 typedef struct orc_result {

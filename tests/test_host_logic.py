@@ -136,7 +136,7 @@ def test_k6_credit_matches_the_isa():
 
 def test_defaults_agree_with_the_oracle(ob):
     p, o = N.default_params(), ob.default_params()
-    for f in ("cluster_tol", "cluster_min", "cluster_max", "ransac_thresh", "ransac_hyp", "ransac_seed",
+    for f in ("cluster_tol", "cluster_min", "cluster_max", "ransac_thresh", "ransac_hyp", "ransac_seed", "ransac_probability",
               "hist_bins", "gray_rate", "huber_delta", "grid_length", "board_w", "board_h", "phase_mode",
               "n_th", "n_ty", "n_tz", "th_min", "th_step", "ty_min", "ty_step", "tz_min", "tz_step",
               "refine_div", "refine_max_rounds", "refine_th_margin", "ambiguity_eps", "min_cell_coverage"):

@@ -1,7 +1,7 @@
 """The real timeline of the pipelined bench at a given depth, WITHOUT a profiler (rocprofv3's kernel trace changes the very
 thing in question: under it the depth cliff disappears).  Uses ilcc_debug_timeline_* (HIP-event times of every batch relative
 to one reference event) and the host's own clock around submit / wait.
-usage: [ILCC_HIP_LIB=build/ab/libilcc_hip_s8.so] python tools/dev_depth_timeline.py DEPTH [steps=40] [out.json]"""
+usage: [ILCC_HIP_LIB=build/ab/libilcc_hip_s8.so] python tools/dev_depth_timeline.py DEPTH [steps=40] [out.json] [config=2|5]"""
 import ctypes as C, json, os, sys, time
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,17 +10,25 @@ import bench
 
 DEPTH = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 40
-F, n_points = 1024, 28800
-clouds, clicks, gts = bench.generate(2, F, 0xC0FFEE, 16)
+CONFIG = int(sys.argv[4]) if len(sys.argv) > 4 else 2
+F, n_points = (1024, 28800) if CONFIG == 2 else (64, 131072)
+clouds, clicks, gts = bench.generate(CONFIG, F, 0xC0FFEE, 16)
 import torch
 from lidar_camera_calibration_amd import LidarCornersBatch
 from lidar_camera_calibration_amd import _native as N
 dev = torch.device("cuda", 0)
 d_cloud = torch.from_numpy(clouds).to(dev)
 d_click = torch.from_numpy(clicks).to(dev)
-est = LidarCornersBatch(F, n_points, N.default_params(), device=0)
+params = N.default_params()
+if CONFIG == 5:
+    params.board_w, params.board_h, params.grid_length = 9, 12, 0.10
+    params.n_th = params.n_ty = params.n_tz = 129
+    params.th_min, params.th_step = -16.0 * np.pi / 180.0, 0.25 * np.pi / 180.0
+    params.ty_min = params.tz_min = -0.10
+    params.ty_step = params.tz_step = 0.10 / 64
+est = LidarCornersBatch(F, n_points, params, device=0)
 est.set_result_mode(N.RESULTS_COMPACT)
-est.reserve(2048, 2560)
+est.reserve(6000, 20000) if CONFIG == 5 else est.reserve(2048, 2560)
 L = est._lib
 
 
@@ -79,7 +87,7 @@ out = {
             "end and the next one's start",
 }
 print(json.dumps(out))
-if len(sys.argv) > 3:
+if len(sys.argv) > 3 and sys.argv[3] != "-":
     json.dump(out, open(sys.argv[3], "w"), indent=1)
 # the last few batches, absolute
 for r in rows[-6:]:
