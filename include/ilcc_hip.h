@@ -63,6 +63,13 @@ enum {
                                  near ties was skipped and the fp32 argmin (same tie-break) was used */
   ILCC_FLAG_REFINE_CAPPED = 2, /* a pattern search stopped at refine_max_rounds before its stride reached the finest lattice:
                                  theta_t is a valid (cheaper-than-start) point but not a lattice minimum */
+  ILCC_FLAG_BORDER_RISK = 8,  /* ABI 5: a labelled point lies within fp32 rounding (4e-6 square) of a cell border under the grid argmin or one
+                                 of its 26 grid neighbours.  The grid pass ranks candidates on fp32 sums; such a point may fall into the
+                                 other cell there, its term differ by a whole residual from the exact (fp64) one, and the ranking of
+                                 those candidates from the exact one.  The refinement then does NOT take its shortcut (the first round is
+                                 evaluated on exact costs, not inferred from the grid pass), so everything downstream of the grid argmin
+                                 is exact; the argmin itself stays the fp32 one.  Measure-zero on real data (7-14 % of synthetic frames
+                                 have a point inside the window somewhere in the 27-neighbourhood; none of 16 384 swept frames differed) */
   ILCC_FLAG_LOW_COVERAGE = 4  /* fewer than min_cell_coverage of the board's squares hold a labelled point under the final
                                  pose (cells_hit < min_cell_coverage * board_w * board_h): the pattern is under-sampled
                                  (far board, few rings) and a one-square slip can fit the data BETTER than the truth.
@@ -334,6 +341,15 @@ int64_t ilcc_fetch_walk(ilcc_handle* h, uint32_t frame, float* out_yz, uint8_t* 
  * selects it.  Test/diagnostic entry of the hot kernel. */
 int32_t ilcc_grid_cost(ilcc_handle* h, const float* yz, const uint8_t* label, uint32_t m,
                        int32_t use_oob, float* cost_out, int32_t* best_index, float* best_cost);
+
+/* The GRID solver exactly as the pipeline runs it -- walk layout, the launches that locate the minimum, common pre-pass, full pass
+ * with its near-tie list, then the refinement with the near-tie recount and its first-round shortcut -- on caller-supplied labelled
+ * points (host buffers).  Out: the grid argmin and its fp32 cost, the refined lattice point (units of step / refine_div from the
+ * grid's minima), phase, fixed-point costs (units of 2^-40) of the result and of the cheapest neighbouring basin, rounds, hops,
+ * ILCC_FLAG_* and the near-tie count.  Test/diagnostic entry (adversarial inputs for the fp32 ranking). */
+int32_t ilcc_grid_solve(ilcc_handle* h, const float* yz, const uint8_t* label, uint32_t m, int32_t* grid_index, float* grid_cost,
+                        int32_t lat[3], int32_t* phase, int64_t* cost_q, int64_t* alt_cost_q, int32_t* rounds, int32_t* hops,
+                        int32_t* flags, int32_t* ties);
 
 /* the GRID-mode refinement kernel on caller-supplied labelled points: lat[3] in/out are lattice coordinates
  * (theta, ty, tz) in units of step / refine_div from (th_min, ty_min, tz_min), *phase in/out; out: fixed-point

@@ -17,7 +17,8 @@ MAX_CORNERS = 256
 
 OK, NO_ROI_POINTS, NO_CLUSTER, NO_PLANE, DEGENERATE_HIST, TOO_FEW_POINTS, BAD_ARGUMENT, CAPACITY, \
     HIP_ERROR, IO_ERROR, BOARD_NOT_FOUND, AMBIGUOUS = range(12)
-FLAG_TIE_OVERFLOW, FLAG_REFINE_CAPPED, FLAG_LOW_COVERAGE = 1, 2, 4
+FLAG_TIE_OVERFLOW, FLAG_REFINE_CAPPED, FLAG_LOW_COVERAGE, FLAG_BORDER_RISK = 1, 2, 4, 8
+FLAGS_FP32_ONLY = FLAG_TIE_OVERFLOW | FLAG_BORDER_RISK   # flags about the fp32 grid pass: the (exact) oracle has no counterpart
 RECORD_HEADER = 20
 TIMELINE_COLS = 15
 COST_Q_ONE = float(1 << 40)
@@ -29,7 +30,7 @@ EXPORTS = [
     "ilcc_abi_version", "ilcc_strerror", "ilcc_last_error", "ilcc_default_params",
     "ilcc_set_chessboard_param", "ilcc_create", "ilcc_destroy", "ilcc_set_params", "ilcc_reserve", "ilcc_extract",
     "ilcc_extract_batch", "ilcc_extract_batch_device", "ilcc_submit_batch_device", "ilcc_submit_batch", "ilcc_wait", "ilcc_wait_records_device", "ilcc_fetch_cloud", "ilcc_fetch_labelled", "ilcc_fetch_walk", "ilcc_chessboard_by_point_batch", "ilcc_fetch_classes",
-    "ilcc_grid_cost", "ilcc_pattern_refine", "ilcc_get_theta_t", "ilcc_get_timing", "ilcc_reset_timing",
+    "ilcc_grid_cost", "ilcc_grid_solve", "ilcc_pattern_refine", "ilcc_get_theta_t", "ilcc_get_timing", "ilcc_reset_timing",
     "ilcc_save_corners2txt", "ilcc_read_lidar_corners",
     "ilcc_set_result_mode", "ilcc_wait_compact", "ilcc_record_floats", "ilcc_fetch_results",
     "ilcc_debug_timeline_enable", "ilcc_debug_timeline_fetch",
@@ -183,6 +184,10 @@ def lib():
         L.ilcc_grid_cost.argtypes = [vp, fp, C.POINTER(C.c_uint8), C.c_uint32, C.c_int32, fp,
                                      C.POINTER(C.c_int32), fp]
         L.ilcc_grid_cost.restype = C.c_int32
+        L.ilcc_grid_solve.argtypes = [vp, fp, C.POINTER(C.c_uint8), C.c_uint32, C.POINTER(C.c_int32), fp, C.POINTER(C.c_int32),
+                                      C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32),
+                                      C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        L.ilcc_grid_solve.restype = C.c_int32
         L.ilcc_pattern_refine.argtypes = [vp, fp, C.POINTER(C.c_uint8), C.c_uint32, C.POINTER(C.c_int32),
                                           C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                                           C.POINTER(C.c_int32), C.POINTER(C.c_int32)]

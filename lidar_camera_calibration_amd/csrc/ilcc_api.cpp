@@ -538,6 +538,143 @@ int32_t enqueue(ilcc_handle* h, int si, const float4* d_xyzi, const uint64_t* of
   return st;
 }
 
+// The grid search of one batch on its stream: K5w (walk layout), the launches that locate the minimum and publish the frame's bound
+// (seed, refinement, anchor), the common pre-pass, the full pass -- with the slot's K6 events recorded in between.  chain: the full
+// pass waits for the previous batch's (the pipeline; the diagnostic entry ilcc_grid_solve runs alone).
+int32_t enqueue_grid_search(ilcc_handle* h, Slot& sl, int si, const Ctx& c, hipStream_t s, uint32_t n_frames, bool chain) {
+  const bool prune = h->p.grid_prune != 0;
+  launch_walk_order(c, s);   // K5w: the labelled points in K6's walk layout, once per frame
+  HIP_TRY(h, hipEventRecord(sl.k6ev[0], s));
+  bool ev1 = false, ev2 = false;
+  Ctx full = c;
+  // (grid_prune = 0 keeps the two small passes: they only initialise the frame's bound, which the cut-free full
+  // pass still needs to recognise near ties; it never cuts a tile)
+  if (h->n_th2 > 0 && h->p.n_th >= 8 && h->p.n_ty >= 8 && h->p.n_tz >= 8) {
+    // All three small launches below only have to LOCATE the minimum.  The first two therefore look at a prefix of the
+    // point walk (an eighth of the frame's labelled points, at least ILCC_SEED_POINTS = 128 positions: a uniform sample of
+    // the board) and keep their own bound word; the anchor launch evaluates what they found -- 3 thetas x 8 x 8 translations
+    // around the refinement's argmin -- on EVERY point and publishes the frame's real bound.  (Round 2 ran seed and
+    // refinement on all points: 16 % of the path's VALU instructions.)
+#ifndef ILCC_SEED_POINTS
+#define ILCC_SEED_POINTS 128
+#endif
+    const uint32_t sub = (uint32_t)ILCC_SEED_POINTS;
+    Ctx seed = c;
+    seed.cth = h->d_cth2;
+    seed.sth = h->d_sth2;
+    seed.ay = h->d_ay2;
+    seed.az = h->d_az2;
+    seed.p.n_th = h->n_th2;
+    seed.p.n_ty = h->n_ty2;
+    seed.p.n_tz = h->n_tz2;
+    seed.grid_blocks = (uint32_t)h->n_th2;
+    seed.partial = sl.d_partial2;
+    // the "nearest to zero" indices of the decimated tables (the kernel reads ay[c_ty] / az[c_tz] for its rim test and
+    // uses all three for the tie-break distance: they must index THIS launch's tables, not the full ones)
+    seed.c_th = std::min(std::max((c.c_th - h->seed_stride_th / 2 + h->seed_stride_th / 2) / std::max(1, h->seed_stride_th), 0), h->n_th2 - 1);
+    seed.c_ty = std::min(c.c_ty / std::max(1, h->seed_stride_t), h->n_ty2 - 1);
+    seed.c_tz = std::min(c.c_tz / std::max(1, h->seed_stride_t), h->n_tz2 - 1);
+    seed.walk_limit = sub;
+    if (sub) seed.grid_bound = sl.d_bound_sub;
+    launch_grid_cost(seed, s, /*use_oob=*/1, nullptr, true);
+    HIP_TRY(h, hipEventRecord(sl.k6ev[1], s));
+    ev1 = true;
+    Ctx refine = c;
+    refine.seed_partial = sl.d_partial2;
+    refine.seed_blocks = (uint32_t)h->n_th2;
+    refine.seed_n_ty = h->n_ty2;
+    refine.seed_n_tz = h->n_tz2;
+    refine.seed_stride_t = h->seed_stride_t;
+    refine.seed_stride_th = h->seed_stride_th;
+    refine.seed_off_th = h->seed_stride_th / 2;
+    // refinement pass: all candidates around the seed argmin (theta +- a third of a seed stride, 8 x 8 translations)
+    refine.refine_window = 1;
+    refine.refine_radius_th = std::max(1, h->seed_stride_th / ILCC_REFINE_RADIUS_DIV);
+    refine.grid_blocks = std::min((uint32_t)(2 * refine.refine_radius_th + 1), h->max_theta);
+    refine.partial = sl.d_partial3;
+    refine.walk_limit = sub;
+    if (sub) refine.grid_bound = sl.d_bound_sub;
+    launch_grid_cost(refine, s, /*use_oob=*/1, nullptr, true);
+    HIP_TRY(h, hipEventRecord(sl.k6ev[2], s));
+    ev2 = true;
+    if (sub) {
+      Ctx anchor = c;
+      anchor.seed_partial = sl.d_partial3;
+      anchor.seed_blocks = refine.grid_blocks;
+      anchor.seed_n_ty = h->p.n_ty;
+      anchor.seed_n_tz = h->p.n_tz;
+      anchor.seed_stride_t = 1;
+      anchor.seed_stride_th = 1;
+      anchor.seed_off_th = 0;
+      anchor.seed_k_from_flat = 1;
+#ifndef ILCC_ANCHOR_RADIUS
+#define ILCC_ANCHOR_RADIUS 1
+#endif
+#ifndef ILCC_ANCHOR_WINDOW
+#define ILCC_ANCHOR_WINDOW 2   // 1: 8 x 8 translations per theta, 2: one 4 x 4 tile around the refinement's argmin (measured: 575 k vs 586 k frames/s; with 1 theta: 581 k)
+#endif
+      anchor.refine_window = ILCC_ANCHOR_WINDOW;
+      anchor.refine_radius_th = ILCC_ANCHOR_RADIUS;
+      anchor.grid_blocks = 2 * ILCC_ANCHOR_RADIUS + 1;
+      anchor.partial = sl.d_partial4;
+      launch_grid_cost(anchor, s, /*use_oob=*/1, nullptr, true);
+      full.seed_partial = sl.d_partial4;
+      full.seed_blocks = 2 * ILCC_ANCHOR_RADIUS + 1;
+      full.seed_n_ty = h->p.n_ty;
+      full.seed_n_tz = h->p.n_tz;
+      full.seed_stride_t = 1;
+      full.seed_stride_th = 1;
+      full.seed_off_th = 0;
+    } else {
+      full.seed_partial = sl.d_partial2;
+      full.seed_blocks = (uint32_t)h->n_th2;
+      full.seed_n_ty = h->n_ty2;
+      full.seed_n_tz = h->n_tz2;
+      full.seed_stride_t = h->seed_stride_t;
+      full.seed_stride_th = h->seed_stride_th;
+      full.seed_off_th = h->seed_stride_th / 2;
+    }
+  }
+  // The FULL passes of different slots are chained so that they never share the chip (their HIP-event
+  // durations stay clean and they do not fight for LDS); the seed and refinement passes above are small,
+  // latency-bound launches and are left free to overlap with another batch's full pass, like K2/K3/K7.
+#ifndef ILCC_BOX_POINTS
+#define ILCC_BOX_POINTS 48   // 16: 461 k, 32: 485 k, 48: 487 k, 64: 484 k, 96: 474 k frames/s when it was introduced; with the one-tile anchor 32: 578 k, 48: 590 k
+#endif
+  const GroupPrepassPlan gp = group_prepass_plan(h->p);
+  // box pre-pass (k6_grid_cost.hip): its monotonicity argument needs a tile's box narrower than one square on both axes
+  full.box_points = (prune && 3.0 * h->p.ty_step < 0.9 * h->p.grid_length && 3.0 * h->p.tz_step < 0.9 * h->p.grid_length) ? (uint32_t)ILCC_BOX_POINTS : 0u;
+  if (!ev1) HIP_TRY(h, hipEventRecord(sl.k6ev[1], s));
+  if (!ev2) HIP_TRY(h, hipEventRecord(sl.k6ev[2], s));
+  HIP_TRY(h, hipEventRecord(sl.k6ev[3], s));   // behind the anchor launch: the common pre-pass gets an event span of its own
+#ifndef ILCC_K6_GROUP_PREPASS
+#define ILCC_K6_GROUP_PREPASS 1
+#endif
+  // k6_group_prepass: one box pre-pass for kThetaGroup consecutive thetas, launched HERE -- behind the anchor (it needs the
+  // frame's bound), in front of the wait for the previous batch's full pass, so it runs beside that pass like the other small
+  // launches.  Its buffers were sized for (max_frames, this grid) by alloc_slot / ilcc_set_params.
+  if (ILCC_K6_GROUP_PREPASS && full.box_points != 0u && gp.on && (size_t)n_frames * gp.groups <= sl.grp_alive_cap &&
+      (size_t)n_frames * gp.groups * gp.words <= sl.grp_mask_cap) {
+    full.grp_count = gp.groups;
+    full.grp_words = gp.words;
+    launch_group_prepass(full, s, sl.d_grp_alive, sl.d_grp_mask);
+    full.grp_alive = sl.d_grp_alive;
+    full.grp_mask = sl.d_grp_mask;
+  }
+  HIP_TRY(h, hipEventRecord(sl.ev[7], s));
+#ifndef ILCC_K6_CHAIN
+#define ILCC_K6_CHAIN 1   // (A/B builds: 0 lets the full passes of different batches overlap)
+#endif
+  if (chain && ILCC_K6_CHAIN && h->k6_last >= 0 && h->k6_last != si && h->slots[h->k6_last].busy)
+    HIP_TRY(h, hipStreamWaitEvent(s, h->slots[h->k6_last].k6_done, 0));
+  HIP_TRY(h, hipEventRecord(sl.ev[8], s));
+  full.tie_count = sl.d_tie_count;
+  launch_grid_cost(full, s, /*use_oob=*/1, nullptr, prune);
+  HIP_TRY(h, hipEventRecord(sl.k6_done, s));
+  if (chain) h->k6_last = si;
+  return ILCC_OK;
+}
+
 int32_t enqueue_impl(ilcc_handle* h, int si, const float4* d_xyzi, const uint64_t* offsets, uint32_t n_frames,
                      const float* d_clicks, bool front_only, bool no_crop) {
   Slot& sl = h->slots[si];
@@ -592,136 +729,8 @@ int32_t enqueue_impl(ilcc_handle* h, int si, const float4* d_xyzi, const uint64_
   sl.grid = !front_only && h->p.solver == ILCC_SOLVER_GRID;
   HIP_TRY(h, hipEventRecord(sl.ev[4], s));
   if (sl.grid) {
-    const bool prune = h->p.grid_prune != 0;
-    launch_walk_order(c, s);   // K5w: the labelled points in K6's walk layout, once per frame
-    HIP_TRY(h, hipEventRecord(sl.k6ev[0], s));
-    bool ev1 = false, ev2 = false;
-    Ctx full = c;
-    // (grid_prune = 0 keeps the two small passes: they only initialise the frame's bound, which the cut-free full
-    // pass still needs to recognise near ties; it never cuts a tile)
-    if (h->n_th2 > 0 && h->p.n_th >= 8 && h->p.n_ty >= 8 && h->p.n_tz >= 8) {
-      // All three small launches below only have to LOCATE the minimum.  The first two therefore look at a prefix of the
-      // point walk (an eighth of the frame's labelled points, at least ILCC_SEED_POINTS = 128 positions: a uniform sample of
-      // the board) and keep their own bound word; the anchor launch evaluates what they found -- 3 thetas x 8 x 8 translations
-      // around the refinement's argmin -- on EVERY point and publishes the frame's real bound.  (Round 2 ran seed and
-      // refinement on all points: 16 % of the path's VALU instructions.)
-#ifndef ILCC_SEED_POINTS
-#define ILCC_SEED_POINTS 128
-#endif
-      const uint32_t sub = (uint32_t)ILCC_SEED_POINTS;
-      Ctx seed = c;
-      seed.cth = h->d_cth2;
-      seed.sth = h->d_sth2;
-      seed.ay = h->d_ay2;
-      seed.az = h->d_az2;
-      seed.p.n_th = h->n_th2;
-      seed.p.n_ty = h->n_ty2;
-      seed.p.n_tz = h->n_tz2;
-      seed.grid_blocks = (uint32_t)h->n_th2;
-      seed.partial = sl.d_partial2;
-      // the "nearest to zero" indices of the decimated tables (the kernel reads ay[c_ty] / az[c_tz] for its rim test and
-      // uses all three for the tie-break distance: they must index THIS launch's tables, not the full ones)
-      seed.c_th = std::min(std::max((c.c_th - h->seed_stride_th / 2 + h->seed_stride_th / 2) / std::max(1, h->seed_stride_th), 0), h->n_th2 - 1);
-      seed.c_ty = std::min(c.c_ty / std::max(1, h->seed_stride_t), h->n_ty2 - 1);
-      seed.c_tz = std::min(c.c_tz / std::max(1, h->seed_stride_t), h->n_tz2 - 1);
-      seed.walk_limit = sub;
-      if (sub) seed.grid_bound = sl.d_bound_sub;
-      launch_grid_cost(seed, s, /*use_oob=*/1, nullptr, true);
-      HIP_TRY(h, hipEventRecord(sl.k6ev[1], s));
-      ev1 = true;
-      Ctx refine = c;
-      refine.seed_partial = sl.d_partial2;
-      refine.seed_blocks = (uint32_t)h->n_th2;
-      refine.seed_n_ty = h->n_ty2;
-      refine.seed_n_tz = h->n_tz2;
-      refine.seed_stride_t = h->seed_stride_t;
-      refine.seed_stride_th = h->seed_stride_th;
-      refine.seed_off_th = h->seed_stride_th / 2;
-      // refinement pass: all candidates around the seed argmin (theta +- a third of a seed stride, 8 x 8 translations)
-      refine.refine_window = 1;
-      refine.refine_radius_th = std::max(1, h->seed_stride_th / ILCC_REFINE_RADIUS_DIV);
-      refine.grid_blocks = std::min((uint32_t)(2 * refine.refine_radius_th + 1), h->max_theta);
-      refine.partial = sl.d_partial3;
-      refine.walk_limit = sub;
-      if (sub) refine.grid_bound = sl.d_bound_sub;
-      launch_grid_cost(refine, s, /*use_oob=*/1, nullptr, true);
-      HIP_TRY(h, hipEventRecord(sl.k6ev[2], s));
-      ev2 = true;
-      if (sub) {
-        Ctx anchor = c;
-        anchor.seed_partial = sl.d_partial3;
-        anchor.seed_blocks = refine.grid_blocks;
-        anchor.seed_n_ty = h->p.n_ty;
-        anchor.seed_n_tz = h->p.n_tz;
-        anchor.seed_stride_t = 1;
-        anchor.seed_stride_th = 1;
-        anchor.seed_off_th = 0;
-        anchor.seed_k_from_flat = 1;
-#ifndef ILCC_ANCHOR_RADIUS
-#define ILCC_ANCHOR_RADIUS 1
-#endif
-#ifndef ILCC_ANCHOR_WINDOW
-#define ILCC_ANCHOR_WINDOW 2   // 1: 8 x 8 translations per theta, 2: one 4 x 4 tile around the refinement's argmin (measured: 575 k vs 586 k frames/s; with 1 theta: 581 k)
-#endif
-        anchor.refine_window = ILCC_ANCHOR_WINDOW;
-        anchor.refine_radius_th = ILCC_ANCHOR_RADIUS;
-        anchor.grid_blocks = 2 * ILCC_ANCHOR_RADIUS + 1;
-        anchor.partial = sl.d_partial4;
-        launch_grid_cost(anchor, s, /*use_oob=*/1, nullptr, true);
-        full.seed_partial = sl.d_partial4;
-        full.seed_blocks = 2 * ILCC_ANCHOR_RADIUS + 1;
-        full.seed_n_ty = h->p.n_ty;
-        full.seed_n_tz = h->p.n_tz;
-        full.seed_stride_t = 1;
-        full.seed_stride_th = 1;
-        full.seed_off_th = 0;
-      } else {
-        full.seed_partial = sl.d_partial2;
-        full.seed_blocks = (uint32_t)h->n_th2;
-        full.seed_n_ty = h->n_ty2;
-        full.seed_n_tz = h->n_tz2;
-        full.seed_stride_t = h->seed_stride_t;
-        full.seed_stride_th = h->seed_stride_th;
-        full.seed_off_th = h->seed_stride_th / 2;
-      }
-    }
-    // The FULL passes of different slots are chained so that they never share the chip (their HIP-event
-    // durations stay clean and they do not fight for LDS); the seed and refinement passes above are small,
-    // latency-bound launches and are left free to overlap with another batch's full pass, like K2/K3/K7.
-#ifndef ILCC_BOX_POINTS
-#define ILCC_BOX_POINTS 48   // 16: 461 k, 32: 485 k, 48: 487 k, 64: 484 k, 96: 474 k frames/s when it was introduced; with the one-tile anchor 32: 578 k, 48: 590 k
-#endif
-    const GroupPrepassPlan gp = group_prepass_plan(h->p);
-    // box pre-pass (k6_grid_cost.hip): its monotonicity argument needs a tile's box narrower than one square on both axes
-    full.box_points = (prune && 3.0 * h->p.ty_step < 0.9 * h->p.grid_length && 3.0 * h->p.tz_step < 0.9 * h->p.grid_length) ? (uint32_t)ILCC_BOX_POINTS : 0u;
-    if (!ev1) HIP_TRY(h, hipEventRecord(sl.k6ev[1], s));
-    if (!ev2) HIP_TRY(h, hipEventRecord(sl.k6ev[2], s));
-    HIP_TRY(h, hipEventRecord(sl.k6ev[3], s));   // behind the anchor launch: the common pre-pass gets an event span of its own
-#ifndef ILCC_K6_GROUP_PREPASS
-#define ILCC_K6_GROUP_PREPASS 1
-#endif
-    // k6_group_prepass: one box pre-pass for kThetaGroup consecutive thetas, launched HERE -- behind the anchor (it needs the
-    // frame's bound), in front of the wait for the previous batch's full pass, so it runs beside that pass like the other small
-    // launches.  Its buffers were sized for (max_frames, this grid) by alloc_slot / ilcc_set_params.
-    if (ILCC_K6_GROUP_PREPASS && full.box_points != 0u && gp.on && (size_t)n_frames * gp.groups <= sl.grp_alive_cap &&
-        (size_t)n_frames * gp.groups * gp.words <= sl.grp_mask_cap) {
-      full.grp_count = gp.groups;
-      full.grp_words = gp.words;
-      launch_group_prepass(full, s, sl.d_grp_alive, sl.d_grp_mask);
-      full.grp_alive = sl.d_grp_alive;
-      full.grp_mask = sl.d_grp_mask;
-    }
-    HIP_TRY(h, hipEventRecord(sl.ev[7], s));
-#ifndef ILCC_K6_CHAIN
-#define ILCC_K6_CHAIN 1   // (A/B builds: 0 lets the full passes of different batches overlap)
-#endif
-    if (ILCC_K6_CHAIN && h->k6_last >= 0 && h->k6_last != si && h->slots[h->k6_last].busy)
-      HIP_TRY(h, hipStreamWaitEvent(s, h->slots[h->k6_last].k6_done, 0));
-    HIP_TRY(h, hipEventRecord(sl.ev[8], s));
-    full.tie_count = sl.d_tie_count;
-    launch_grid_cost(full, s, /*use_oob=*/1, nullptr, prune);
-    HIP_TRY(h, hipEventRecord(sl.k6_done, s));
-    h->k6_last = si;
+    const int32_t st = enqueue_grid_search(h, sl, si, c, s, n_frames, /*chain=*/true);
+    if (st != ILCC_OK) return st;
   }
   HIP_TRY(h, hipEventRecord(sl.ev[5], s));
   if (!front_only) {
@@ -1463,6 +1472,62 @@ int32_t ilcc_grid_cost(ilcc_handle* h, const float* yz, const uint8_t* label, ui
   }
   if (best_index) *best_index = (int32_t)b.flat;
   if (best_cost) *best_cost = b.cost;
+  return ILCC_OK;
+}
+
+int32_t ilcc_grid_solve(ilcc_handle* h, const float* yz, const uint8_t* label, uint32_t m, int32_t* grid_index, float* grid_cost,
+                        int32_t lat[3], int32_t* phase, int64_t* cost_q, int64_t* alt_cost_q, int32_t* rounds, int32_t* hops,
+                        int32_t* flags, int32_t* ties) {
+  if (!h || h->p.solver != ILCC_SOLVER_GRID) {
+    if (h) h->err = "ilcc_grid_solve needs ILCC_SOLVER_GRID";
+    return ILCC_BAD_ARGUMENT;
+  }
+  int32_t st = stage_labelled(h, yz, label, m);
+  if (st != ILCC_OK) return st;
+  Slot& sl = h->slots[0];
+  hipStream_t s = sl.stream;
+  uint32_t lds = 1024;
+  while (lds < m && lds < (uint32_t)kGridLdsPointsMax) lds <<= 1;
+  const uint32_t saved = h->grid_lds_points;
+  h->grid_lds_points = std::max(saved, lds);
+  Ctx c = make_ctx(h, sl, nullptr, nullptr, 1, 1);
+  h->grid_lds_points = saved;
+  // what K1 resets per frame and per batch
+  const uint32_t inf_bits = 0x7f800000u, zero = 0u;
+  HIP_TRY(h, hipMemcpyAsync(sl.d_bound, &inf_bits, sizeof(inf_bits), hipMemcpyHostToDevice, s));
+  HIP_TRY(h, hipMemcpyAsync(sl.d_bound_sub, &inf_bits, sizeof(inf_bits), hipMemcpyHostToDevice, s));
+  HIP_TRY(h, hipMemcpyAsync(sl.d_tie_count, &zero, sizeof(zero), hipMemcpyHostToDevice, s));
+  HIP_TRY(h, hipMemsetAsync(sl.d_iters, 0, sizeof(unsigned long long) * kBatchWords, s));
+  st = enqueue_grid_search(h, sl, 0, c, s, 1, /*chain=*/false);
+  if (st != ILCC_OK) return st;
+  Ctx c7 = c;
+  c7.tie_count = sl.d_tie_count;
+  launch_pattern_refine_corners(c7, s);
+  HIP_TRY(h, hipGetLastError());
+  SolveRec rec{};
+  ilcc_result r;
+  HIP_TRY(h, hipMemcpyAsync(&rec, sl.d_solverec, sizeof(rec), hipMemcpyDeviceToHost, s));
+  HIP_TRY(h, hipMemcpyAsync(&r, sl.d_res, offsetof(ilcc_result, corners), hipMemcpyDeviceToHost, s));
+  HIP_TRY(h, hipStreamSynchronize(s));
+  if (!rec.valid) {
+    h->err = "ilcc_grid_solve: the grid search produced no candidate";
+    return ILCC_TOO_FEW_POINTS;
+  }
+  const double div = (double)(h->p.refine_div > 0 ? h->p.refine_div : 1);
+  if (grid_index) *grid_index = r.grid_index;
+  if (grid_cost) *grid_cost = r.grid_cost;
+  if (lat) {
+    lat[0] = (int32_t)std::lround((rec.x[0] - h->p.th_min) / (h->p.th_step / div));
+    lat[1] = (int32_t)std::lround((rec.x[1] - h->p.ty_min) / (h->p.ty_step / div));
+    lat[2] = (int32_t)std::lround((rec.x[2] - h->p.tz_min) / (h->p.tz_step / div));
+  }
+  if (phase) *phase = rec.phase;
+  if (cost_q) *cost_q = (int64_t)std::llround(rec.sel * 1099511627776.0);      // exact: the record holds cost_q / 2^40 in a double
+  if (alt_cost_q) *alt_cost_q = (int64_t)std::llround(rec.cost_b * 1099511627776.0);
+  if (rounds) *rounds = rec.iters_a;
+  if (hops) *hops = rec.iters_b;
+  if (flags) *flags = rec.flags;
+  if (ties) *ties = rec.ties;
   return ILCC_OK;
 }
 

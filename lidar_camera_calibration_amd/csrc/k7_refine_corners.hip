@@ -651,6 +651,7 @@ constexpr double kCostQOne = 1099511627776.0;   // 2^40: quantum of the fixed-po
 static_assert(kRefineThreads % ILCC_WAVE == 0 && kRefineThreads / ILCC_WAVE >= 3 && kRefineThreads >= kRefineList &&
               kRefineThreadsSmallBatch % (3 * ILCC_WAVE) == 0,
               "ILCC_K7R_THREADS must be a multiple of 64, at least 192");
+constexpr float kBorderRisk = 4e-6f;             // squares: a board coordinate this close to an integer may be classified differently in fp32 (K6) and fp64
 constexpr int32_t kNoTheta = INT32_MIN;         // candidate whose theta lies outside the lattice table: never evaluated
 
 struct RCand {
@@ -1071,8 +1072,41 @@ __device__ void refine_frame(const Ctx& c, SolveRec* rec, float2* s_yz, uint8_t*
     // re-ordered on exact costs above -- none can be STRICTLY cheaper than the argmin, the round cannot move and is not
     // evaluated (it still counts as a round: `rounds` stays the oracle's number).  Not when the near-tie list overflowed
     // (the argmin is then the fp32 one).
+    // ... and not when K6's ranking of these 27 candidates cannot be trusted: K6 sums fp32 terms, and a point within fp32 rounding
+    // of a cell border under one of them may sit in the OTHER cell there -- its term then differs from the exact one by a whole
+    // residual, not by rounding, and "pruned => costs more" no longer follows.  The test below recomputes, with K6's own fp32
+    // expressions (its staging's rotation, its table values), the board coordinates of every labelled point under the 3 thetas
+    // x (3 + 3) axis translations of the neighbourhood and looks for one within 4e-6 square of an integer (fp32 and fp64 agree
+    // to ~1e-6 there).  None: every point is classified alike in fp32 and fp64 for all 27, their fp32 costs are the exact ones
+    // up to summation rounding (1e-6 relative, far inside the 2e-5 window) and the shortcut is sound.  Any: ILCC_FLAG_BORDER_RISK,
+    // and the round is evaluated like every other.
     const int gk = (int)(cell / (n_tz * n_ty)), ga = (int)((cell / n_tz) % n_ty), gb = (int)(cell % n_tz);
-    st.skip_first = ILCC_K7R_SKIP_FIRST && !(flags & ILCC_FLAG_TIE_OVERFLOW) && gk > 0 && gk < c.p.n_th - 1 && ga > 0 &&
+    bool risk = false;
+    for (uint32_t i = (uint32_t)tid; i < n; i += blockDim.x) {
+      const float2 v = yz[i];
+#pragma unroll
+      for (int dk = -1; dk <= 1; ++dk) {
+        const int k = gk + dk;
+        if (k < 0 || k >= c.p.n_th) continue;
+        const float cth = c.cth[k], sth = c.sth[k];
+        const float pi = fmaf(-sth, v.y, cth * v.x), pj = fmaf(cth, v.y, sth * v.x);   // = k6_grid_cost's staging
+#pragma unroll
+        for (int d = -1; d <= 1; ++d) {
+          const int a = ga + d, b = gb + d;
+          if (a >= 0 && a < (int)n_ty) {
+            const float x = pi + c.ay[a];
+            risk |= fabsf(x - rintf(x)) < kBorderRisk;
+          }
+          if (b >= 0 && b < (int)n_tz) {
+            const float x = pj + c.az[b];
+            risk |= fabsf(x - rintf(x)) < kBorderRisk;
+          }
+        }
+      }
+    }
+    risk = __syncthreads_or(risk ? 1 : 0) != 0;
+    if (risk) flags |= ILCC_FLAG_BORDER_RISK;
+    st.skip_first = ILCC_K7R_SKIP_FIRST && !risk && !(flags & ILCC_FLAG_TIE_OVERFLOW) && gk > 0 && gk < c.p.n_th - 1 && ga > 0 &&
                     ga < (int)n_ty - 1 && gb > 0 && gb < (int)n_tz - 1;
   }
   pattern_refine(c, bd, yz, lab, n, sh, sweep, st);

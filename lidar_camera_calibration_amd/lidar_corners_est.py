@@ -422,6 +422,24 @@ class LidarCornersBatch:
             raise IlccError(st, self._err())
         return q, ph.value, cq.value, aq.value, rounds.value, hops.value
 
+    def grid_solve(self, yz: np.ndarray, label: np.ndarray) -> dict:
+        """The pipeline's GRID solver (locate launches, common pre-pass, full pass with near ties, refinement with its first-round
+        shortcut) on caller-supplied labelled points -> dict(grid_index, grid_cost, lat, phase, cost_q, alt_cost_q, rounds, hops,
+        flags, ties).  Diagnostic entry (adversarial inputs for the fp32 ranking)."""
+        yz = np.ascontiguousarray(yz, dtype=np.float32).reshape(-1, 2)
+        label = np.ascontiguousarray(label, dtype=np.uint8)
+        q = np.zeros(3, dtype=np.int32)
+        gi, ph, rounds, hops, flags, ties = (C.c_int32(0) for _ in range(6))
+        gc = C.c_float(0)
+        cq, aq = C.c_int64(0), C.c_int64(0)
+        st = self._lib.ilcc_grid_solve(self._h, N.fptr(yz), label.ctypes.data_as(C.POINTER(C.c_uint8)), len(label), C.byref(gi),
+                                       C.byref(gc), q.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(ph), C.byref(cq), C.byref(aq),
+                                       C.byref(rounds), C.byref(hops), C.byref(flags), C.byref(ties))
+        if st != N.OK:
+            raise IlccError(st, self._err())
+        return dict(grid_index=gi.value, grid_cost=gc.value, lat=q, phase=ph.value, cost_q=cq.value, alt_cost_q=aq.value,
+                    rounds=rounds.value, hops=hops.value, flags=flags.value, ties=ties.value)
+
     def get_theta_t(self, yz: np.ndarray, label: np.ndarray, topleft_white: bool, use_oob: bool,
                     theta_t0=(0.0, 0.0, 0.0)):
         yz = np.ascontiguousarray(yz, dtype=np.float32).reshape(-1, 2)

@@ -89,7 +89,7 @@ def test_every_stage_matches_the_oracle(ob, est, frames, solver):
         worst = max(worst, dev)
         # the confidence signal (squares holding points / points off the board under the final pose) and its flag
         assert (r.cells_hit, r.n_oob) == (o.cells_hit, o.n_oob), (f, r.cells_hit, o.cells_hit, r.n_oob, o.n_oob)
-        assert (r.flags & ~N.FLAG_TIE_OVERFLOW) == o.flags, (f, r.flags, o.flags)
+        assert (r.flags & ~N.FLAGS_FP32_ONLY) == o.flags, (f, r.flags, o.flags)
         if solver == N.SOLVER_GRID:
             assert r.grid_index == o.grid_index, f
             assert r.grid_cost == pytest.approx(o.grid_cost, rel=2e-5, abs=2e-6)
@@ -409,7 +409,7 @@ def test_low_coverage_flag_and_accept_rule(ob):
     r2 = e2.extract(cut[None], click[None])[0]
     o2 = ob.extract(cut, click, _oparams(ob, N.SOLVER_GRID))
     assert r2.status == o2.status and (r2.cells_hit, r2.n_oob) == (o2.cells_hit, o2.n_oob)
-    assert (r2.flags & ~N.FLAG_TIE_OVERFLOW) == o2.flags
+    assert (r2.flags & ~N.FLAGS_FP32_ONLY) == o2.flags
     if r2.status in (N.OK, N.AMBIGUOUS):
         assert r2.cells_hit < 0.9 * 48 and (r2.flags & N.FLAG_LOW_COVERAGE)
         m = LidarCornersEst(device=0, max_points_per_frame=len(cut))
@@ -1044,9 +1044,73 @@ def test_near_tie_is_ordered_like_the_fp64_oracle(ob):
         e.close()
         assert r.status == ref.status and ref.status in (N.OK, N.AMBIGUOUS)
         assert r.grid_index == ref.grid_index and r.grid_index in (33157, 34756)   # the two tied basins
-        assert r.grid_ties >= 2 and (r.flags & N.FLAG_TIE_OVERFLOW) == 0 and (r.flags & ~N.FLAG_TIE_OVERFLOW) == ref.flags
+        assert r.grid_ties >= 2 and (r.flags & N.FLAG_TIE_OVERFLOW) == 0 and (r.flags & ~N.FLAGS_FP32_ONLY) == ref.flags
         assert tuple(r.theta_t) == tuple(ref.theta_t)
         assert np.abs(r.corners_array() - ob.result_corners(ref)).max() < 1e-6
+
+
+def test_points_on_cell_borders_of_the_grid_argmin(ob):
+    """Adversarial input for the fp32 grid pass.  K6 ranks the grid on fp32 sums; a labelled point
+    within fp32 rounding of a cell border under a candidate may be put into the OTHER cell there, and its term then differs from
+    the exact (fp64) one by a whole residual.  Here 48 points are placed ON cell borders (to the float32 of their coordinates:
+    a few 1e-7 square) of the grid argmin and of its grid neighbours, on real frames' labelled points, and the pipeline's solver
+    (ilcc_grid_solve) is run beside the oracle's exhaustive exact search:
+      * ILCC_FLAG_BORDER_RISK fires (K7r recomputes K6's fp32 coordinates for the 27-neighbourhood of the argmin);
+      * with it the refinement drops its first-round shortcut, so everything downstream of the grid argmin is EXACT: lattice
+        point, phase, both fixed-point costs, rounds and hops == the oracle's pattern search from the same start;
+      * the grid argmin itself either equals the oracle's exact one, or the flag is set (the documented limit: the argmin of an
+        fp32 ranking, measure-zero on real data).  Without the gate the shortcut skipped a round the oracle moves in."""
+    from lidar_camera_calibration_amd import LidarCornersBatch, synth
+    from lidar_camera_calibration_amd import _native as N
+    F = 6
+    clouds, clicks, _, _ = synth.make_batch(F, seed=0xB0BDE4)
+    p = N.default_params()
+    est = LidarCornersBatch(F, clouds.shape[1], p)
+    res = est.extract(clouds, clicks)
+    sets = [est.fetch_labelled(f) for f in range(F) if res[f].status in (N.OK, N.AMBIGUOUS)]
+    op = ob.default_params()
+    op.solver = ob.SOLVER_GRID
+    g, W, H, div = p.grid_length, p.board_w, p.board_h, p.refine_div
+    rng = np.random.default_rng(5)
+    n_flag = n_same_argmin = 0
+    for yz, lab in sets:
+        flat0, _, _ = ob.grid_search(yz[:, 0], yz[:, 1], lab.astype(np.int8), op, 1)
+        cell = flat0 >> 1
+        k0, a0, b0 = cell // (p.n_ty * p.n_tz), (cell // p.n_tz) % p.n_ty, cell % p.n_tz
+        extra = []
+        for _ in range(48):
+            k = int(np.clip(k0 + rng.integers(-1, 2), 0, p.n_th - 1))
+            th = p.th_min + k * p.th_step
+            if rng.random() < 0.5:      # on an i-border of candidate (k, a): ((cos y - sin z) + ty + W g / 2) / g = n
+                a = int(np.clip(a0 + rng.integers(-1, 2), 0, p.n_ty - 1))
+                ty, n = p.ty_min + a * p.ty_step, int(rng.integers(1, W))
+                z = rng.uniform(-0.4, 0.4) * H * g
+                y = ((n * g - W * g / 2.0 - ty) + np.sin(th) * z) / np.cos(th)
+            else:                       # on a j-border of candidate (k, b): ((sin y + cos z) + tz + H g / 2) / g = n
+                b = int(np.clip(b0 + rng.integers(-1, 2), 0, p.n_tz - 1))
+                tz, n = p.tz_min + b * p.tz_step, int(rng.integers(1, H))
+                y = rng.uniform(-0.4, 0.4) * W * g
+                z = ((n * g - H * g / 2.0 - tz) - np.sin(th) * y) / np.cos(th)
+            extra.append((y, z))
+        yz2 = np.concatenate([yz, np.array(extra, dtype=np.float32)])
+        lab2 = np.concatenate([lab, rng.integers(0, 2, len(extra)).astype(np.uint8)])
+        got = est.grid_solve(yz2, lab2)
+        flat, _, _ = ob.grid_search(yz2[:, 0], yz2[:, 1], lab2.astype(np.int8), op, 1)
+        # the refinement is exact from the solver's OWN grid argmin, whatever the fp32 ranking did
+        c2 = got["grid_index"] >> 1
+        start = np.array([c2 // (p.n_ty * p.n_tz), (c2 // p.n_tz) % p.n_ty, c2 % p.n_tz], dtype=np.int32) * div
+        q, ph, cq, aq, rounds, hops = ob.pattern_refine(yz2[:, 0], yz2[:, 1], lab2.astype(np.int8), op, start, got["grid_index"] & 1)
+        assert (tuple(got["lat"]), got["phase"], got["cost_q"], got["alt_cost_q"], got["rounds"], got["hops"]) == \
+               (tuple(q), ph, cq, aq, rounds, hops), (got, q, ph, cq, aq, rounds, hops)
+        near = abs(c2 // (p.n_ty * p.n_tz) - k0) <= 1 and abs((c2 // p.n_tz) % p.n_ty - a0) <= 1 and abs(c2 % p.n_tz - b0) <= 1
+        if near and c2 == cell:
+            assert got["flags"] & N.FLAG_BORDER_RISK, got      # 48 points within ~3e-7 square of borders of this very neighbourhood
+        assert got["grid_index"] == flat or (got["flags"] & N.FLAG_BORDER_RISK), (got, flat)
+        n_flag += int(bool(got["flags"] & N.FLAG_BORDER_RISK))
+        n_same_argmin += int(got["grid_index"] == flat)
+    assert len(sets) >= 4 and n_flag >= len(sets) - 1
+    print("border-adversarial frames: %d, flagged %d, grid argmin == exact argmin on %d" % (len(sets), n_flag, n_same_argmin))
+    est.close()
 
 
 def test_sparse_wide_roi_takes_the_point_level_hash(ob):

@@ -57,7 +57,7 @@ same_theta = sum(int(tuple(res[f].theta_t) == tuple(ref[f].theta_t) and res[f].s
                      and res[f].basin_margin == ref[f].basin_margin) for f in both) if mode in ("grid", "grid5") else -1
 flagged = sum(int(res[f].status == 11) for f in range(F))
 overflow = sum(int(res[f].flags & N.FLAG_TIE_OVERFLOW != 0) for f in range(F))
-same_conf = sum(int((res[f].cells_hit, res[f].n_oob, res[f].flags & ~N.FLAG_TIE_OVERFLOW) == (ref[f].cells_hit, ref[f].n_oob, ref[f].flags))
+same_conf = sum(int((res[f].cells_hit, res[f].n_oob, res[f].flags & ~N.FLAGS_FP32_ONLY) == (ref[f].cells_hit, ref[f].n_oob, ref[f].flags))
                 for f in both)
 low_cov = sum(int(res[f].flags & N.FLAG_LOW_COVERAGE != 0) for f in both)
 dev = [float(np.abs(res[f].corners_array() - ob.result_corners(ref[f])).max()) for f in both]
