@@ -559,6 +559,40 @@ int32_t enqueue_grid_search(ilcc_handle* h, Slot& sl, int si, const Ctx& c, hipS
 #define ILCC_SEED_POINTS 128
 #endif
     const uint32_t sub = (uint32_t)ILCC_SEED_POINTS;
+    // one launch, one workgroup per frame (k6_locate) when the batch has the frames to fill the chip that way
+    LocatePlan lp{};
+    lp.cth2 = h->d_cth2;
+    lp.sth2 = h->d_sth2;
+    lp.ay2 = h->d_ay2;
+    lp.az2 = h->d_az2;
+    lp.n_th2 = h->n_th2;
+    lp.n_ty2 = h->n_ty2;
+    lp.n_tz2 = h->n_tz2;
+    lp.c_th2 = std::min(std::max(c.c_th / std::max(1, h->seed_stride_th), 0), h->n_th2 - 1);
+    lp.c_ty2 = std::min(c.c_ty / std::max(1, h->seed_stride_t), h->n_ty2 - 1);
+    lp.c_tz2 = std::min(c.c_tz / std::max(1, h->seed_stride_t), h->n_tz2 - 1);
+    lp.stride_th = h->seed_stride_th;
+    lp.off_th = h->seed_stride_th / 2;
+    lp.stride_t = h->seed_stride_t;
+    lp.refine_radius = std::max(1, h->seed_stride_th / ILCC_REFINE_RADIUS_DIV);
+    lp.sample_min = sub;
+    lp.sample_cap = std::max(sub, ((c.grid_lds_points >> 3) + 63u) & ~63u);
+    lp.out = sl.d_partial4;
+    const bool fused = n_frames >= (uint32_t)kLocateMinFrames && sub != 0u && h->n_th2 <= 16 &&
+                       locate_lds_bytes(lp.sample_cap, h->p.n_ty, h->p.n_tz, h->n_ty2, h->n_tz2) <= 60u * 1024u;
+    if (fused) {
+      launch_locate(c, s, lp);
+      HIP_TRY(h, hipEventRecord(sl.k6ev[1], s));   // (the whole locate launch is accounted as the "seed" span)
+      HIP_TRY(h, hipEventRecord(sl.k6ev[2], s));
+      ev1 = ev2 = true;
+      full.seed_partial = sl.d_partial4;
+      full.seed_blocks = 1;
+      full.seed_n_ty = h->p.n_ty;
+      full.seed_n_tz = h->p.n_tz;
+      full.seed_stride_t = 1;
+      full.seed_stride_th = 1;
+      full.seed_off_th = 0;
+    } else {
     Ctx seed = c;
     seed.cth = h->d_cth2;
     seed.sth = h->d_sth2;
@@ -634,6 +668,7 @@ int32_t enqueue_grid_search(ilcc_handle* h, Slot& sl, int si, const Ctx& c, hipS
       full.seed_stride_th = h->seed_stride_th;
       full.seed_off_th = h->seed_stride_th / 2;
     }
+  }
   }
   // The FULL passes of different slots are chained so that they never share the chip (their HIP-event
   // durations stay clean and they do not fight for LDS); the seed and refinement passes above are small,

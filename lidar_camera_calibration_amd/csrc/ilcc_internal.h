@@ -280,6 +280,21 @@ __device__ __forceinline__ uint32_t block_rank(bool flag, uint32_t* scratch, uin
   return base + in_wave;
 }
 
+// k6_locate (k6_grid_cost.hip): seed + refinement + anchor of the grid search in one launch, one workgroup per frame
+struct LocatePlan {
+  const float *cth2, *sth2, *ay2, *az2;   // the seed's decimated tables (subsets of the full ones)
+  int32_t n_th2, n_ty2, n_tz2;
+  int32_t c_th2, c_ty2, c_tz2;            // their entries nearest zero (tie-break distance)
+  int32_t stride_th, off_th, stride_t;    // seed (k2, a2, b2) -> full tables (off_th + k2 stride_th, a2 stride_t, b2 stride_t)
+  int32_t refine_radius;                  // refinement: theta within +- this many steps of the seed's
+  uint32_t sample_min, sample_cap;        // the sample: max(sample_min, M >> kSeedShift) walk positions, at most sample_cap (LDS)
+  GridPartial* out;                       // one record per frame: the anchor's best candidate (full-table flat index, (a << 16) | b)
+};
+
+size_t locate_lds_bytes(uint32_t sample_cap, int n_ty, int n_tz, int n_ty2, int n_tz2);
+void launch_locate(const Ctx& c, hipStream_t s, const LocatePlan& lp);
+constexpr int kLocateMinFrames = 128;   // smaller batches keep the three launches: a frame's 17 workgroups are what fills the chip there
+
 // ---------------------------------------------------------------- launchers (one per stage TU)
 void launch_roi_crop(const Ctx& c, hipStream_t s, hipEvent_t after_count = nullptr);   // after_count: recorded between the count pass and the scatter
 void launch_cluster(const Ctx& c, hipStream_t s);

@@ -997,6 +997,348 @@ void launch_group_prepass(const Ctx& c, hipStream_t s, uint32_t* grp_alive, uint
     hipLaunchKernelGGL((k6_group_prepass<kGridThreads>), grid, dim3(kGridThreads), lds, s, c, grp_alive, grp_mask);
 }
 
+// k6_locate (round 5): seed + refinement + anchor in ONE launch, one workgroup per frame.  The three launches it replaces only
+// have to say WHERE the minimum is and publish the frame's bound; as 17 small workgroups per frame in three dependent launches
+// they were 277 of the K6 stage's 733 us with a batch alone on the chip, at 16-28 % issue utilisation: each stages
+// its points and tables again, reads the previous launch's argmin from global memory, and the anchor's workgroups run one
+// wavefront of four.  Here a frame's 8 wavefronts
+//   1. stage the SAMPLE of the walk (an eighth of the labelled points, a proportional prefix of each class of the walk layout)
+//      once, rotated by the five seed thetas; 5 x (8 x 8 decimated translations) = 20 tiles, one per wavefront at a time,
+//      pruned against a bound word in LDS; argmin in LDS;
+//   2. rotate the sample by the (2 r + 1) thetas around the seed's and score their 8 x 8 windows of full-table translations
+//      (36 tiles); argmin in LDS;
+//   3. score the 4 x 4 tile around that argmin at theta - 1, theta, theta + 1 on EVERY labelled point (rotated on the fly from
+//      the walk layout in L2), two wavefronts per theta on alternate blocks of the walk, and publish the best complete cost as
+//      the frame's bound and its candidate as the full pass's starting tile.
+// The same candidates on the same points as the three launches; the sums are grouped differently (the anchor's two half-walks
+// are added at the end), which the full pass cannot see: the bound only has to be the cost of SOME complete candidate, and a
+// candidate is cut, or listed as a near tie, with 2e-5 to spare -- 20 x the rounding of an fp32 sum of a thousand terms.
+// Batches of fewer than kLocateMinFrames frames keep the three launches: there a frame's 17 workgroups are what fills the chip.
+constexpr int kLocateThreads = 512;       // measured (k frames/s, one MI355X): 256: 1056, 512: 1089, 1024: 1011-1033
+constexpr int kAnchorThetas = 3;          // thetas around the refinement's argmin the anchor scores (1: locate 0.26 -> 0.21 ms alone, full pass 0.36 -> 0.40: a wash)
+constexpr int kAnchorParts = (kLocateThreads / 64) / kAnchorThetas;  // wavefronts sharing a theta's walk
+constexpr int kLocateWaves = kLocateThreads / ILCC_WAVE;
+constexpr int kLocateThetasMax = 16;      // rotations of the sample kept in LDS at a time (seed: 5, refinement: 2 r + 1 = 9)
+__global__ __launch_bounds__(kLocateThreads) void k6_locate(Ctx c, LocatePlan lp) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  __shared__ Best s_best[kLocateWaves];
+  __shared__ uint32_t s_ab[kLocateWaves];
+  __shared__ uint32_t s_bound;              // float bits: best complete SAMPLE cost so far (seed and refinement share the sample)
+  __shared__ uint32_t s_pick[4];            // argmin of a phase: flat, (a << 16) | b
+  __shared__ uint32_t s_iters[kLocateWaves], s_iters_in[kLocateWaves];
+  __shared__ float s_part[kAnchorThetas][kAnchorParts][16][2];     // anchor: (theta, part of the walk, candidate, phase) partial costs / 2
+  const uint32_t f = blockIdx.x;
+  GridPartial* out = lp.out + f;
+  const int lane = lane_id();
+  const int wid = __builtin_amdgcn_readfirstlane(wave_id());
+  const uint32_t Mfull = c.n_lab[f];
+  if (c.res[f].status != ILCC_OK) {
+    if (threadIdx.x == 0) *out = GridPartial{__builtin_inff(), 0xFFFFFFFFu, 0xFFFFFFFFu, 0u};
+    return;
+  }
+  const uint64_t beg = c.off[f];
+  const bool walk_layout = Mfull <= (uint32_t)kGridLdsPointsMax;   // k5w_walk_order has laid the frame out; else: the points in golden-ratio order through L2
+  const float2* __restrict__ wyz = walk_layout ? c.walk_yz + beg : c.yz + beg;
+  const uint8_t* __restrict__ wlab = walk_layout ? c.walk_lab + beg : c.lab + beg;
+  const uint32_t S = (!walk_layout && Mfull) ? c.walk_stride[f] : 1u;
+  const uint32_t Mi_all = walk_layout ? c.walk_mi[f] : 0u, n_rim_all = walk_layout ? c.walk_nrim[f] : 0u;
+  const uint32_t Ms = min(min(Mfull, max(lp.sample_min, Mfull >> kSeedShift)), lp.sample_cap);
+  uint32_t n_in = Mi_all, n_rm = n_rim_all;
+  if (Ms < Mfull) {
+    n_in = (uint32_t)(((uint64_t)Mi_all * Ms) / Mfull);
+    n_rm = (uint32_t)(((uint64_t)n_rim_all * Ms) / Mfull);
+  }
+  const int n_ty = c.p.n_ty, n_tz = c.p.n_tz, n_th = c.p.n_th;
+  // dynamic LDS: the raw sample, its rotations, the (ty, tz) tables (full, then the seed's)
+  float2* s_raw = reinterpret_cast<float2*>(smem);
+  float* s_hw = reinterpret_cast<float*>(s_raw + lp.sample_cap);
+  float2* s_rot = reinterpret_cast<float2*>(s_hw + lp.sample_cap);                  // [kLocateThetasMax][sample_cap]
+  float* s_ay = reinterpret_cast<float*>(s_rot + (size_t)kLocateThetasMax * lp.sample_cap);
+  float* s_az = s_ay + n_ty;
+  float* s_ay2 = s_az + n_tz;
+  float* s_az2 = s_ay2 + lp.n_ty2;
+  for (uint32_t sl = threadIdx.x; sl < Ms; sl += kLocateThreads) {
+    uint32_t src = sl < n_in ? sl : sl < n_in + n_rm ? Mi_all + (sl - n_in) : Mi_all + n_rim_all + (sl - n_in - n_rm);
+    src = min(src, Mfull - 1u);
+    if (!walk_layout) src = (uint32_t)(((uint64_t)sl * S) % Mfull);
+    s_raw[sl] = wyz[src];
+    s_hw[sl] = wlab[src] ? 0.5f : 0.f;
+  }
+  for (int i = threadIdx.x; i < n_ty; i += kLocateThreads) s_ay[i] = c.ay[i];
+  for (int i = threadIdx.x; i < n_tz; i += kLocateThreads) s_az[i] = c.az[i];
+  for (int i = threadIdx.x; i < lp.n_ty2; i += kLocateThreads) s_ay2[i] = lp.ay2[i];
+  for (int i = threadIdx.x; i < lp.n_tz2; i += kLocateThreads) s_az2[i] = lp.az2[i];
+  if (threadIdx.x == 0) s_bound = 0x7f800000u;
+  const float Wh = 0.5f * (float)c.p.board_w, Hh = 0.5f * (float)c.p.board_h, delta2 = (float)c.p.huber_delta;
+  const int my_s = lane & (kSlices - 1), my_c = lane >> 2, my_a = my_c >> 2, my_b = my_c & 3;
+  uint32_t pts_done = 0, pts_in = 0;
+
+  // the sample rotated by n_rot thetas (theta index of rotation r: th_of(r))
+  auto rotate_sample = [&](int n_rot, auto th_of, const float* cth_tab, const float* sth_tab) {
+    for (uint32_t item = threadIdx.x; item < (uint32_t)n_rot * Ms; item += kLocateThreads) {
+      const uint32_t r = item / Ms, sl = item - r * Ms;
+      const int k = th_of((int)r);
+      const float cth = cth_tab[k], sth = sth_tab[k];
+      const float2 v = s_raw[sl];
+      s_rot[(size_t)r * lp.sample_cap + sl] = make_float2(fmaf(-sth, v.y, cth * v.x), fmaf(cth, v.y, sth * v.x));   // = k6_grid_cost's staging
+    }
+  };
+  // one 4 x 4 tile on the rotated sample `rot`, quad-sliced like k6_grid_cost (border class first, a bound test every 8 walk
+  // positions against the sample bound); false: every candidate provably loses
+  auto sample_tile = [&](const float2* rot, float ay, float az, float& c0, float& c1) -> bool {
+    float A0 = 0.f, A1 = 0.f;
+    uint32_t since = 0;
+    float lim2 = 0.5f * (1.f + kTieEps) * __uint_as_float(s_bound);
+    uint32_t pos = 0;
+    for (uint32_t at0 = n_in; at0 < Ms; at0 += kSlices) {   // (at0 is wave-uniform: every lane makes the same trips)
+      const uint32_t at = at0 + (uint32_t)my_s;
+      if (at < Ms) {
+        const float2 v = rot[at];
+        accumulate<true>(PointTerms{v.x, v.y, s_hw[at]}, ay, az, Wh, Hh, delta2, A0, A1);
+      }
+      pos += kSlices;
+      since += kSlices;
+      if (since >= 8u) {
+        since = 0;
+        const float part = fminf(quad_sum(A0), quad_sum(A1));
+        if (__ballot(!(part > lim2)) == 0ull) {
+          pts_done += pos;
+          return false;
+        }
+        lim2 = 0.5f * (1.f + kTieEps) * __uint_as_float(s_bound);
+      }
+    }
+    for (uint32_t at0 = 0; at0 < n_in; at0 += kSlices) {
+      const uint32_t at = at0 + (uint32_t)my_s;
+      if (at < n_in) {
+        const float2 v = rot[at];
+        accumulate_interior(PointTerms{v.x, v.y, s_hw[at]}, ay, az, delta2, A0, A1);
+      }
+      pos += kSlices;
+      since += kSlices;
+      if (since >= 8u) {
+        since = 0;
+        const float part = fminf(quad_sum(A0), quad_sum(A1));
+        if (__ballot(!(part > lim2)) == 0ull) {
+          pts_done += pos;
+          pts_in += at0 + kSlices;
+          return false;
+        }
+        lim2 = 0.5f * (1.f + kTieEps) * __uint_as_float(s_bound);
+      }
+    }
+    pts_done += pos;
+    pts_in += n_in;
+    c0 = 2.f * quad_sum(A0);
+    c1 = 2.f * quad_sum(A1);
+    return true;
+  };
+  // a phase's argmin: every wavefront's best -> LDS -> s_pick (flat, ab)
+  auto reduce_best = [&](Best best, uint32_t ab) {
+#pragma unroll
+    for (int o = ILCC_WAVE / 2; o > 0; o >>= 1) {
+      Best t;
+      t.cost = __shfl_down(best.cost, o, ILCC_WAVE);
+      t.d2 = __shfl_down(best.d2, o, ILCC_WAVE);
+      t.flat = __shfl_down(best.flat, o, ILCC_WAVE);
+      const uint32_t tab = __shfl_down(ab, o, ILCC_WAVE);
+      if (better(t.cost, t.d2, t.flat, best)) {
+        best = t;
+        ab = tab;
+      }
+    }
+    if (lane == 0) {
+      s_best[wid] = best;
+      s_ab[wid] = ab;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      Best b = s_best[0];
+      uint32_t bab = s_ab[0];
+      for (int w = 1; w < kLocateWaves; ++w)
+        if (better(s_best[w].cost, s_best[w].d2, s_best[w].flat, b)) {
+          b = s_best[w];
+          bab = s_ab[w];
+        }
+      s_pick[0] = b.flat;
+      s_pick[1] = bab;
+      s_pick[2] = __float_as_uint(b.cost);
+      s_pick[3] = b.d2;
+    }
+    __syncthreads();
+  };
+  __syncthreads();
+
+  // ---- 1. seed: n_th2 thetas x (n_ty2 x n_tz2 decimated translations) on the sample
+  const int n_th2 = min(lp.n_th2, kLocateThetasMax);
+  rotate_sample(n_th2, [&](int r) { return r; }, lp.cth2, lp.sth2);
+  __syncthreads();
+  {
+    const int nta = (lp.n_ty2 + kTile - 1) / kTile, ntb = (lp.n_tz2 + kTile - 1) / kTile, per = nta * ntb, n_tiles = n_th2 * per;
+    Best best{__builtin_inff(), 0xFFFFFFFFu, 0xFFFFFFFFu};
+    uint32_t best_ab = 0;
+    for (int t = wid; t < n_tiles; t += kLocateWaves) {
+      const int k2 = t / per, q = t - k2 * per, ta = q / ntb, tb = q - ta * ntb;
+      const int ia = ta * kTile + my_a, ib = tb * kTile + my_b;
+      const bool owner = ia < lp.n_ty2 && ib < lp.n_tz2;
+      float c0, c1;
+      if (!sample_tile(s_rot + (size_t)k2 * lp.sample_cap, s_ay2[min(ia, lp.n_ty2 - 1)], s_az2[min(ib, lp.n_tz2 - 1)], c0, c1)) continue;
+      if (owner) {
+        const uint32_t cell = ((uint32_t)k2 * (uint32_t)lp.n_ty2 + (uint32_t)ia) * (uint32_t)lp.n_tz2 + (uint32_t)ib;
+        const uint32_t d2 = (uint32_t)((k2 - lp.c_th2) * (k2 - lp.c_th2) + (ia - lp.c_ty2) * (ia - lp.c_ty2) + (ib - lp.c_tz2) * (ib - lp.c_tz2));
+        const uint32_t ab = ((uint32_t)ia << 16) | (uint32_t)ib;
+        if (better(c0, d2, 2u * cell, best)) { best = Best{c0, d2, 2u * cell}; best_ab = ab; }
+        if (better(c1, d2, 2u * cell + 1u, best)) { best = Best{c1, d2, 2u * cell + 1u}; best_ab = ab; }
+      }
+      float wb = owner ? fminf(c0, c1) : __builtin_inff();
+#pragma unroll
+      for (int o = ILCC_WAVE / 2; o > 0; o >>= 1) wb = fminf(wb, __shfl_xor(wb, o, ILCC_WAVE));
+      if (lane == 0) atomicMin(&s_bound, __float_as_uint(wb));   // costs are >= 0: uint order == float order
+    }
+    reduce_best(best, best_ab);
+  }
+  if (s_pick[0] == 0xFFFFFFFFu) {   // (no candidate at all: an empty frame)
+    if (threadIdx.x == 0) *out = GridPartial{__builtin_inff(), 0xFFFFFFFFu, 0xFFFFFFFFu, 0u};
+    return;
+  }
+  // ---- 2. refinement: theta within +- refine_radius steps of the seed's, the 8 x 8 window of full-table translations around its argmin
+  const int k2s = (int)((s_pick[0] >> 1) / (uint32_t)(lp.n_ty2 * lp.n_tz2));
+  const int sa = min((int)(s_pick[1] >> 16) * lp.stride_t, n_ty - 1), sbb = min((int)(s_pick[1] & 0xFFFFu) * lp.stride_t, n_tz - 1);
+  const int n_ref = min(2 * lp.refine_radius + 1, kLocateThetasMax);
+  const int k_ref0 = lp.off_th + k2s * lp.stride_th - lp.refine_radius;
+  rotate_sample(n_ref, [&](int r) { return min(max(k_ref0 + r, 0), n_th - 1); }, c.cth, c.sth);
+  __syncthreads();
+  {
+    const int a_org = min(max(sa - kTile, 0), max(n_ty - 2 * kTile, 0)), b_org = min(max(sbb - kTile, 0), max(n_tz - 2 * kTile, 0));
+    const int nta = min(2, (n_ty + kTile - 1) / kTile), ntb = min(2, (n_tz + kTile - 1) / kTile), per = nta * ntb, n_tiles = n_ref * per;
+    Best best{__builtin_inff(), 0xFFFFFFFFu, 0xFFFFFFFFu};
+    uint32_t best_ab = 0;
+    for (int t = wid; t < n_tiles; t += kLocateWaves) {
+      const int r = t / per, q = t - r * per, ta = q / ntb, tb = q - ta * ntb;
+      const int k = min(max(k_ref0 + r, 0), n_th - 1);
+      const int ia = a_org + ta * kTile + my_a, ib = b_org + tb * kTile + my_b;
+      const bool owner = ia < n_ty && ib < n_tz;
+      float c0, c1;
+      if (!sample_tile(s_rot + (size_t)r * lp.sample_cap, s_ay[min(ia, n_ty - 1)], s_az[min(ib, n_tz - 1)], c0, c1)) continue;
+      if (owner) {
+        const uint32_t cell = ((uint32_t)k * (uint32_t)n_ty + (uint32_t)ia) * (uint32_t)n_tz + (uint32_t)ib;
+        const uint32_t d2 = (uint32_t)((k - c.c_th) * (k - c.c_th) + (ia - c.c_ty) * (ia - c.c_ty) + (ib - c.c_tz) * (ib - c.c_tz));
+        const uint32_t ab = ((uint32_t)ia << 16) | (uint32_t)ib;
+        if (better(c0, d2, 2u * cell, best)) { best = Best{c0, d2, 2u * cell}; best_ab = ab; }
+        if (better(c1, d2, 2u * cell + 1u, best)) { best = Best{c1, d2, 2u * cell + 1u}; best_ab = ab; }
+      }
+      float wb = owner ? fminf(c0, c1) : __builtin_inff();
+#pragma unroll
+      for (int o = ILCC_WAVE / 2; o > 0; o >>= 1) wb = fminf(wb, __shfl_xor(wb, o, ILCC_WAVE));
+      if (lane == 0) atomicMin(&s_bound, __float_as_uint(wb));
+    }
+    reduce_best(best, best_ab);
+  }
+  // ---- 3. anchor: the 4 x 4 tile around the refinement's argmin at theta - 1, theta, theta + 1 on EVERY labelled point
+  {
+    // (the refinement evaluates every candidate of the seed's argmin window again, so it always has a pick)
+    const int kr = (int)((s_pick[0] >> 1) / (uint32_t)(n_ty * n_tz));
+    const int ra = min((int)(s_pick[1] >> 16), n_ty - 1), rb = min((int)(s_pick[1] & 0xFFFFu), n_tz - 1);
+    const int a_org = min(max(ra - 1, 0), max(n_ty - kTile, 0)), b_org = min(max(rb - 1, 0), max(n_tz - kTile, 0));
+    const int ia = a_org + my_a, ib = b_org + my_b;
+    const bool owner = ia < n_ty && ib < n_tz;
+    if (wid < kAnchorThetas * kAnchorParts) {
+      const int t = wid % kAnchorThetas, half = wid / kAnchorThetas;
+      const int k = min(max(kr + t - kAnchorThetas / 2, 0), n_th - 1);
+      const float cth = c.cth[k], sth = c.sth[k];
+      const float ay = s_ay[min(ia, n_ty - 1)], az = s_az[min(ib, n_tz - 1)];
+      float A0 = 0.f, A1 = 0.f;
+      uint32_t idx = 0, pos = 0, pin = 0;
+      // blocks of four walk positions go round the theta's wavefronts
+      for (uint32_t at0 = (uint32_t)half * kSlices; at0 < Mfull; at0 += (uint32_t)kAnchorParts * kSlices) {
+        const uint32_t at = at0 + (uint32_t)my_s;
+        if (at < Mfull) {
+          idx = walk_layout ? at : (uint32_t)(((uint64_t)at * S) % Mfull);
+          const float2 v = wyz[idx];
+          const PointTerms pt{fmaf(-sth, v.y, cth * v.x), fmaf(cth, v.y, sth * v.x), wlab[idx] ? 0.5f : 0.f};
+          if (at < Mi_all)
+            accumulate_interior(pt, ay, az, delta2, A0, A1);
+          else
+            accumulate<true>(pt, ay, az, Wh, Hh, delta2, A0, A1);
+        }
+        pos += kSlices;
+        pin += at0 < Mi_all ? (uint32_t)kSlices : 0u;
+      }
+      pts_done += pos;
+      pts_in += pin;
+      const float t0s = quad_sum(A0), t1s = quad_sum(A1);
+      if (my_s == 0) {
+        s_part[t][half][my_c][0] = t0s;
+        s_part[t][half][my_c][1] = t1s;
+      }
+    }
+    __syncthreads();
+    if (wid == 0) {
+      Best best{__builtin_inff(), 0xFFFFFFFFu, 0xFFFFFFFFu};
+      uint32_t best_ab = 0;
+      if (lane < 16 * kAnchorThetas) {
+        const int t = lane >> 4, cand = lane & 15, ca = cand >> 2, cb = cand & 3;
+        const int k = min(max(kr + t - kAnchorThetas / 2, 0), n_th - 1), ja = a_org + ca, jb = b_org + cb;
+        if (ja < n_ty && jb < n_tz) {
+          float h0 = 0.f, h1 = 0.f;
+#pragma unroll
+          for (int q = 0; q < kAnchorParts; ++q) {
+            h0 += s_part[t][q][cand][0];
+            h1 += s_part[t][q][cand][1];
+          }
+          const float c0 = 2.f * h0, c1 = 2.f * h1;
+          const uint32_t cell = ((uint32_t)k * (uint32_t)n_ty + (uint32_t)ja) * (uint32_t)n_tz + (uint32_t)jb;
+          const uint32_t d2 = (uint32_t)((k - c.c_th) * (k - c.c_th) + (ja - c.c_ty) * (ja - c.c_ty) + (jb - c.c_tz) * (jb - c.c_tz));
+          best = Best{c0, d2, 2u * cell};
+          if (better(c1, d2, 2u * cell + 1u, best)) best = Best{c1, d2, 2u * cell + 1u};
+          best_ab = ((uint32_t)ja << 16) | (uint32_t)jb;
+        }
+      }
+#pragma unroll
+      for (int o = ILCC_WAVE / 2; o > 0; o >>= 1) {
+        Best tt;
+        tt.cost = __shfl_down(best.cost, o, ILCC_WAVE);
+        tt.d2 = __shfl_down(best.d2, o, ILCC_WAVE);
+        tt.flat = __shfl_down(best.flat, o, ILCC_WAVE);
+        const uint32_t tab = __shfl_down(best_ab, o, ILCC_WAVE);
+        if (better(tt.cost, tt.d2, tt.flat, best)) {
+          best = tt;
+          best_ab = tab;
+        }
+      }
+      if (lane == 0) {
+        *out = GridPartial{best.cost, best.d2, best.flat, best_ab};
+        if (best.flat != 0xFFFFFFFFu) atomicMin(c.grid_bound + f, __float_as_uint(best.cost));   // the frame's real bound: a complete candidate on every point
+      }
+    }
+    (void)owner;
+  }
+  if (lane == 0) {
+    s_iters[wid] = pts_done;
+    s_iters_in[wid] = pts_in;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t it_sum = 0, in_sum = 0;
+    for (int w = 0; w < kLocateWaves; ++w) {
+      it_sum += s_iters[w];
+      in_sum += s_iters_in[w];
+    }
+    atomicAdd(c.grid_iters + (f & (kIterSlots - 1)), (unsigned long long)it_sum);
+    atomicAdd(c.grid_iters + kIterSlots + (f & (kIterSlots - 1)), (unsigned long long)in_sum);
+  }
+}
+
+size_t locate_lds_bytes(uint32_t sample_cap, int n_ty, int n_tz, int n_ty2, int n_tz2) {
+  return (sizeof(float2) + sizeof(float)) * (size_t)sample_cap + sizeof(float2) * (size_t)kLocateThetasMax * sample_cap +
+         sizeof(float) * (size_t)(n_ty + n_tz + n_ty2 + n_tz2);
+}
+
+void launch_locate(const Ctx& c, hipStream_t s, const LocatePlan& lp) {
+  const size_t lds = locate_lds_bytes(lp.sample_cap, c.p.n_ty, c.p.n_tz, lp.n_ty2, lp.n_tz2);
+  hipLaunchKernelGGL(k6_locate, dim3(c.n_frames), dim3(kLocateThreads), lds, s, c, lp);
+}
+
 // K5w walk order: the frame's labelled points in the layout k6_grid_cost stages -- [interior | rim | other border], each part
 // in golden-ratio walk order -- written ONCE per frame (round 3 until here: every one of a frame's ~80 K6 workgroups
 // classified and partitioned the points again, 20 % of the full pass's VALU instructions).
@@ -1184,7 +1526,7 @@ hipError_t set_kernel_attributes_k6() {
                        (const void*)k6_grid_cost<false, true, false, kGridThreads>, (const void*)k6_grid_cost<false, false, false, kGridThreads>,
                        (const void*)k6_grid_cost<true, false, true, kGridThreads>,  (const void*)k6_grid_cost<false, false, true, kGridThreads>,
                        (const void*)k6_grid_cost<true, false, true, kGridThreadsLarge>,
-                       (const void*)k6_group_prepass<kGridThreads>, (const void*)k6_group_prepass<kGridThreadsLarge>};
+                       (const void*)k6_group_prepass<kGridThreads>, (const void*)k6_group_prepass<kGridThreadsLarge>, (const void*)k6_locate};
   const int cap = (int)((sizeof(float2) + sizeof(float)) * (size_t)kGridLdsPointsMax + sizeof(float) * (size_t)kGridTableMax);
   for (const void* fn : fns) {
     const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
