@@ -290,7 +290,8 @@ def main():
     est.set_result_mode(N.RESULTS_COMPACT)
     # ilcc_reserve: the sensor is known, so the handle's on-chip capacities are set up front and the warm-up batches take the
     # same kernels as the timed ones (a fresh handle grows them after its first batch: INTEGRATION.md, "Sizing")
-    est.reserve(6000, 20000) if args.config == 5 else est.reserve(2048, 2560)
+    # (config 5: the bench's frames hold up to 6 170 labelled points)
+    est.reserve(6400, 20000) if args.config == 5 else est.reserve(2048, 2560)
     n_cand = params.n_th * params.n_ty * params.n_tz * 2
     depth = max(1, min(args.in_flight, int(os.environ.get("ILCC_BENCH_MAX_DEPTH", "4"))))
 
@@ -533,6 +534,7 @@ def main():
                             "median_corner_error_mm_accepted": 1e3 * float(np.median(err_acc)) if len(err_acc) else None,
                             "frames_ok_but_low_coverage": int(sum(1 for f in ok if low[f]))},
             "labelled_points_per_frame": m_lab,
+            "labelled_points_max": int(max([res[f].n_black + res[f].n_white for f in ok + amb] or [0])),
             "stage_ms_last_batch_overlapped": {k: round(getattr(tm, k), 4) for k in
                                                ("roi_crop", "cluster", "ransac_plane", "plane_frame_hist", "grid_cost",
                                                 "refine_corners", "total")},

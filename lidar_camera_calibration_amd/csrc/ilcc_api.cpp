@@ -456,6 +456,7 @@ Ctx make_ctx(ilcc_handle* h, Slot& sl, const float4* d_xyzi, const float* d_clic
   c.seed_stride_th = 1;
   c.seed_off_th = 0;
   c.refine_radius_th = 0;
+  c.refine_step_th = 1;
   c.refine_window = 0;
   c.cth = h->d_cth;
   c.sth = h->d_sth;
@@ -623,8 +624,9 @@ int32_t enqueue_grid_search(ilcc_handle* h, Slot& sl, int si, const Ctx& c, hipS
     refine.seed_off_th = h->seed_stride_th / 2;
     // refinement pass: all candidates around the seed argmin (theta +- a third of a seed stride, 8 x 8 translations)
     refine.refine_window = 1;
-    refine.refine_radius_th = std::max(1, h->seed_stride_th / ILCC_REFINE_RADIUS_DIV);
-    refine.grid_blocks = std::min((uint32_t)(2 * refine.refine_radius_th + 1), h->max_theta);
+    refine.refine_radius_th = (std::max(1, h->seed_stride_th / ILCC_REFINE_RADIUS_DIV) / kRefineThetaStride) * kRefineThetaStride;
+    refine.refine_step_th = kRefineThetaStride;
+    refine.grid_blocks = std::min((uint32_t)(2 * (refine.refine_radius_th / kRefineThetaStride) + 1), h->max_theta);
     refine.partial = sl.d_partial3;
     refine.walk_limit = sub;
     if (sub) refine.grid_bound = sl.d_bound_sub;

@@ -177,6 +177,7 @@ struct Ctx {
   // the seed argmin at theta index (seed theta) + j - refine_radius_th; 0 = this launch is not a refinement
   int32_t refine_window;     // 1: this launch evaluates only the 8 x 8 (ty, tz) window around the seed argmin, theta within +-refine_radius_th
   int32_t refine_radius_th;
+  int32_t refine_step_th;    // theta step between the workgroups of a refinement / anchor launch (kRefineThetaStride / 1)
   // candidate tables (device)
   const float* cth;          // cos(theta_k)/g
   const float* sth;          // sin(theta_k)/g
@@ -293,6 +294,7 @@ struct LocatePlan {
 
 size_t locate_lds_bytes(uint32_t sample_cap, int n_ty, int n_tz, int n_ty2, int n_tz2);
 void launch_locate(const Ctx& c, hipStream_t s, const LocatePlan& lp);
+constexpr int kRefineThetaStride = 2;  // the refinement scores every other theta of its range (the anchor covers the ones in between)
 constexpr int kLocateMinFrames = 128;   // smaller batches keep the three launches: a frame's 17 workgroups are what fills the chip there
 
 // ---------------------------------------------------------------- launchers (one per stage TU)
