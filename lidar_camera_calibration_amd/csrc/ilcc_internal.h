@@ -295,7 +295,7 @@ struct LocatePlan {
 size_t locate_lds_bytes(uint32_t sample_cap, int n_ty, int n_tz, int n_ty2, int n_tz2);
 void launch_locate(const Ctx& c, hipStream_t s, const LocatePlan& lp);
 constexpr int kRefineThetaStride = 2;  // the refinement scores every other theta of its range (the anchor covers the ones in between)
-constexpr int kLocateMinFrames = 128;   // smaller batches keep the three launches: a frame's 17 workgroups are what fills the chip there
+constexpr int kLocateMinFrames = 512;   // smaller batches keep the three launches: a frame's workgroups per theta are what fills the chip there (128 frames alone: 0.27 ms in three launches, 0.30 ms in one)
 
 // ---------------------------------------------------------------- launchers (one per stage TU)
 void launch_roi_crop(const Ctx& c, hipStream_t s, hipEvent_t after_count = nullptr);   // after_count: recorded between the count pass and the scatter

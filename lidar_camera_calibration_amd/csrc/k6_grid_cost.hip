@@ -1355,7 +1355,10 @@ void launch_locate(const Ctx& c, hipStream_t s, const LocatePlan& lp) {
 //   rim:      border-class and within kRimMilli thousandths of a square of the outline at the grid's centre candidate:
 //             walked first, they are the points that leave the board when the translation is wrong (ordering only).
 constexpr int kRimMilli = 300;   // rim = within 0.3 square of the outline
-constexpr int kWalkThreads = 1024;
+// 256 threads: in the pipeline the kernel runs beside another batch's full pass, and a 1024-thread workgroup needs 16 free wave
+// slots on ONE CU while that pass keeps refilling them -- its span on the batch's stream was 0.65 ms against 0.04 ms alone, the
+// largest item of a batch's front end (tools/dev_depth_timeline.py).  1024 -> 256 threads: bench 1105 -> 1157 k frames/s
+constexpr int kWalkThreads = 256;
 __global__ __launch_bounds__(kWalkThreads) void k5w_walk_order(Ctx c) {
   __shared__ uint8_t s_cls[kGridLdsPointsMax];
   __shared__ uint32_t s_in[kWalkThreads / ILCC_WAVE], s_rim[kWalkThreads / ILCC_WAVE], s_oth[kWalkThreads / ILCC_WAVE];
