@@ -193,8 +193,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", type=int, default=2, choices=(2, 5),
                     help="2: BASELINE configs[1] frames (the headline); 5: configs[4], the dense-cloud fine-grid run")
-    ap.add_argument("--frames-per-batch", type=int, default=0, help="default 1024 (config 2) / 64 (config 5)")
-    ap.add_argument("--batches-per-step", type=int, default=0, help="distinct batches per step and GPU: default 1 (config 2) / 2 (config 5)")
+    ap.add_argument("--frames-per-batch", type=int, default=0, help="default 1024 (config 2) / 128 (config 5)")
+    ap.add_argument("--batches-per-step", type=int, default=0, help="distinct batches per step and GPU: default 1")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline time budget (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the H2D-inclusive / reference-mode legs (profiling runs)")
@@ -219,8 +219,10 @@ def main():
     # the grid search's share of the step; measured then: 256 x 4: 738 k, 384 x 2: 819 k, 512 x 2: 853 k, 768 x 2: 922 k, 1024 x 1: 923-928 k
     # frames/s resident (H2D-inclusive: 117.6-119.7 k at 512 x 2, 115.9 k at 1024 x 1: the link either way).  Config 5: 32 x 4: 46.4 k,
     # 64 x 2: 59.0 k (H2D-inclusive 23.8 k), 128 x 1: 61.9 k (22.6 k): 64 x 2 stays, its contract metric is the one still short of the link
-    F = args.frames_per_batch or (1024 if args.config == 2 else 64)
-    B = max(1, args.batches_per_step or (1 if args.config == 2 else 2))
+    # Round 5 (k6_anchor's second round, K7r's silent points): config 5 64 x 2: 70.6 k resident / 24.4 k H2D-inclusive, 128 x 1: 78.6 k / 23.4 k
+    # (link bound 26.9 k either way): 128 x 1 is the default now
+    F = args.frames_per_batch or (1024 if args.config == 2 else 128)
+    B = max(1, args.batches_per_step or 1)
     FS = F * B                                        # frames per step and GPU
 
     # synthetic inputs first (forked workers; nothing has touched the HIP runtime yet).  Weak scaling: every rank

@@ -653,8 +653,26 @@ int32_t enqueue_grid_search(ilcc_handle* h, Slot& sl, int si, const Ctx& c, hipS
       anchor.refine_radius_th = ILCC_ANCHOR_RADIUS;
       anchor.grid_blocks = 2 * ILCC_ANCHOR_RADIUS + 1;
       anchor.partial = sl.d_partial4;
-      launch_grid_cost(anchor, s, /*use_oob=*/1, nullptr, true);
-      full.seed_partial = sl.d_partial4;
+#ifndef ILCC_ANCHOR_ROUNDS
+#define ILCC_ANCHOR_ROUNDS 2
+#endif
+      // anchor rounds (k6_anchor): 3 thetas x one tile on ALL points; every further round re-centres the tile on the previous
+      // round's argmin -- a greedy descent on complete costs towards the grid minimum, for a tighter bound in front of the full pass
+      GridPartial* ping[2] = {sl.d_partial4, sl.d_partial2};
+      if (ILCC_ANCHOR_WINDOW == 2) {
+        launch_anchor(anchor, s);
+        for (int round = 1; round < ILCC_ANCHOR_ROUNDS; ++round) {
+          Ctx again = anchor;
+          again.seed_partial = ping[(round - 1) & 1];
+          again.seed_blocks = 2 * ILCC_ANCHOR_RADIUS + 1;
+          again.partial = ping[round & 1];
+          launch_anchor(again, s);
+        }
+        full.seed_partial = ping[(ILCC_ANCHOR_ROUNDS - 1) & 1];
+      } else {
+        launch_grid_cost(anchor, s, /*use_oob=*/1, nullptr, true);
+        full.seed_partial = sl.d_partial4;
+      }
       full.seed_blocks = 2 * ILCC_ANCHOR_RADIUS + 1;
       full.seed_n_ty = h->p.n_ty;
       full.seed_n_tz = h->p.n_tz;

@@ -294,6 +294,7 @@ struct LocatePlan {
 
 size_t locate_lds_bytes(uint32_t sample_cap, int n_ty, int n_tz, int n_ty2, int n_tz2);
 void launch_locate(const Ctx& c, hipStream_t s, const LocatePlan& lp);
+void launch_anchor(const Ctx& c, hipStream_t s);   // one anchor round of the separate locate launches (c.seed_partial -> c.partial, c.grid_blocks thetas)
 constexpr int kRefineThetaStride = 2;  // the refinement scores every other theta of its range (the anchor covers the ones in between)
 constexpr int kLocateMinFrames = 512;   // smaller batches keep the three launches: a frame's workgroups per theta are what fills the chip there (128 frames alone: 0.27 ms in three launches, 0.30 ms in one)
 

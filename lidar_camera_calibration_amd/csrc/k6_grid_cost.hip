@@ -1334,6 +1334,124 @@ __global__ __launch_bounds__(kLocateThreads) void k6_locate(Ctx c, LocatePlan lp
   }
 }
 
+// k6_anchor (round 5): one ANCHOR round for batches that keep the separate locate launches (fewer than kLocateMinFrames frames:
+// BASELINE config 5's 64-frame batches).  Workgroup = (theta - 1 | theta | theta + 1 around the previous launch's argmin, frame);
+// its 8 wavefronts split the walk over ALL labelled points of ONE 4 x 4 tile of translations around that argmin (blocks of
+// four walk positions go round the wavefronts, partial sums meet in LDS), where the anchor instance of k6_grid_cost walked the
+// tile with one wavefront of eight: 0.16 ms per round on config 5, latency of a serial walk over 4 400 points.  At 0.03 ms a
+// round can be repeated: every round re-centres the tile on the previous round's argmin -- a greedy descent on complete costs
+// towards the grid minimum.  On a fine grid (config 5: steps of 1.6 mm and 0.25 degrees) the refinement's argmin, found on an
+// eighth of the points, is several steps from it; a second round makes the bound 20 % tighter in executed work (225 -> 180 M
+// point-candidate evaluations per 64 frames in the full pass, 224 -> 189 M in the pre-passes).
+constexpr int kAnchorThreads = 512;
+constexpr int kAnchorWaves = kAnchorThreads / ILCC_WAVE;
+__global__ __launch_bounds__(kAnchorThreads) void k6_anchor(Ctx c) {
+  __shared__ float s_part[kAnchorWaves][16][2];
+  __shared__ uint32_t s_iters[kAnchorWaves], s_iters_in[kAnchorWaves];
+  const uint32_t f = blockIdx.y, kblk = blockIdx.x;
+  GridPartial* out = &c.partial[(uint64_t)f * c.grid_blocks + kblk];
+  const int lane = lane_id();
+  const int wid = __builtin_amdgcn_readfirstlane(wave_id());
+  uint32_t k2u = 0, ab = 0;
+  Best sb{__builtin_inff(), 0xFFFFFFFFu, 0xFFFFFFFFu};
+  if (c.res[f].status == ILCC_OK) sb = seed_argmin(c, f, k2u, ab);
+  if (sb.flat == 0xFFFFFFFFu) {
+    if (threadIdx.x == 0) *out = GridPartial{__builtin_inff(), 0xFFFFFFFFu, 0xFFFFFFFFu, 0u};
+    return;
+  }
+  const int n_ty = c.p.n_ty, n_tz = c.p.n_tz, n_th = c.p.n_th;
+  const int kr = (int)((sb.flat >> 1) / (uint32_t)(n_ty * n_tz));   // (the records come from launches over the full tables)
+  const int k = min(max(kr + (int)kblk - c.refine_radius_th, 0), n_th - 1);
+  const int ra = min((int)(ab >> 16), n_ty - 1), rb = min((int)(ab & 0xFFFFu), n_tz - 1);
+  const int a_org = min(max(ra - 1, 0), max(n_ty - kTile, 0)), b_org = min(max(rb - 1, 0), max(n_tz - kTile, 0));
+  const int my_s = lane & (kSlices - 1), my_c = lane >> 2, my_a = my_c >> 2, my_b = my_c & 3;
+  const int ia = a_org + my_a, ib = b_org + my_b;
+  const uint32_t Mfull = c.n_lab[f];
+  const uint64_t beg = c.off[f];
+  const bool walk_layout = Mfull <= (uint32_t)kGridLdsPointsMax;
+  const float2* __restrict__ wyz = walk_layout ? c.walk_yz + beg : c.yz + beg;
+  const uint8_t* __restrict__ wlab = walk_layout ? c.walk_lab + beg : c.lab + beg;
+  const uint32_t S = (!walk_layout && Mfull) ? c.walk_stride[f] : 1u;
+  const uint32_t Mi_all = walk_layout ? c.walk_mi[f] : 0u;
+  const float Wh = 0.5f * (float)c.p.board_w, Hh = 0.5f * (float)c.p.board_h, delta2 = (float)c.p.huber_delta;
+  const float cth = c.cth[k], sth = c.sth[k];
+  const float ay = c.ay[min(ia, n_ty - 1)], az = c.az[min(ib, n_tz - 1)];
+  float A0 = 0.f, A1 = 0.f;
+  uint32_t pos = 0, pin = 0;
+  for (uint32_t at0 = (uint32_t)wid * kSlices; at0 < Mfull; at0 += (uint32_t)kAnchorWaves * kSlices) {
+    const uint32_t at = at0 + (uint32_t)my_s;
+    if (at < Mfull) {
+      const uint32_t idx = walk_layout ? at : (uint32_t)(((uint64_t)at * S) % Mfull);
+      const float2 v = wyz[idx];
+      const PointTerms pt{fmaf(-sth, v.y, cth * v.x), fmaf(cth, v.y, sth * v.x), wlab[idx] ? 0.5f : 0.f};   // = k6_grid_cost's staging
+      if (at < Mi_all)
+        accumulate_interior(pt, ay, az, delta2, A0, A1);
+      else
+        accumulate<true>(pt, ay, az, Wh, Hh, delta2, A0, A1);
+    }
+    pos += kSlices;
+    pin += at0 < Mi_all ? (uint32_t)kSlices : 0u;
+  }
+  const float t0s = quad_sum(A0), t1s = quad_sum(A1);
+  if (my_s == 0) {
+    s_part[wid][my_c][0] = t0s;
+    s_part[wid][my_c][1] = t1s;
+  }
+  if (lane == 0) {
+    s_iters[wid] = pos;
+    s_iters_in[wid] = pin;
+  }
+  __syncthreads();
+  if (wid == 0) {
+    Best best{__builtin_inff(), 0xFFFFFFFFu, 0xFFFFFFFFu};
+    uint32_t best_ab = 0;
+    if (lane < 16) {
+      const int ja = a_org + (lane >> 2), jb = b_org + (lane & 3);
+      if (ja < n_ty && jb < n_tz) {
+        float h0 = 0.f, h1 = 0.f;
+#pragma unroll
+        for (int q = 0; q < kAnchorWaves; ++q) {
+          h0 += s_part[q][lane][0];
+          h1 += s_part[q][lane][1];
+        }
+        const float c0 = 2.f * h0, c1 = 2.f * h1;
+        const uint32_t cell = ((uint32_t)k * (uint32_t)n_ty + (uint32_t)ja) * (uint32_t)n_tz + (uint32_t)jb;
+        const uint32_t d2 = (uint32_t)((k - c.c_th) * (k - c.c_th) + (ja - c.c_ty) * (ja - c.c_ty) + (jb - c.c_tz) * (jb - c.c_tz));
+        best = Best{c0, d2, 2u * cell};
+        if (better(c1, d2, 2u * cell + 1u, best)) best = Best{c1, d2, 2u * cell + 1u};
+        best_ab = ((uint32_t)ja << 16) | (uint32_t)jb;
+      }
+    }
+#pragma unroll
+    for (int o = ILCC_WAVE / 2; o > 0; o >>= 1) {
+      Best tt;
+      tt.cost = __shfl_down(best.cost, o, ILCC_WAVE);
+      tt.d2 = __shfl_down(best.d2, o, ILCC_WAVE);
+      tt.flat = __shfl_down(best.flat, o, ILCC_WAVE);
+      const uint32_t tab = __shfl_down(best_ab, o, ILCC_WAVE);
+      if (better(tt.cost, tt.d2, tt.flat, best)) {
+        best = tt;
+        best_ab = tab;
+      }
+    }
+    if (lane == 0) {
+      *out = GridPartial{best.cost, best.d2, best.flat, best_ab};
+      if (best.flat != 0xFFFFFFFFu) atomicMin(c.grid_bound + f, __float_as_uint(best.cost));   // a complete candidate on every point: a valid bound
+      uint32_t it_sum = 0, in_sum = 0;
+      for (int w = 0; w < kAnchorWaves; ++w) {
+        it_sum += s_iters[w];
+        in_sum += s_iters_in[w];
+      }
+      atomicAdd(c.grid_iters + (f & (kIterSlots - 1)), (unsigned long long)it_sum);
+      atomicAdd(c.grid_iters + kIterSlots + (f & (kIterSlots - 1)), (unsigned long long)in_sum);
+    }
+  }
+}
+
+void launch_anchor(const Ctx& c, hipStream_t s) {
+  hipLaunchKernelGGL(k6_anchor, dim3(c.grid_blocks, c.n_frames), dim3(kAnchorThreads), 0, s, c);
+}
+
 size_t locate_lds_bytes(uint32_t sample_cap, int n_ty, int n_tz, int n_ty2, int n_tz2) {
   return (sizeof(float2) + sizeof(float)) * (size_t)sample_cap + sizeof(float2) * (size_t)kLocateThetasMax * sample_cap +
          sizeof(float) * (size_t)(n_ty + n_tz + n_ty2 + n_tz2);
