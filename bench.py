@@ -75,40 +75,43 @@ K6_VALU_OPS_INTERIOR = 15.0
 K6_VALU_OPS_BOX = 24.0
 # PMC passes of the K6 stage at the batch sizes this bench runs (tools/gpu_pmc.sh -> profiles/): per-launch counters of one
 # batch alone on the chip.  roofline.traffic and roofline.issued_vs_credited are computed from these files at run time.
-PMC_FILES = {(2, 1024): ("profiles/r04_pmc_cfg2_1024f.csv",),
+PMC_FILES = {(2, 1024): ("profiles/r05_pmc_cfg2_1024f.csv", "profiles/r04_pmc_cfg2_1024f.csv"),
              (2, 512): ("profiles/r04_pmc_cfg2_512f.csv", "profiles/r03_pmc_cfg2_512f.csv"),
+             (5, 128): ("profiles/r05_pmc_cfg5_128f.csv",),
              (5, 64): ("profiles/r04_pmc_cfg5_64f.csv",)}   # (round 3's config-5 file averaged a cold first dispatch in: not used)
 # rocprofv3 --kernel-trace --stats of this bench's own command (tools/gpu_profile.sh): pipelined (4 batches in flight) and
 # --in-flight 1 (one batch alone on the chip).  roofline.rocprof recomputes `frac` from their per-kernel averages.
-KSTATS_FILES = {2: ("profiles/r04_kernel_stats_bench_20_5.csv", "profiles/r04_kernel_stats_bench_inflight1.csv"),
-                5: ("profiles/r04_kernel_stats_config5.csv", "profiles/r04_kernel_stats_config5_inflight1.csv")}
+KSTATS_FILES = {2: ("profiles/r05_kernel_stats_bench_20_5.csv", "profiles/r05_kernel_stats_bench_inflight1.csv"),
+                5: ("profiles/r05_kernel_stats_config5.csv", "profiles/r05_kernel_stats_config5_inflight1.csv")}
 
 
 def k6_pmc(config, frames_per_batch):
-    """Counters of the K6 launches (seed, refinement, anchor, common pre-pass, full pass) of ONE batch from the committed PMC summary:
-    HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (MI355X_MICROARCH.md: FETCH_SIZE counts half the bytes of wide reads on
-    gfx950; separate passes), issued VALU wavefront-instructions, busy cycles.  None when no file matches this run."""
+    """Counters of the K6 launches (locate: k6_locate, or seed + refinement + k6_anchor rounds; common pre-pass; full pass) of ONE
+    batch from the committed PMC summary: HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (MI355X_MICROARCH.md: FETCH_SIZE counts
+    half the bytes of wide reads on gfx950; separate passes), issued VALU wavefront-instructions, busy cycles.  A summary row is a
+    mean per dispatch; `launches_per_batch` (round 5) says how many dispatches of it a batch makes.  None when no file matches."""
     import csv
     path = next((q for q in PMC_FILES.get((config, frames_per_batch), ()) if os.path.exists(os.path.join(ROOT, q))), None)
     if not path:
         return None
-    rows = [r for r in csv.DictReader(open(os.path.join(ROOT, path))) if "k6_grid_cost" in r["kernel"] or "k6_triple_prepass" in r["kernel"] or "k6_group_prepass" in r["kernel"]
-            or "k6_locate" in r["kernel"]]
-    if len(rows) not in (3, 4, 5):    # seed, refinement, (anchor,) (common pre-pass,) full pass: one summary row per distinct launch
+    rows = [r for r in csv.DictReader(open(os.path.join(ROOT, path))) if any(k in r["kernel"] for k in
+            ("k6_grid_cost", "k6_triple_prepass", "k6_group_prepass", "k6_locate", "k6_anchor"))]
+    if not 3 <= len(rows) <= 6:
         return None
     f = lambda r, k: float(r[k]) if r.get(k) not in (None, "") else 0.0
+    per = lambda r: f(r, "launches_per_batch") or 1.0
     full = max(rows, key=lambda r: f(r, "SQ_INSTS_VALU"))
     return {"file": path,
-            "traffic_bytes": int(sum((2.0 * f(r, "FETCH_SIZE") + f(r, "WRITE_SIZE")) * 1024.0 for r in rows)),
-            "valu_wave_instr": sum(f(r, "SQ_INSTS_VALU") for r in rows),
+            "traffic_bytes": int(sum(per(r) * (2.0 * f(r, "FETCH_SIZE") + f(r, "WRITE_SIZE")) * 1024.0 for r in rows)),
+            "valu_wave_instr": sum(per(r) * f(r, "SQ_INSTS_VALU") for r in rows),
             "full_pass": {"valu_wave_instr": f(full, "SQ_INSTS_VALU"), "gui_active_cycles_per_xcd": f(full, "GRBM_GUI_ACTIVE") / 8.0,
                           "valu_busy_quad_cycles": f(full, "SQ_ACTIVE_INST_VALU")}}
 
 
-def k6_rocprof(config, credited_lane_instr_per_batch, launches_per_batch=4):
-    """roofline.frac recomputed from the committed rocprofv3 kernel-stats CSVs of this bench's command: per batch K6's average
-    kernel duration x its four launches (seed, refinement, anchor, full pass) + the common pre-pass kernel's (k6_triple_prepass),
-    pipelined and with one batch alone on the chip."""
+def k6_rocprof(config, credited_lane_instr_per_batch):
+    """roofline.frac recomputed from the committed rocprofv3 kernel-stats CSVs of this bench's command (tools/gpu_profile.sh): the
+    summed duration of every K6 kernel (k6_locate / k6_grid_cost / k6_anchor / k6_group_prepass) divided by the batches the run made
+    (= calls of k5w_walk_order, one per batch), pipelined and with one batch alone on the chip."""
     import csv
     out = {}
     for tag, path in zip(("pipelined", "in_flight_1"), KSTATS_FILES.get(config, ())):
@@ -116,16 +119,14 @@ def k6_rocprof(config, credited_lane_instr_per_batch, launches_per_batch=4):
         if not os.path.exists(full):
             continue
         rows = list(csv.DictReader(open(full)))
-        k6 = max((r for r in rows if "k6_grid_cost" in r.get("Name", "")), key=lambda r: int(r["Calls"]), default=None)
-        pre = next((r for r in rows if "k6_triple_prepass" in r.get("Name", "") or "k6_group_prepass" in r.get("Name", "")), None)
-        if k6 is None:
+        k6 = [r for r in rows if any(k in r.get("Name", "") for k in ("k6_grid_cost", "k6_locate", "k6_anchor", "k6_group_prepass", "k6_triple_prepass"))]
+        batches = next((int(r["Calls"]) for r in rows if "k5w_walk_order" in r.get("Name", "")), 0)
+        if not k6 or not batches:
             continue
-        avg_us = float(k6["AverageNs"]) / 1e3
-        pre_us = float(pre["AverageNs"]) / 1e3 if pre else 0.0
-        ms = (launches_per_batch * avg_us + pre_us) / 1e3
+        ms = sum(float(r["TotalDurationNs"]) for r in k6) / batches / 1e6
         rate = credited_lane_instr_per_batch / (ms * 1e-3) / 1e12
-        out[tag] = {"file": path, "k6_calls": int(k6["Calls"]), "k6_average_us": avg_us, "k6_group_prepass_average_us": pre_us,
-                    "k6_ms_per_batch": ms, "achieved_this_run": rate, "frac_this_run": rate / VALU_ISSUE_PEAK_T,
+        out[tag] = {"file": path, "batches": batches, "k6_ms_per_batch": ms, "achieved_this_run": rate, "frac_this_run": rate / VALU_ISSUE_PEAK_T,
+                    "kernels_us_per_batch": {r["Name"].replace("ilcc::", "").replace("void ", "")[:40]: round(float(r["TotalDurationNs"]) / batches / 1e3, 1) for r in k6},
                     "what": "THIS run's credited work over the committed profile's per-batch K6 time"}
     return out or None
 

@@ -1,9 +1,9 @@
 # PMC passes at the batch sizes the bench runs (through gpurun from the repo root):  tools/gpu_pmc.sh TAG [FRAMES] [CONFIG]
 # three separate rocprofv3 --pmc passes (SQ counters; FETCH_SIZE; WRITE_SIZE -- MI355X_MICROARCH.md: never combined with
 # other trace domains) of tools/pmc_target.py, summarised per kernel into gpurun_out/<TAG>_pmc_cfg<CONFIG>_<FRAMES>f.csv
-TAG=${1:-r04}
+TAG=${1:-r05}
 CFG=${3:-2}
-F=${2:-$([ "$CFG" = 5 ] && echo 64 || echo 1024)}
+F=${2:-$([ "$CFG" = 5 ] && echo 128 || echo 1024)}
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp

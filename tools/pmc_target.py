@@ -3,7 +3,7 @@ time -- per-dispatch counters of every kernel of the path without bench.py's oth
 two) is a warm-up that tools/pmc_summary.py drops: round 3's config-5 file averaged a first dispatch in that issued 4.3 x the K6
 instructions -- its handle was reserved for 4500 labelled points and these frames hold up to ~5.4 k, so the frames above the
 reserved capacity walked their points through L2 until the handle had grown.
-usage: pmc_target.py [frames_per_batch=512] [config=2|5]      (the batch sizes bench.py runs: 1024 / 64)"""
+usage: pmc_target.py [frames_per_batch=512] [config=2|5]      (the batch sizes bench.py runs: 1024 / 128)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -11,7 +11,7 @@ import torch
 from lidar_camera_calibration_amd import LidarCornersBatch, synth
 from lidar_camera_calibration_amd import _native as N
 config = int(sys.argv[2]) if len(sys.argv) > 2 else 2
-F = int(sys.argv[1]) if len(sys.argv) > 1 else (1024 if config == 2 else 64)
+F = int(sys.argv[1]) if len(sys.argv) > 1 else (1024 if config == 2 else 128)
 params = N.default_params()
 if config == 5:      # BASELINE configs[4], as bench.py --config 5 sets it up
     lidar = synth.hdl64()
@@ -31,7 +31,7 @@ est = LidarCornersBatch(F, n, params)
 # every dispatch takes the steady-state kernels: the capacities are reserved exactly as bench.py reserves them (config 5:
 # 6000 labelled points = 72 KB per K6 workgroup, two per CU like the bench's; reserving the maximum, 8192 = 96 KB, would
 # profile a one-workgroup-per-CU full pass the bench never runs).  The first batch is still a warm-up (pmc_summary.py drops it).
-est.reserve(6000, 20000) if config == 5 else est.reserve(2048, 2560)
+est.reserve(6400, 20000) if config == 5 else est.reserve(2048, 2560)
 for _ in range(4):
     est.extract_device(d_c.data_ptr(), F, n, d_k.data_ptr())
 t = est.timing()
