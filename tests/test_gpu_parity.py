@@ -705,7 +705,7 @@ def test_config5_dense_64_ring_cloud_fine_grid(ob):
 
 def test_large_roi_takes_the_global_memory_paths(ob):
     """A 12 x 12 x 12 m ROI over a 64-ring cloud: > 16 384 ROI points in a bounding grid far larger than K2's cell bitmap (the
-    point-level spatial hash in global memory takes the frame: the fresh handle's own workgroup, unarmed) and more labelled
+    hashed-block cell table in global memory takes the frame) and more labelled
     points than a fresh handle's K6 / K7 LDS stage: these variants must give the oracle's result."""
     board = synth.Board(9, 12, 0.10)
     rng = np.random.default_rng(21)
@@ -913,7 +913,9 @@ def test_cluster_threshold_geometry_matches_the_oracle(ob):
 
 def test_online_caller_get_chessboard_by_point(ob):
     """get_chessboard_by_point (no ROI crop, tolerance 0.10, plane >= 500 points) + gray-zone
-    colouring on whole 28 800-point clouds: K2's spatial-hash path vs the oracle's BFS clustering."""
+    colouring on whole 28 800-point clouds: the two-tier online path (a verified window around the click on K2's LDS cell
+    grid, the whole cloud through the hashed-block k2h_* chain for the frames the window cannot vouch for) vs the oracle's BFS
+    clustering."""
     clouds, _, _, poses = synth.make_batch(6, fixture_poses=True, seed=900)
     pts = np.stack([(p.centre + [0.04, -0.05, 0.03]) for p in poses]).astype(np.float32)
     pts[4] = [-3.0, 2.0, 5.0]                            # predicted centre off the board: whatever surface is nearest wins
@@ -958,6 +960,68 @@ def test_online_caller_get_chessboard_by_point(ob):
     got = m.get_corners(corners)
     assert m.result.n_corners == 35 and (len(corners) == 35) == got
     m.close()
+
+
+def _patch(rng, centre, u, v, half_u, half_v, pitch, jitter=0.002):
+    """points of a planar patch: a lattice of `pitch` metres spanned by the unit vectors u, v, a little noise along the normal"""
+    a = np.arange(-half_u, half_u + 1e-9, pitch)
+    b = np.arange(-half_v, half_v + 1e-9, pitch)
+    A, B = np.meshgrid(a, b, indexing="ij")
+    n = np.cross(u, v)
+    pts = centre + A.reshape(-1, 1) * u + B.reshape(-1, 1) * v + rng.normal(0, jitter, (A.size, 1)) * n
+    return np.concatenate([pts, rng.uniform(5, 90, (len(pts), 1))], axis=1).astype(np.float32)
+
+
+def test_online_caller_two_tiers_agree_with_the_oracle_on_the_tier_boundary(ob):
+    """The online caller answers from a +-1.25 m window around the click when it can PROVE the window's answer is the whole
+    cloud's, and reruns the frame on the whole cloud otherwise (k2_cluster.hip, fine_cluster_frame's first-tier checks).  Scenes
+    built to sit on each side of each check: a compact patch (tier 1); the same patch with a strip that reaches to 1.10 m /
+    1.16 m from the click (inside / outside the 'no member within tol of a face' margin of 1.149 m); a wall wider than the
+    window; a clump of 60 points at the click (inadmissible: the reference falls back to the LARGEST component of the whole
+    cloud, here a far wall the window never sees); a click with nothing within the window; an empty cloud.  Every frame must
+    give the oracle's counts, plane cloud and classes, and exactly the frames that need it take the second tier."""
+    rng = np.random.default_rng(5150)
+    ex, ey, ez = np.eye(3)
+    click = np.array([3.0, 0.2, 0.1])
+    far_wall = _patch(rng, np.array([9.0, -4.0, 0.5]), ey, ez, 1.5, 1.0, 0.04)          # ~ 3 900 points, > 2 m from every window
+    compact = _patch(rng, click + [0.02, 0, 0], ey, ez, 0.45, 0.35, 0.025)              # ~ 1 070 points
+    def strip(reach):    # a 6 cm wide strip from the patch's edge out to `reach` metres from the click along +y
+        return _patch(rng, click + [0.02, (0.45 + reach) / 2, 0.0], ey, ez, (reach - 0.45) / 2, 0.03, 0.025)
+    scenes = [
+        (np.concatenate([compact, far_wall]), click, False),
+        (np.concatenate([compact, strip(1.10), far_wall]), click, False),
+        (np.concatenate([compact, strip(1.16), far_wall]), click, True),
+        (np.concatenate([compact, strip(1.60), far_wall]), click, True),
+        (np.concatenate([_patch(rng, click + [0.02, 0, 0], ey, ez, 2.0, 0.6, 0.03), far_wall]), click, True),   # wider than the window
+        (np.concatenate([_patch(rng, click, ey, ez, 0.05, 0.04, 0.012), far_wall]), click, True),                 # 60-odd points at the click
+        (np.concatenate([compact, far_wall]), click + [0.0, 2.0, 1.5], True),                                     # nothing in the window
+        (np.full((64, 4), np.nan, dtype=np.float32), click, True),                                               # no finite point at all
+    ]
+    n_max = max(len(c) for c, _, _ in scenes)
+    clouds = np.full((len(scenes), n_max, 4), np.nan, dtype=np.float32)     # ragged frames padded with non-finite points (dropped by K1)
+    for k, (c, _, _) in enumerate(scenes):
+        clouds[k, :len(c)] = c[rng.permutation(len(c))]
+    pts = np.stack([q for _, q, _ in scenes]).astype(np.float32)
+    p = N.default_params()
+    p.gray_rate = 2.4
+    e = LidarCornersBatch(len(scenes), n_max, p)
+    e.reset_timing()
+    res = e.chessboard_by_point(clouds, pts)
+    second = e.timing().online_second_tier_frames
+    op = ob.default_params()
+    op.cluster_tol, op.gray_rate = 0.10, 2.4
+    for f in range(len(scenes)):
+        o, ocb, ocl = ob.chessboard_by_point(clouds[f], pts[f], op)
+        r = res[f]
+        assert r.status == o.status, (f, r.status, o.status)
+        assert (r.n_roi, r.n_cluster, r.n_plane, r.found_board) == (o.n_roi, o.n_cluster, o.n_plane, o.phase), f
+        if o.status in (0, N.BOARD_NOT_FOUND) and o.n_plane >= 3:
+            assert np.array_equal(e.fetch_cloud(f, N.CLOUD_CHESSBOARD), ocb), f
+            assert np.array_equal(e.fetch_classes(f), ocl), f
+    assert res[0].found_board and res[1].found_board and res[3].found_board and not res[5].found_board
+    assert res[5].n_cluster > 3000                       # the far wall: the largest admissible component of the WHOLE cloud
+    assert second == sum(1 for _, _, t2 in scenes if t2), second
+    e.close()
 
 
 def test_device_records_equal_host_packing():
@@ -1113,9 +1177,40 @@ def test_points_on_cell_borders_of_the_grid_argmin(ob):
     est.close()
 
 
-def test_sparse_wide_roi_takes_the_point_level_hash(ob):
+def test_fused_locate_equals_the_three_launches():
+    """Batches of >= 512 frames locate the grid minimum with ONE launch (k6_locate: seed, refinement and anchor in one workgroup
+    per frame), smaller ones with three k6_grid_cost launches over (theta, frame) grids.  Same candidates on the same points in
+    the same order: every field of the result must be identical, and so must the executed-evaluation-independent outputs
+    (grid argmin, cost, margin, refinement trajectory, corners).  64 distinct frames, tiled 8 x into one 512-frame batch."""
+    from lidar_camera_calibration_amd import LidarCornersBatch, synth
+    from lidar_camera_calibration_amd import _native as N
+    clouds, clicks, _, _ = synth.make_batch(64, seed=0xF05ED)
+    small = LidarCornersBatch(64, clouds.shape[1], N.default_params())
+    small.reserve(2048, 4096)
+    r_small = small.extract(clouds, clicks)
+    big = LidarCornersBatch(512, clouds.shape[1], N.default_params())
+    big.reserve(2048, 4096)
+    r_big = big.extract(np.tile(clouds, (8, 1, 1)), np.tile(clicks, (8, 1)))
+    n_ok = 0
+    for f in range(512):
+        a, b = r_small[f % 64], r_big[f]
+        assert (a.status, a.flags, a.n_roi, a.n_cluster, a.n_plane, a.grid_index) == (b.status, b.flags, b.n_roi, b.n_cluster, b.n_plane, b.grid_index), f
+        if a.status in (N.OK, N.AMBIGUOUS):
+            # (grid_ties is not compared: how many candidates were LISTED as near ties depends on how far the frame's bound had come
+            # down when each completed -- a superset of the true near ties either way, re-ranked exactly by K7r)
+            assert (a.grid_cost, a.basin_margin, a.sel_cost, a.iters_a, a.iters_b, a.cells_hit, a.n_oob) == \
+                   (b.grid_cost, b.basin_margin, b.sel_cost, b.iters_a, b.iters_b, b.cells_hit, b.n_oob), f
+            assert tuple(a.theta_t) == tuple(b.theta_t) and np.array_equal(a.corners_array(), b.corners_array()), f
+            n_ok += 1
+    assert n_ok >= 8 * 55
+    small.close()
+    big.close()
+
+
+def test_sparse_wide_roi_takes_the_hashed_block_path(ob):
     """<= 4096 ROI points whose bounding grid is far larger than K2's cell bitmap (a 12 x 12 x 6 m ROI over a thinned cloud:
-    ~2.7 M cells of 0.068 m against 96 k bits): the frame falls back to the point-level spatial hash in global memory.
+    ~2.7 M cells of 0.068 m against 96 k bits): the frame takes the cell-level components with the cells in a hash table of
+    4 x 4 x 4-cell blocks in global memory (the frame's own workgroup: hashed_cluster_frame).
     Stage counts and the cluster cloud must equal the oracle's."""
     board = synth.Board()
     pose = synth.pose_from_fixture(1)
