@@ -444,7 +444,6 @@ Ctx make_ctx(ilcc_handle* h, Slot& sl, const float4* d_xyzi, const float* d_clic
   c.grid_bound = sl.d_bound;
   c.grid_bound_sub = sl.d_bound_sub;
   c.walk_limit = 0;
-  c.seed_k_from_flat = 0;
   c.tie_count = nullptr;   // only the full pass of K6 collects; K7a gets the pointers below
   c.tie_count_all = sl.d_tie_count;
   c.tie_list = sl.d_tie_list;
@@ -539,28 +538,105 @@ int32_t enqueue(ilcc_handle* h, int si, const float4* d_xyzi, const uint64_t* of
   return st;
 }
 
+// Host-side constants of the grid search.  (A/B builds override the #defines with -D, tools/build_variant.sh; what each was
+// measured at is recorded in DESIGN.md section 4 "K6" and profiles/README.md.)
+#ifndef ILCC_SEED_POINTS
+#define ILCC_SEED_POINTS 128   // seed and refinement walk a PREFIX of the frame's walk: an eighth of its labelled points, at least this many
+#endif
+#ifndef ILCC_BOX_POINTS
+#define ILCC_BOX_POINTS 48     // rim points a (frame, theta) workgroup's own box pre-pass looks at, at least
+#endif
+#ifndef ILCC_K6_CHAIN
+#define ILCC_K6_CHAIN 1        // 0: the full passes of different batches may share the chip (measured slower every round)
+#endif
+constexpr int kAnchorRadius = 1;   // the anchor scores 2 * 1 + 1 thetas around the refinement's argmin, one 4 x 4 tile each, on ALL points
+constexpr int kAnchorRounds = 2;   // k6_anchor rounds, each re-centred on the previous one's argmin (config 5: 62.5 -> 70.6 k frames/s)
+
+// where the full pass (and the common pre-pass) find the records of the launch that published the frame's bound: `blocks` records
+// per frame from a launch over the FULL tables
+void seeded_by_full_table_records(Ctx& full, const ilcc_handle* h, GridPartial* records, uint32_t blocks) {
+  full.seed_partial = records;
+  full.seed_blocks = blocks;
+  full.seed_n_ty = h->p.n_ty;
+  full.seed_n_tz = h->p.n_tz;
+  full.seed_stride_t = 1;
+  full.seed_stride_th = 1;
+  full.seed_off_th = 0;
+}
+
+// Locating the minimum with three kinds of launches (batches too small for k6_locate's one workgroup per frame): seed over the
+// decimated tables, refinement around its argmin (both on the walk's prefix, with a bound word of their own: their sums are not
+// costs of complete candidates), then kAnchorRounds anchor rounds on every point, which publish the frame's real bound.
+int32_t enqueue_locate_launches(ilcc_handle* h, Slot& sl, const Ctx& c, hipStream_t s, Ctx& full) {
+  Ctx seed = c;
+  seed.cth = h->d_cth2;
+  seed.sth = h->d_sth2;
+  seed.ay = h->d_ay2;
+  seed.az = h->d_az2;
+  seed.p.n_th = h->n_th2;
+  seed.p.n_ty = h->n_ty2;
+  seed.p.n_tz = h->n_tz2;
+  seed.grid_blocks = (uint32_t)h->n_th2;
+  seed.partial = sl.d_partial2;
+  // the "nearest to zero" indices of the decimated tables (the kernel reads ay[c_ty] / az[c_tz] for its rim test and
+  // uses all three for the tie-break distance: they must index THIS launch's tables, not the full ones)
+  seed.c_th = std::min(std::max(c.c_th / std::max(1, h->seed_stride_th), 0), h->n_th2 - 1);
+  seed.c_ty = std::min(c.c_ty / std::max(1, h->seed_stride_t), h->n_ty2 - 1);
+  seed.c_tz = std::min(c.c_tz / std::max(1, h->seed_stride_t), h->n_tz2 - 1);
+  seed.walk_limit = (uint32_t)ILCC_SEED_POINTS;
+  seed.grid_bound = sl.d_bound_sub;
+  launch_grid_cost(seed, s, /*use_oob=*/1, nullptr, true);
+  HIP_TRY(h, hipEventRecord(sl.k6ev[1], s));
+  // refinement: every kRefineThetaStride-th theta within a third of a seed stride of the seed's argmin, 8 x 8 translations
+  Ctx refine = c;
+  refine.seed_partial = sl.d_partial2;
+  refine.seed_blocks = (uint32_t)h->n_th2;
+  refine.seed_n_ty = h->n_ty2;
+  refine.seed_n_tz = h->n_tz2;
+  refine.seed_stride_t = h->seed_stride_t;
+  refine.seed_stride_th = h->seed_stride_th;
+  refine.seed_off_th = h->seed_stride_th / 2;
+  refine.refine_window = 1;
+  refine.refine_radius_th = (std::max(1, h->seed_stride_th / ILCC_REFINE_RADIUS_DIV) / kRefineThetaStride) * kRefineThetaStride;
+  refine.refine_step_th = kRefineThetaStride;
+  refine.grid_blocks = std::min((uint32_t)(2 * (refine.refine_radius_th / kRefineThetaStride) + 1), h->max_theta);
+  refine.partial = sl.d_partial3;
+  refine.walk_limit = (uint32_t)ILCC_SEED_POINTS;
+  refine.grid_bound = sl.d_bound_sub;
+  launch_grid_cost(refine, s, /*use_oob=*/1, nullptr, true);
+  HIP_TRY(h, hipEventRecord(sl.k6ev[2], s));
+  // anchor rounds (k6_anchor): 3 thetas x one tile on ALL points; every further round re-centres the tile on the previous
+  // round's argmin -- a greedy descent on complete costs towards the grid minimum, for a tighter bound in front of the full pass
+  Ctx anchor = c;
+  seeded_by_full_table_records(anchor, h, sl.d_partial3, refine.grid_blocks);
+  anchor.refine_radius_th = kAnchorRadius;
+  anchor.grid_blocks = 2 * kAnchorRadius + 1;
+  GridPartial* const ping[2] = {sl.d_partial4, sl.d_partial2};
+  for (int round = 0; round < kAnchorRounds; ++round) {
+    anchor.partial = ping[round & 1];
+    launch_anchor(anchor, s);
+    anchor.seed_partial = ping[round & 1];
+    anchor.seed_blocks = 2 * kAnchorRadius + 1;
+  }
+  seeded_by_full_table_records(full, h, ping[(kAnchorRounds - 1) & 1], 2 * kAnchorRadius + 1);
+  return ILCC_OK;
+}
+
 // The grid search of one batch on its stream: K5w (walk layout), the launches that locate the minimum and publish the frame's bound
-// (seed, refinement, anchor), the common pre-pass, the full pass -- with the slot's K6 events recorded in between.  chain: the full
-// pass waits for the previous batch's (the pipeline; the diagnostic entry ilcc_grid_solve runs alone).
+// (k6_locate, or seed + refinement + anchor rounds), the common pre-pass, the full pass -- with the slot's K6 events recorded in
+// between.  chain: the full pass waits for the previous batch's (the pipeline; the diagnostic entry ilcc_grid_solve runs alone).
 int32_t enqueue_grid_search(ilcc_handle* h, Slot& sl, int si, const Ctx& c, hipStream_t s, uint32_t n_frames, bool chain) {
   const bool prune = h->p.grid_prune != 0;
   launch_walk_order(c, s);   // K5w: the labelled points in K6's walk layout, once per frame
   HIP_TRY(h, hipEventRecord(sl.k6ev[0], s));
-  bool ev1 = false, ev2 = false;
   Ctx full = c;
-  // (grid_prune = 0 keeps the two small passes: they only initialise the frame's bound, which the cut-free full
+  // (grid_prune = 0 keeps the locate launches: they only initialise the frame's bound, which the cut-free full
   // pass still needs to recognise near ties; it never cuts a tile)
   if (h->n_th2 > 0 && h->p.n_th >= 8 && h->p.n_ty >= 8 && h->p.n_tz >= 8) {
-    // All three small launches below only have to LOCATE the minimum.  The first two therefore look at a prefix of the
-    // point walk (an eighth of the frame's labelled points, at least ILCC_SEED_POINTS = 128 positions: a uniform sample of
-    // the board) and keep their own bound word; the anchor launch evaluates what they found -- 3 thetas x 8 x 8 translations
-    // around the refinement's argmin -- on EVERY point and publishes the frame's real bound.  (Round 2 ran seed and
-    // refinement on all points: 16 % of the path's VALU instructions.)
-#ifndef ILCC_SEED_POINTS
-#define ILCC_SEED_POINTS 128
-#endif
-    const uint32_t sub = (uint32_t)ILCC_SEED_POINTS;
-    // one launch, one workgroup per frame (k6_locate) when the batch has the frames to fill the chip that way
+    // These launches only have to LOCATE the minimum.  Seed and refinement therefore look at a prefix of the point walk (an
+    // eighth of the frame's labelled points, at least ILCC_SEED_POINTS positions: a uniform sample of the board) and keep their
+    // own bound word; the anchor evaluates what they found on EVERY point and publishes the frame's real bound.  (Round 2 ran
+    // seed and refinement on all points: 16 % of the path's VALU instructions.)
     LocatePlan lp{};
     lp.cth2 = h->d_cth2;
     lp.sth2 = h->d_sth2;
@@ -576,139 +652,33 @@ int32_t enqueue_grid_search(ilcc_handle* h, Slot& sl, int si, const Ctx& c, hipS
     lp.off_th = h->seed_stride_th / 2;
     lp.stride_t = h->seed_stride_t;
     lp.refine_radius = std::max(1, h->seed_stride_th / ILCC_REFINE_RADIUS_DIV);
-    lp.sample_min = sub;
-    lp.sample_cap = std::max(sub, ((c.grid_lds_points >> 3) + 63u) & ~63u);
+    lp.sample_min = (uint32_t)ILCC_SEED_POINTS;
+    lp.sample_cap = std::max((uint32_t)ILCC_SEED_POINTS, ((c.grid_lds_points >> 3) + 63u) & ~63u);
     lp.out = sl.d_partial4;
-    const bool fused = n_frames >= (uint32_t)kLocateMinFrames && sub != 0u && h->n_th2 <= 16 &&
+    // one launch, one workgroup per frame (k6_locate) when the batch has the frames to fill the chip that way
+    const bool fused = n_frames >= (uint32_t)kLocateMinFrames && h->n_th2 <= 16 &&
                        locate_lds_bytes(lp.sample_cap, h->p.n_ty, h->p.n_tz, h->n_ty2, h->n_tz2) <= 60u * 1024u;
     if (fused) {
       launch_locate(c, s, lp);
       HIP_TRY(h, hipEventRecord(sl.k6ev[1], s));   // (the whole locate launch is accounted as the "seed" span)
       HIP_TRY(h, hipEventRecord(sl.k6ev[2], s));
-      ev1 = ev2 = true;
-      full.seed_partial = sl.d_partial4;
-      full.seed_blocks = 1;
-      full.seed_n_ty = h->p.n_ty;
-      full.seed_n_tz = h->p.n_tz;
-      full.seed_stride_t = 1;
-      full.seed_stride_th = 1;
-      full.seed_off_th = 0;
+      seeded_by_full_table_records(full, h, sl.d_partial4, 1);
     } else {
-    Ctx seed = c;
-    seed.cth = h->d_cth2;
-    seed.sth = h->d_sth2;
-    seed.ay = h->d_ay2;
-    seed.az = h->d_az2;
-    seed.p.n_th = h->n_th2;
-    seed.p.n_ty = h->n_ty2;
-    seed.p.n_tz = h->n_tz2;
-    seed.grid_blocks = (uint32_t)h->n_th2;
-    seed.partial = sl.d_partial2;
-    // the "nearest to zero" indices of the decimated tables (the kernel reads ay[c_ty] / az[c_tz] for its rim test and
-    // uses all three for the tie-break distance: they must index THIS launch's tables, not the full ones)
-    seed.c_th = std::min(std::max((c.c_th - h->seed_stride_th / 2 + h->seed_stride_th / 2) / std::max(1, h->seed_stride_th), 0), h->n_th2 - 1);
-    seed.c_ty = std::min(c.c_ty / std::max(1, h->seed_stride_t), h->n_ty2 - 1);
-    seed.c_tz = std::min(c.c_tz / std::max(1, h->seed_stride_t), h->n_tz2 - 1);
-    seed.walk_limit = sub;
-    if (sub) seed.grid_bound = sl.d_bound_sub;
-    launch_grid_cost(seed, s, /*use_oob=*/1, nullptr, true);
-    HIP_TRY(h, hipEventRecord(sl.k6ev[1], s));
-    ev1 = true;
-    Ctx refine = c;
-    refine.seed_partial = sl.d_partial2;
-    refine.seed_blocks = (uint32_t)h->n_th2;
-    refine.seed_n_ty = h->n_ty2;
-    refine.seed_n_tz = h->n_tz2;
-    refine.seed_stride_t = h->seed_stride_t;
-    refine.seed_stride_th = h->seed_stride_th;
-    refine.seed_off_th = h->seed_stride_th / 2;
-    // refinement pass: all candidates around the seed argmin (theta +- a third of a seed stride, 8 x 8 translations)
-    refine.refine_window = 1;
-    refine.refine_radius_th = (std::max(1, h->seed_stride_th / ILCC_REFINE_RADIUS_DIV) / kRefineThetaStride) * kRefineThetaStride;
-    refine.refine_step_th = kRefineThetaStride;
-    refine.grid_blocks = std::min((uint32_t)(2 * (refine.refine_radius_th / kRefineThetaStride) + 1), h->max_theta);
-    refine.partial = sl.d_partial3;
-    refine.walk_limit = sub;
-    if (sub) refine.grid_bound = sl.d_bound_sub;
-    launch_grid_cost(refine, s, /*use_oob=*/1, nullptr, true);
-    HIP_TRY(h, hipEventRecord(sl.k6ev[2], s));
-    ev2 = true;
-    if (sub) {
-      Ctx anchor = c;
-      anchor.seed_partial = sl.d_partial3;
-      anchor.seed_blocks = refine.grid_blocks;
-      anchor.seed_n_ty = h->p.n_ty;
-      anchor.seed_n_tz = h->p.n_tz;
-      anchor.seed_stride_t = 1;
-      anchor.seed_stride_th = 1;
-      anchor.seed_off_th = 0;
-      anchor.seed_k_from_flat = 1;
-#ifndef ILCC_ANCHOR_RADIUS
-#define ILCC_ANCHOR_RADIUS 1
-#endif
-#ifndef ILCC_ANCHOR_WINDOW
-#define ILCC_ANCHOR_WINDOW 2   // 1: 8 x 8 translations per theta, 2: one 4 x 4 tile around the refinement's argmin (measured: 575 k vs 586 k frames/s; with 1 theta: 581 k)
-#endif
-      anchor.refine_window = ILCC_ANCHOR_WINDOW;
-      anchor.refine_radius_th = ILCC_ANCHOR_RADIUS;
-      anchor.grid_blocks = 2 * ILCC_ANCHOR_RADIUS + 1;
-      anchor.partial = sl.d_partial4;
-#ifndef ILCC_ANCHOR_ROUNDS
-#define ILCC_ANCHOR_ROUNDS 2
-#endif
-      // anchor rounds (k6_anchor): 3 thetas x one tile on ALL points; every further round re-centres the tile on the previous
-      // round's argmin -- a greedy descent on complete costs towards the grid minimum, for a tighter bound in front of the full pass
-      GridPartial* ping[2] = {sl.d_partial4, sl.d_partial2};
-      if (ILCC_ANCHOR_WINDOW == 2) {
-        launch_anchor(anchor, s);
-        for (int round = 1; round < ILCC_ANCHOR_ROUNDS; ++round) {
-          Ctx again = anchor;
-          again.seed_partial = ping[(round - 1) & 1];
-          again.seed_blocks = 2 * ILCC_ANCHOR_RADIUS + 1;
-          again.partial = ping[round & 1];
-          launch_anchor(again, s);
-        }
-        full.seed_partial = ping[(ILCC_ANCHOR_ROUNDS - 1) & 1];
-      } else {
-        launch_grid_cost(anchor, s, /*use_oob=*/1, nullptr, true);
-        full.seed_partial = sl.d_partial4;
-      }
-      full.seed_blocks = 2 * ILCC_ANCHOR_RADIUS + 1;
-      full.seed_n_ty = h->p.n_ty;
-      full.seed_n_tz = h->p.n_tz;
-      full.seed_stride_t = 1;
-      full.seed_stride_th = 1;
-      full.seed_off_th = 0;
-    } else {
-      full.seed_partial = sl.d_partial2;
-      full.seed_blocks = (uint32_t)h->n_th2;
-      full.seed_n_ty = h->n_ty2;
-      full.seed_n_tz = h->n_tz2;
-      full.seed_stride_t = h->seed_stride_t;
-      full.seed_stride_th = h->seed_stride_th;
-      full.seed_off_th = h->seed_stride_th / 2;
+      const int32_t st = enqueue_locate_launches(h, sl, c, s, full);
+      if (st != ILCC_OK) return st;
     }
+  } else {
+    HIP_TRY(h, hipEventRecord(sl.k6ev[1], s));
+    HIP_TRY(h, hipEventRecord(sl.k6ev[2], s));
   }
-  }
-  // The FULL passes of different slots are chained so that they never share the chip (their HIP-event
-  // durations stay clean and they do not fight for LDS); the seed and refinement passes above are small,
-  // latency-bound launches and are left free to overlap with another batch's full pass, like K2/K3/K7.
-#ifndef ILCC_BOX_POINTS
-#define ILCC_BOX_POINTS 48   // 16: 461 k, 32: 485 k, 48: 487 k, 64: 484 k, 96: 474 k frames/s when it was introduced; with the one-tile anchor 32: 578 k, 48: 590 k
-#endif
+  HIP_TRY(h, hipEventRecord(sl.k6ev[3], s));   // behind the anchor: the common pre-pass gets an event span of its own
   const GroupPrepassPlan gp = group_prepass_plan(h->p);
   // box pre-pass (k6_grid_cost.hip): its monotonicity argument needs a tile's box narrower than one square on both axes
   full.box_points = (prune && 3.0 * h->p.ty_step < 0.9 * h->p.grid_length && 3.0 * h->p.tz_step < 0.9 * h->p.grid_length) ? (uint32_t)ILCC_BOX_POINTS : 0u;
-  if (!ev1) HIP_TRY(h, hipEventRecord(sl.k6ev[1], s));
-  if (!ev2) HIP_TRY(h, hipEventRecord(sl.k6ev[2], s));
-  HIP_TRY(h, hipEventRecord(sl.k6ev[3], s));   // behind the anchor launch: the common pre-pass gets an event span of its own
-#ifndef ILCC_K6_GROUP_PREPASS
-#define ILCC_K6_GROUP_PREPASS 1
-#endif
   // k6_group_prepass: one box pre-pass for kThetaGroup consecutive thetas, launched HERE -- behind the anchor (it needs the
   // frame's bound), in front of the wait for the previous batch's full pass, so it runs beside that pass like the other small
   // launches.  Its buffers were sized for (max_frames, this grid) by alloc_slot / ilcc_set_params.
-  if (ILCC_K6_GROUP_PREPASS && full.box_points != 0u && gp.on && (size_t)n_frames * gp.groups <= sl.grp_alive_cap &&
+  if (full.box_points != 0u && gp.on && (size_t)n_frames * gp.groups <= sl.grp_alive_cap &&
       (size_t)n_frames * gp.groups * gp.words <= sl.grp_mask_cap) {
     full.grp_count = gp.groups;
     full.grp_words = gp.words;
@@ -717,9 +687,9 @@ int32_t enqueue_grid_search(ilcc_handle* h, Slot& sl, int si, const Ctx& c, hipS
     full.grp_mask = sl.d_grp_mask;
   }
   HIP_TRY(h, hipEventRecord(sl.ev[7], s));
-#ifndef ILCC_K6_CHAIN
-#define ILCC_K6_CHAIN 1   // (A/B builds: 0 lets the full passes of different batches overlap)
-#endif
+  // The FULL passes of different slots are chained so that they never share the chip (two passes side by side both run at half
+  // speed and every batch's front end waits longer for wave slots); the launches above are small and are left free to overlap
+  // with another batch's full pass, like K2 / K3 / K7.
   if (chain && ILCC_K6_CHAIN && h->k6_last >= 0 && h->k6_last != si && h->slots[h->k6_last].busy)
     HIP_TRY(h, hipStreamWaitEvent(s, h->slots[h->k6_last].k6_done, 0));
   HIP_TRY(h, hipEventRecord(sl.ev[8], s));

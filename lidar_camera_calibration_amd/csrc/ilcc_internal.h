@@ -156,7 +156,6 @@ struct Ctx {
   uint32_t* grid_bound;      // per frame: float bits of the best complete candidate cost so far (K6 pruning)
   uint32_t* grid_bound_sub;  // the same for the subsampled seed / refinement launches (costs over a prefix of the walk: never a valid bound for complete costs)
   uint32_t walk_limit;       // K6: 0 = every labelled point; else only the first walk_limit positions of the walk (a uniform sample of the board)
-  uint32_t seed_k_from_flat; // K6: the seed records come from a launch over the FULL tables: theta index = flat / (2 n_ty n_tz), not the record's position
   // near ties: candidates of the full pass whose fp32 cost is within kTieEps of the bound at the time they
   // complete; K7r recounts them on the oracle's fixed-point cost so that the argmin is the oracle's even when fp32 cannot order them
   uint32_t* tie_count;       // per frame (nullptr: this launch does not collect)
@@ -175,7 +174,7 @@ struct Ctx {
   int32_t seed_stride_th, seed_off_th;           // seed k2 -> grid theta index seed_off_th + k2*seed_stride_th
   // refinement pass (between seed and full pass): workgroup j evaluates the 16 x 16 (ty, tz) window around
   // the seed argmin at theta index (seed theta) + j - refine_radius_th; 0 = this launch is not a refinement
-  int32_t refine_window;     // 1: this launch evaluates only the 8 x 8 (ty, tz) window around the seed argmin, theta within +-refine_radius_th
+  int32_t refine_window;     // 1: this launch (the refinement) evaluates only the 8 x 8 (ty, tz) window around the seed argmin, every refine_step_th-th theta within +-refine_radius_th
   int32_t refine_radius_th;
   int32_t refine_step_th;    // theta step between the workgroups of a refinement / anchor launch (kRefineThetaStride / 1)
   // candidate tables (device)

@@ -227,28 +227,19 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
     const Best sb = seed_argmin(c, f, k2u, ab);
     if (sb.flat != 0xFFFFFFFFu) {
       const int a2 = __builtin_amdgcn_readfirstlane((int)(ab >> 16)), b2 = __builtin_amdgcn_readfirstlane((int)(ab & 0xFFFFu));
-      // (records of a launch over the full tables carry the theta index in their flat index: one division per wavefront of
-      // the small anchor launch)
-      const int k2 = __builtin_amdgcn_readfirstlane(c.seed_k_from_flat ? (int)((sb.flat >> 1) / (uint32_t)(n_ty * n_tz)) : (int)k2u);
+      const int k2 = __builtin_amdgcn_readfirstlane((int)k2u);
       const int sa = min(a2 * c.seed_stride_t, n_ty - 1), sbb = min(b2 * c.seed_stride_t, n_tz - 1);
       if (c.refine_window) {
         // refinement pass: every candidate within +-radius theta steps and the 8 x 8 (ty, tz) window
         // around the seed argmin -> the frame's bound is (nearly always) the true minimum before the
         // full pass starts, which is what lets the full pass cut almost every tile after 8 points
-        // (the refinement launch scores every kRefineThetaStride-th theta of its range, the anchor launch every one: refine_step_th)
+        // (it scores every kRefineThetaStride-th theta of its range: refine_step_th; the anchor rounds -- k6_anchor, or the tail of k6_locate -- cover the ones in between)
         const int kc = c.seed_off_th + k2 * c.seed_stride_th + (int)kblk * c.refine_step_th - c.refine_radius_th;
         k = (uint32_t)__builtin_amdgcn_readfirstlane(min(max(kc, 0), c.p.n_th - 1));
-        if (c.refine_window == 1) {        // 8 x 8 translations around the argmin
-          a_org = __builtin_amdgcn_readfirstlane(min(max(sa - kTile, 0), max(n_ty - 2 * kTile, 0)));
-          b_org = __builtin_amdgcn_readfirstlane(min(max(sbb - kTile, 0), max(n_tz - 2 * kTile, 0)));
-          nta = min(2, nta);
-          ntb = min(2, ntb);
-        } else {                           // one tile: the argmin, one step below and two above it on both axes
-          a_org = __builtin_amdgcn_readfirstlane(min(max(sa - 1, 0), max(n_ty - kTile, 0)));
-          b_org = __builtin_amdgcn_readfirstlane(min(max(sbb - 1, 0), max(n_tz - kTile, 0)));
-          nta = 1;
-          ntb = 1;
-        }
+        a_org = __builtin_amdgcn_readfirstlane(min(max(sa - kTile, 0), max(n_ty - 2 * kTile, 0)));   // 8 x 8 translations around the argmin
+        b_org = __builtin_amdgcn_readfirstlane(min(max(sbb - kTile, 0), max(n_tz - 2 * kTile, 0)));
+        nta = min(2, nta);
+        ntb = min(2, ntb);
       } else {
         // full pass: start at the tile that holds the seed's best translation; the order never changes the result
         t0 = __builtin_amdgcn_readfirstlane((sa / kTile) * ntb + (sbb / kTile));
