@@ -69,6 +69,7 @@ constexpr int kGroupShiftDelta = -1;   // the common pre-pass (k6_group_prepass)
 static_assert(kBoxShiftSmall + kGroupShiftDelta >= 1 && kBoxShiftLarge + kGroupShiftDelta >= 1,
               "k6_group_prepass stages M >> (kBoxShift + kGroupShiftDelta) <= M / 2 points: launch_group_prepass sizes its LDS for that");
 constexpr int kBoxCheck = 8;          // box pre-pass: points per lane between two looks at "is every tile of this wavefront beaten already"
+constexpr int kBoxSegment = 1024;                  // box pre-pass: tile ids per compaction round (the list of live tiles: 2 KB of LDS; a multiple of every workgroup size)
 constexpr int kBoxTilesMax = 4096;                 // box pre-pass: tiles per workgroup its LDS bit mask holds
 constexpr float kBoxSafety = 1.f - 0x1p-12f;
 constexpr int kBoundRefresh = 256;                  // points between reloads of the frame's shared bound
@@ -77,6 +78,18 @@ constexpr int kBoundRefresh = 256;                  // points between reloads of
 __device__ __forceinline__ float quad_sum(float v) {
   v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0xB1 /*quad_perm [1,0,3,2]*/, 0xf, 0xf, false));
   v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x4E /*quad_perm [2,3,0,1]*/, 0xf, 0xf, false));
+  return v;
+}
+
+// sum over aligned groups of P lanes (P a power of two, 2 ... 64; wave-uniform): every lane of a group gets the same bits (each
+// step adds two values that both partners hold: a + b == b + a)
+__device__ __forceinline__ float lanes_sum(float v, uint32_t P) {
+  v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0xB1 /*quad_perm [1,0,3,2]*/, 0xf, 0xf, false));
+  if (P > 2u) v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x4E /*quad_perm [2,3,0,1]*/, 0xf, 0xf, false));
+  if (P > 4u) v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x141 /*row_half_mirror*/, 0xf, 0xf, false));
+  if (P > 8u) v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x140 /*row_mirror*/, 0xf, 0xf, false));
+  if (P > 16u) v += __shfl_xor(v, 16);
+  if (P > 32u) v += __shfl_xor(v, 32);
   return v;
 }
 
@@ -176,7 +189,7 @@ __device__ __forceinline__ Best seed_argmin(const Ctx& c, uint32_t f, uint32_t& 
 
 template <bool OOB, bool VOLUME, bool LDS_POINTS, bool PRUNE, int THREADS>
 __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, float2* s_ij, float* s_hw, Best* s_best,
-                                               uint32_t* s_iters, uint32_t* s_cnt, float* s_ay, float* s_az, uint32_t* s_dead,
+                                               uint32_t* s_iters, uint32_t* s_cnt, float* s_ay, float* s_az, uint32_t* s_dead, uint16_t* s_live,
                                                uint32_t* s_next, const uint32_t kblk) {
   // kblk: this workgroup's index within the frame (= blockIdx.x)
   const uint32_t f = blockIdx.y;
@@ -320,48 +333,69 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
     if (use_box) {
       for (int w = threadIdx.x; w < (n_tiles + 31) / 32; w += THREADS) s_dead[w] = s_dead0 ? s_dead0[w] : 0u;
       if (threadIdx.x == 0) s_cnt[0] = 0u;   // "a tile of this workgroup is still alive" (s_cnt is free until the epilogue)
-      __syncthreads();
       const uint32_t n_pre = min(max(c.box_points, Mfull >> kBoxShift), M - Mi);   // the frame's bound grows with its point count: so must the sample that has to exceed it
       const float lim_box = 0.5f * (1.f + kTieEps) * __uint_as_float(gb_bits);
-      const int half = (int)(threadIdx.x & 1u);
       uint32_t wave_evals = 0;   // (point, tile) evaluations this wavefront really did (wave-uniform)
-      for (int q0 = 0; q0 < n_tiles; q0 += THREADS / 2) {
-        const int q = q0 + (int)(threadIdx.x >> 1);
-        const int qc = min(q, n_tiles - 1);
-        const int qa = qc / ntb, qb = qc - qa * ntb;
-        float alo = __builtin_inff(), ahi = -__builtin_inff(), zlo = __builtin_inff(), zhi = -__builtin_inff();
-#pragma unroll
-        for (int d = 0; d < kTile; ++d) {
-          const float va = s_ay[min(a_org + qa * kTile + d, n_ty - 1)], vz = s_az[min(b_org + qb * kTile + d, n_tz - 1)];
-          alo = fminf(alo, va);
-          ahi = fmaxf(ahi, va);
-          zlo = fminf(zlo, vz);
-          zhi = fmaxf(zhi, vz);
+      // Round 5: the tiles the group's common pre-pass has left (a scattered few, around the minimum) are COMPACTED first, and the
+      // workgroup's lanes are dealt out over them: P lanes per tile, each on every P-th point of the sample -- all lanes busy
+      // instead of two per live tile in mostly-idle wavefronts.  Segments of kBoxSegment tile ids, so that the list stays small.
+      constexpr int kWaves = THREADS / ILCC_WAVE;
+      for (int seg0 = 0; seg0 < n_tiles; seg0 += kBoxSegment) {
+        uint32_t* n_live = &s_cnt[1 + ((seg0 / kBoxSegment) & 1)];   // (two counters in turn: the next segment's reset cannot overtake this one's readers)
+        if (threadIdx.x == 0) *n_live = 0u;
+        __syncthreads();   // (also: s_dead / s_cnt[0] initialised; the previous segment's list no longer read)
+        for (int q = seg0 + (int)threadIdx.x; q < min(seg0 + kBoxSegment, n_tiles); q += THREADS) {   // (kBoxSegment is a multiple of THREADS: whole wavefronts)
+          const bool live = !((s_dead[q >> 5] >> (q & 31)) & 1u);
+          const unsigned long long m = __ballot(live);
+          uint32_t base = 0;
+          if (lane == 0 && m != 0ull) base = atomicAdd(n_live, (uint32_t)__popcll(m));
+          base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+          if (live) s_live[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)q;
         }
-        // (the sum only grows: a wavefront whose 32 tiles are all beaten already stops looking at further points -- most
-        // wavefronts, far from the minimum, after the first few)
-        float lb = 0.f, both = 0.f;
-        // tiles the group's common pre-pass has rejected are not looked at again (a tile's bit is only ever set by its own lane)
-        const bool todo = q < n_tiles && !((s_dead[q >> 5] >> (q & 31)) & 1u);
-        const uint32_t wave_tiles = (uint32_t)__popcll(__ballot(todo && half == 0));
-        for (uint32_t u0 = 0; wave_tiles != 0u && u0 < n_pre; u0 += 2u * kBoxCheck) {
-          wave_evals += wave_tiles * min(2u * kBoxCheck, n_pre - u0);
+        __syncthreads();
+        const uint32_t L = *n_live;   // live tiles of this segment (any order: a tile's sum does not depend on its place in the list)
+        if (L == 0u) continue;
+        // tiles per wavefront: the smallest power of two that deals all L out in one round, at most 32 (P >= 2 lanes per tile)
+        uint32_t tpw = 1u;
+        while (tpw < 32u && tpw * (uint32_t)kWaves < L) tpw <<= 1;
+        const uint32_t P = 64u / tpw, lgP = (uint32_t)__builtin_ctz(P);
+        const uint32_t chk = min(8u, max(2u, 32u / P));   // points per lane between two looks at "is every tile of this wavefront beaten already"
+        const uint32_t slice = (uint32_t)lane & (P - 1u);
+        for (uint32_t j0 = (uint32_t)wid * tpw; j0 < L; j0 += (uint32_t)kWaves * tpw) {
+          const uint32_t j = j0 + ((uint32_t)lane >> lgP);
+          const bool todo = j < L;
+          const int q = (int)s_live[todo ? j : 0u];
+          const int qa = q / ntb, qb = q - qa * ntb;
+          float alo = __builtin_inff(), ahi = -__builtin_inff(), zlo = __builtin_inff(), zhi = -__builtin_inff();
 #pragma unroll
-          for (uint32_t d = 0; d < (uint32_t)kBoxCheck; ++d) {
-            const uint32_t u = u0 + 2u * d + (uint32_t)half;
-            if (u < n_pre && todo) {
-              const float2 v = s_ij[Mi + u];
-              box_term(v.x, v.x, v.y, v.y, alo, ahi, zlo, zhi, Wh, Hh, delta2, lb);
-            }
+          for (int d = 0; d < kTile; ++d) {
+            const float va = s_ay[min(a_org + qa * kTile + d, n_ty - 1)], vz = s_az[min(b_org + qb * kTile + d, n_tz - 1)];
+            alo = fminf(alo, va);
+            ahi = fmaxf(ahi, va);
+            zlo = fminf(zlo, vz);
+            zhi = fmaxf(zhi, vz);
           }
-          both = lb + __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(lb), 0xB1 /*quad_perm [1,0,3,2]*/, 0xf, 0xf, false));
-          if (__ballot(todo && !(both * kBoxSafety > lim_box)) == 0ull) break;
-        }
-        if (half == 0 && todo) {
-          if (both * kBoxSafety > lim_box)
-            atomicOr(&s_dead[q >> 5], 1u << (q & 31));
-          else
-            s_cnt[0] = 1u;
+          // (the sum only grows: a wavefront whose tiles are all beaten already stops looking at further points)
+          float lb = 0.f, both = 0.f;
+          const uint32_t wave_tiles = (uint32_t)__popcll(__ballot(todo && slice == 0u));
+          for (uint32_t u0 = 0; u0 < n_pre; u0 += P * chk) {
+            wave_evals += wave_tiles * min(P * chk, n_pre - u0);
+            for (uint32_t d = 0; d < chk; ++d) {
+              const uint32_t u = u0 + d * P + slice;
+              if (u < n_pre && todo) {
+                const float2 v = s_ij[Mi + u];
+                box_term(v.x, v.x, v.y, v.y, alo, ahi, zlo, zhi, Wh, Hh, delta2, lb);
+              }
+            }
+            both = lanes_sum(lb, P);   // the same bits in all P lanes of a tile
+            if (__ballot(todo && !(both * kBoxSafety > lim_box)) == 0ull) break;
+          }
+          if (slice == 0u && todo) {
+            if (both * kBoxSafety > lim_box)
+              atomicOr(&s_dead[q >> 5], 1u << (q & 31));   // (a tile's bit is only ever set by its own lanes)
+            else
+              s_cnt[0] = 1u;
+          }
         }
       }
       if (lane == 0) s_iters[wid] = wave_evals;   // (s_iters is free until the epilogue)
@@ -847,6 +881,7 @@ __global__ __launch_bounds__(THREADS) void k6_grid_cost(Ctx c, float* volume) {
   __shared__ uint32_t s_iters[THREADS / ILCC_WAVE];
   __shared__ uint32_t s_cnt[THREADS / ILCC_WAVE];
   __shared__ uint32_t s_dead[kBoxTilesMax / 32];   // box pre-pass: one bit per tile of the workgroup
+  __shared__ uint16_t s_live[kBoxSegment];         // box pre-pass: the tiles still alive, compacted
   __shared__ uint32_t s_next;                      // next chunk of tiles to hand to a wavefront
   float2* s_ij = reinterpret_cast<float2*>(smem);
   float* s_hw = reinterpret_cast<float*>(smem + sizeof(float2) * (size_t)c.grid_lds_points);
@@ -856,9 +891,9 @@ __global__ __launch_bounds__(THREADS) void k6_grid_cost(Ctx c, float* volume) {
   const uint32_t M = c.walk_limit ? min(Mall, max(c.walk_limit, Mall >> kSeedShift)) : Mall;
   (void)M;
   if (Mall <= c.grid_lds_points)   // (k5w_walk_order has laid out every frame of at most kGridLdsPointsMax points)
-    grid_cost_body<OOB, VOLUME, true, PRUNE, THREADS>(c, volume, s_ij, s_hw, s_best, s_iters, s_cnt, s_ay, s_az, s_dead, &s_next, blockIdx.x);
+    grid_cost_body<OOB, VOLUME, true, PRUNE, THREADS>(c, volume, s_ij, s_hw, s_best, s_iters, s_cnt, s_ay, s_az, s_dead, s_live, &s_next, blockIdx.x);
   else
-    grid_cost_body<OOB, VOLUME, false, PRUNE, THREADS>(c, volume, s_ij, s_hw, s_best, s_iters, s_cnt, s_ay, s_az, s_dead, &s_next, blockIdx.x);
+    grid_cost_body<OOB, VOLUME, false, PRUNE, THREADS>(c, volume, s_ij, s_hw, s_best, s_iters, s_cnt, s_ay, s_az, s_dead, s_live, &s_next, blockIdx.x);
 }
 
 // k6_group_prepass: ONE box pre-pass for a GROUP of kThetaGroup consecutive thetas, in front of the full pass.  71 % of the (frame,
