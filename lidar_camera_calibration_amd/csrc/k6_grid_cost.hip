@@ -41,6 +41,7 @@
 // for an interior-class point (it is in the board under every translation of the grid: accumulate_interior) --
 // tools/k6_isa_count.sh counts them in the assembly of the probe kernels at the end of this file.
 #include "ilcc_internal.h"
+#include <type_traits>
 #ifdef ILCC_K6_TIMING
 #include <algorithm>
 #include <vector>
@@ -68,7 +69,8 @@ constexpr int kBoxShiftLarge = 2;   // ... 1/4 in the 512-thread instance (frame
 constexpr int kGroupShiftDelta = -1;   // the common pre-pass (k6_group_prepass) looks at M >> (kBoxShift + delta) points: twice each theta's own sample
 static_assert(kBoxShiftSmall + kGroupShiftDelta >= 1 && kBoxShiftLarge + kGroupShiftDelta >= 1,
               "k6_group_prepass stages M >> (kBoxShift + kGroupShiftDelta) <= M / 2 points: launch_group_prepass sizes its LDS for that");
-constexpr int kBoxCheck = 8;          // box pre-pass: points per lane between two looks at "is every tile of this wavefront beaten already"
+constexpr int kBoxFirstRound = 32;                 // box pre-pass: points of the first round (an eighth of the sample, at least this many) when many tiles are alive ...
+constexpr int kBoxFirstRoundFrom = 8;              // ... = from this many tiles per wavefront on (8 lanes or fewer per tile)
 constexpr int kBoxSegment = 1024;                  // box pre-pass: tile ids per compaction round (the list of live tiles: 2 KB of LDS; a multiple of every workgroup size)
 constexpr int kBoxTilesMax = 4096;                 // box pre-pass: tiles per workgroup its LDS bit mask holds
 constexpr float kBoxSafety = 1.f - 0x1p-12f;
@@ -157,7 +159,7 @@ __device__ __forceinline__ void accumulate_interior(const PointTerms& p, float a
 // (pi_lo, pi_hi), (pj_lo, pj_hi): the point's rotated coordinates -- one value each (lo == hi) in a workgroup's own pre-pass, the
 // extremes over the thetas of a group in k6_group_prepass's common pre-pass (fl(p + a) is monotone in p as in a).
 __device__ __forceinline__ void box_term(float pi_lo, float pi_hi, float pj_lo, float pj_hi, float alo, float ahi, float zlo, float zhi,
-                                         float Wh, float Hh, float delta, float& lb) {
+                                         float Wh, float Hh, float delta, float& lb, bool count = true) {
   const float i_lo = pi_lo + alo, i_hi = pi_hi + ahi, j_lo = pj_lo + zlo, j_hi = pj_hi + zhi;
   const float ui_lo = fabsf(i_lo - Wh) - Wh, ui_hi = fabsf(i_hi - Wh) - Wh;
   const float uj_lo = fabsf(j_lo - Hh) - Hh, uj_hi = fabsf(j_hi - Hh) - Hh;
@@ -166,7 +168,7 @@ __device__ __forceinline__ void box_term(float pi_lo, float pi_hi, float pj_lo, 
   const float R = fabsf(__builtin_amdgcn_fmed3f(ui_lo, ui_hi, 0.f)) + fabsf(__builtin_amdgcn_fmed3f(uj_lo, uj_hi, 0.f));
   const float Q = fminf(R, delta);
   const float T = Q * fmaf(-0.5f, Q, R);
-  lb = out_all ? fmaf(T, 0.5f, lb) : lb;
+  lb = (out_all && count) ? fmaf(T, 0.5f, lb) : lb;   // (count = false: a lane past the end of the sample, evaluated branch-free)
 }
 
 // the seed pass's best candidate of frame f and the seed workgroup (= seed theta index) that found it; wave-uniform.
@@ -186,6 +188,109 @@ __device__ __forceinline__ Best seed_argmin(const Ctx& c, uint32_t f, uint32_t& 
   }
   return sb;
 }
+
+// Box pre-pass of one workgroup over the tiles whose bit in s_dead is clear (grid_cost_body's own pre-pass behind the common one's
+// mask; k6_group_prepass over all tiles).  Round 5: the live tiles are COMPACTED into a list and the workgroup's lanes dealt out
+// over them -- P lanes per tile (a power of two, 2 ... 64), each on every P-th point of the sample -- so that all lanes work on
+// tiles that still need work; and when many tiles are alive a first round on the sample's first kBoxFirstRound points weeds out
+// the tiles far from the minimum (most of them) before the survivors get the whole sample.  Segments of kBoxSegment tile ids keep
+// the list small.  A tile's bound is a sum in an order that depends on P: kBoxSafety covers that (it is a lower bound in real
+// arithmetic whatever the order; see box_term).  Sets the tile's bit in s_dead when its bound exceeds lim_box; *s_alive = 1 when
+// a tile survives the whole sample.  cnt: two counters used in turn.  interval(u): the u-th point's (i_lo, i_hi, j_lo, j_hi).
+// Returns the (point, tile) evaluations this wavefront really did (wave-uniform).  Ends with every thread past its last barrier
+// -- the caller synchronises before it reads s_dead / *s_alive.
+template <int THREADS, class Interval>
+__device__ __forceinline__ uint32_t box_prepass_rounds(int n_tiles, int ntb, int a_org, int b_org, int n_ty, int n_tz, const float* s_ay,
+                                                       const float* s_az, uint32_t* s_dead, uint16_t* s_live, uint32_t* cnt, uint32_t* s_alive,
+                                                       uint32_t n_pre, float lim_box, float Wh, float Hh, float delta2, Interval interval) {
+  constexpr int kWaves = THREADS / ILCC_WAVE;
+  const int lane = lane_id();
+  const int wid = __builtin_amdgcn_readfirstlane(wave_id());
+  uint32_t wave_evals = 0, turn = 0;
+  for (int seg0 = 0; seg0 < n_tiles; seg0 += kBoxSegment) {
+    for (int round = 0; round < 2; ++round) {
+      uint32_t* n_live = &cnt[turn & 1u];   // (two counters in turn: the next compaction's reset cannot overtake this one's readers)
+      ++turn;
+      if (threadIdx.x == 0) *n_live = 0u;
+      __syncthreads();   // (also: s_dead initialised / the previous round's bits set; the previous list no longer read)
+      for (int q = seg0 + (int)threadIdx.x; q < min(seg0 + kBoxSegment, n_tiles); q += THREADS) {   // (kBoxSegment is a multiple of THREADS: whole wavefronts)
+        const bool live = !((s_dead[q >> 5] >> (q & 31)) & 1u);
+        const unsigned long long m = __ballot(live);
+        uint32_t base = 0;
+        if (lane == 0 && m != 0ull) base = atomicAdd(n_live, (uint32_t)__popcll(m));
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        if (live) s_live[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)q;
+      }
+      __syncthreads();
+      const uint32_t L = *n_live;   // live tiles of this segment (any order: a tile's sum does not depend on its place in the list)
+      if (L == 0u) break;
+      // tiles per wavefront: the smallest power of two that deals all L out in one go, at most 32 (P >= 2 lanes per tile)
+      uint32_t tpw = 1u;
+      while (tpw < 32u && tpw * (uint32_t)kWaves < L) tpw <<= 1;
+      const uint32_t P = 64u / tpw, lgP = (uint32_t)__builtin_ctz(P);
+      const uint32_t chk = min(8u, max(2u, 32u / P));   // points per lane between two looks at "is every tile of this wavefront beaten already"
+      // many tiles alive: a first round on a prefix of the sample; few: the whole sample at once
+      const uint32_t n_first = max((uint32_t)kBoxFirstRound, n_pre >> 3);
+      const bool first = round == 0 && tpw >= (uint32_t)kBoxFirstRoundFrom && n_pre > 2u * n_first;
+      const uint32_t n_use = first ? n_first : n_pre;
+      const uint32_t slice = (uint32_t)lane & (P - 1u);
+      for (uint32_t j0 = (uint32_t)wid * tpw; j0 < L; j0 += (uint32_t)kWaves * tpw) {
+        const uint32_t j = j0 + ((uint32_t)lane >> lgP);
+        const bool todo = j < L;
+        const int q = (int)s_live[todo ? j : 0u];
+        const int qa = q / ntb, qb = q - qa * ntb;
+        float alo = __builtin_inff(), ahi = -__builtin_inff(), zlo = __builtin_inff(), zhi = -__builtin_inff();
+#pragma unroll
+        for (int d = 0; d < kTile; ++d) {
+          const float va = s_ay[min(a_org + qa * kTile + d, n_ty - 1)], vz = s_az[min(b_org + qb * kTile + d, n_tz - 1)];
+          alo = fminf(alo, va);
+          ahi = fmaxf(ahi, va);
+          zlo = fminf(zlo, vz);
+          zhi = fmaxf(zhi, vz);
+        }
+        // (the sum only grows: a wavefront whose tiles are all beaten already stops looking at further points)
+        float lb = 0.f, both = 0.f;
+        const uint32_t wave_tiles = (uint32_t)__popcll(__ballot(todo && slice == 0u));
+        for (uint32_t u0 = 0; u0 < n_use; u0 += P * chk) {
+          wave_evals += wave_tiles * min(P * chk, n_use - u0);
+          auto block = [&](auto n) {   // unrolled and branch-free, the LDS reads of four points issued together
+            constexpr int N = decltype(n)::value, SUB = N >= 4 ? 4 : N;
+#pragma unroll
+            for (int d0 = 0; d0 < N; d0 += SUB) {
+              float4 v[SUB];
+              bool ok[SUB];
+#pragma unroll
+              for (int e = 0; e < SUB; ++e) {
+                const uint32_t u = u0 + (uint32_t)(d0 + e) * P + slice;
+                ok[e] = u < n_use && todo;
+                v[e] = interval(min(u, n_use - 1u));
+              }
+#pragma unroll
+              for (int e = 0; e < SUB; ++e) box_term(v[e].x, v[e].y, v[e].z, v[e].w, alo, ahi, zlo, zhi, Wh, Hh, delta2, lb, ok[e]);
+            }
+          };
+          if (chk == 8u)
+            block(std::integral_constant<int, 8>{});
+          else if (chk == 4u)
+            block(std::integral_constant<int, 4>{});
+          else
+            block(std::integral_constant<int, 2>{});
+          both = lanes_sum(lb, P);   // the same bits in all P lanes of a tile
+          if (__ballot(todo && !(both * kBoxSafety > lim_box)) == 0ull) break;
+        }
+        if (slice == 0u && todo) {
+          if (both * kBoxSafety > lim_box)
+            atomicOr(&s_dead[q >> 5], 1u << (q & 31));   // (a tile's bit is only ever set by its own lanes)
+          else if (!first)
+            *s_alive = 1u;
+        }
+      }
+      if (!first) break;   // (uniform: first depends on L only)
+    }
+  }
+  return wave_evals;
+}
+
 
 template <bool OOB, bool VOLUME, bool LDS_POINTS, bool PRUNE, int THREADS>
 __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, float2* s_ij, float* s_hw, Best* s_best,
@@ -335,69 +440,12 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
       if (threadIdx.x == 0) s_cnt[0] = 0u;   // "a tile of this workgroup is still alive" (s_cnt is free until the epilogue)
       const uint32_t n_pre = min(max(c.box_points, Mfull >> kBoxShift), M - Mi);   // the frame's bound grows with its point count: so must the sample that has to exceed it
       const float lim_box = 0.5f * (1.f + kTieEps) * __uint_as_float(gb_bits);
-      uint32_t wave_evals = 0;   // (point, tile) evaluations this wavefront really did (wave-uniform)
-      // Round 5: the tiles the group's common pre-pass has left (a scattered few, around the minimum) are COMPACTED first, and the
-      // workgroup's lanes are dealt out over them: P lanes per tile, each on every P-th point of the sample -- all lanes busy
-      // instead of two per live tile in mostly-idle wavefronts.  Segments of kBoxSegment tile ids, so that the list stays small.
-      constexpr int kWaves = THREADS / ILCC_WAVE;
-      for (int seg0 = 0; seg0 < n_tiles; seg0 += kBoxSegment) {
-        uint32_t* n_live = &s_cnt[1 + ((seg0 / kBoxSegment) & 1)];   // (two counters in turn: the next segment's reset cannot overtake this one's readers)
-        if (threadIdx.x == 0) *n_live = 0u;
-        __syncthreads();   // (also: s_dead / s_cnt[0] initialised; the previous segment's list no longer read)
-        for (int q = seg0 + (int)threadIdx.x; q < min(seg0 + kBoxSegment, n_tiles); q += THREADS) {   // (kBoxSegment is a multiple of THREADS: whole wavefronts)
-          const bool live = !((s_dead[q >> 5] >> (q & 31)) & 1u);
-          const unsigned long long m = __ballot(live);
-          uint32_t base = 0;
-          if (lane == 0 && m != 0ull) base = atomicAdd(n_live, (uint32_t)__popcll(m));
-          base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-          if (live) s_live[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)q;
-        }
-        __syncthreads();
-        const uint32_t L = *n_live;   // live tiles of this segment (any order: a tile's sum does not depend on its place in the list)
-        if (L == 0u) continue;
-        // tiles per wavefront: the smallest power of two that deals all L out in one round, at most 32 (P >= 2 lanes per tile)
-        uint32_t tpw = 1u;
-        while (tpw < 32u && tpw * (uint32_t)kWaves < L) tpw <<= 1;
-        const uint32_t P = 64u / tpw, lgP = (uint32_t)__builtin_ctz(P);
-        const uint32_t chk = min(8u, max(2u, 32u / P));   // points per lane between two looks at "is every tile of this wavefront beaten already"
-        const uint32_t slice = (uint32_t)lane & (P - 1u);
-        for (uint32_t j0 = (uint32_t)wid * tpw; j0 < L; j0 += (uint32_t)kWaves * tpw) {
-          const uint32_t j = j0 + ((uint32_t)lane >> lgP);
-          const bool todo = j < L;
-          const int q = (int)s_live[todo ? j : 0u];
-          const int qa = q / ntb, qb = q - qa * ntb;
-          float alo = __builtin_inff(), ahi = -__builtin_inff(), zlo = __builtin_inff(), zhi = -__builtin_inff();
-#pragma unroll
-          for (int d = 0; d < kTile; ++d) {
-            const float va = s_ay[min(a_org + qa * kTile + d, n_ty - 1)], vz = s_az[min(b_org + qb * kTile + d, n_tz - 1)];
-            alo = fminf(alo, va);
-            ahi = fmaxf(ahi, va);
-            zlo = fminf(zlo, vz);
-            zhi = fmaxf(zhi, vz);
-          }
-          // (the sum only grows: a wavefront whose tiles are all beaten already stops looking at further points)
-          float lb = 0.f, both = 0.f;
-          const uint32_t wave_tiles = (uint32_t)__popcll(__ballot(todo && slice == 0u));
-          for (uint32_t u0 = 0; u0 < n_pre; u0 += P * chk) {
-            wave_evals += wave_tiles * min(P * chk, n_pre - u0);
-            for (uint32_t d = 0; d < chk; ++d) {
-              const uint32_t u = u0 + d * P + slice;
-              if (u < n_pre && todo) {
-                const float2 v = s_ij[Mi + u];
-                box_term(v.x, v.x, v.y, v.y, alo, ahi, zlo, zhi, Wh, Hh, delta2, lb);
-              }
-            }
-            both = lanes_sum(lb, P);   // the same bits in all P lanes of a tile
-            if (__ballot(todo && !(both * kBoxSafety > lim_box)) == 0ull) break;
-          }
-          if (slice == 0u && todo) {
-            if (both * kBoxSafety > lim_box)
-              atomicOr(&s_dead[q >> 5], 1u << (q & 31));   // (a tile's bit is only ever set by its own lanes)
-            else
-              s_cnt[0] = 1u;
-          }
-        }
-      }
+      // (tiles the group's common pre-pass has rejected are not looked at again)
+      const uint32_t wave_evals = box_prepass_rounds<THREADS>(n_tiles, ntb, a_org, b_org, n_ty, n_tz, s_ay, s_az, s_dead, s_live, s_cnt + 1, s_cnt, n_pre,
+                                                              lim_box, Wh, Hh, delta2, [&](uint32_t u) {
+                                                                const float2 v = s_ij[Mi + u];
+                                                                return make_float4(v.x, v.x, v.y, v.y);
+                                                              });
       if (lane == 0) s_iters[wid] = wave_evals;   // (s_iters is free until the epilogue)
       __syncthreads();
       for (int w = 0; w < THREADS / ILCC_WAVE; ++w) box_evals += s_iters[w];
@@ -911,6 +959,8 @@ __global__ __launch_bounds__(THREADS) void k6_group_prepass(Ctx c, uint32_t* grp
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ uint32_t s_iters[THREADS / ILCC_WAVE];
   __shared__ uint32_t s_dead3[kBoxTilesMax / 32];
+  __shared__ uint16_t s_live[kBoxSegment];   // the tiles still alive, compacted (box_prepass_rounds)
+  __shared__ uint32_t s_cnt2[2];
   __shared__ uint32_t s_any;
   constexpr int kBoxShift = (THREADS == kGridThreadsLarge && kGridThreadsLarge != kGridThreads) ? kBoxShiftLarge : kBoxShiftSmall;
   const uint32_t f = blockIdx.y;
@@ -962,44 +1012,8 @@ __global__ __launch_bounds__(THREADS) void k6_group_prepass(Ctx c, uint32_t* grp
   __syncthreads();
   const float Wh = 0.5f * (float)c.p.board_w, Hh = 0.5f * (float)c.p.board_h, delta2 = (float)c.p.huber_delta;
   const float lim_box = 0.5f * (1.f + kTieEps) * __uint_as_float(__hip_atomic_load(c.grid_bound + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-  const int half = (int)(threadIdx.x & 1u);
-  uint32_t wave_evals = 0;
-  for (int q0 = 0; q0 < n_tiles; q0 += THREADS / 2) {
-    const int q = q0 + (int)(threadIdx.x >> 1);
-    const int qc = min(q, n_tiles - 1);
-    const int qa = qc / ntb, qb = qc - qa * ntb;
-    float alo = __builtin_inff(), ahi = -__builtin_inff(), zlo = __builtin_inff(), zhi = -__builtin_inff();
-#pragma unroll
-    for (int d = 0; d < kTile; ++d) {
-      const float va = s_ay[min(qa * kTile + d, n_ty - 1)], vz = s_az[min(qb * kTile + d, n_tz - 1)];
-      alo = fminf(alo, va);
-      ahi = fmaxf(ahi, va);
-      zlo = fminf(zlo, vz);
-      zhi = fmaxf(zhi, vz);
-    }
-    float lb = 0.f, both = 0.f;
-    const bool todo = q < n_tiles;
-    const uint32_t wave_tiles = (uint32_t)__popcll(__ballot(todo && half == 0));
-    for (uint32_t u0 = 0; wave_tiles != 0u && u0 < n_pre; u0 += 2u * kBoxCheck) {
-      wave_evals += wave_tiles * min(2u * kBoxCheck, n_pre - u0);
-#pragma unroll
-      for (uint32_t d = 0; d < (uint32_t)kBoxCheck; ++d) {
-        const uint32_t u = u0 + 2u * d + (uint32_t)half;
-        if (u < n_pre && todo) {
-          const float4 v = s_w4[u];
-          box_term(v.x, v.y, v.z, v.w, alo, ahi, zlo, zhi, Wh, Hh, delta2, lb);
-        }
-      }
-      both = lb + __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(lb), 0xB1 /*quad_perm [1,0,3,2]*/, 0xf, 0xf, false));
-      if (__ballot(todo && !(both * kBoxSafety > lim_box)) == 0ull) break;
-    }
-    if (half == 0 && todo) {
-      if (both * kBoxSafety > lim_box)
-        atomicOr(&s_dead3[q >> 5], 1u << (q & 31));
-      else
-        s_any = 1u;
-    }
-  }
+  const uint32_t wave_evals = box_prepass_rounds<THREADS>(n_tiles, ntb, 0, 0, n_ty, n_tz, s_ay, s_az, s_dead3, s_live, s_cnt2, &s_any, n_pre, lim_box, Wh, Hh,
+                                                          delta2, [&](uint32_t u) { return s_w4[u]; });
   if (lane == 0) s_iters[wid] = wave_evals;
   __syncthreads();
   const bool any_alive = s_any != 0u;
