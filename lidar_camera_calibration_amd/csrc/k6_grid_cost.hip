@@ -1056,6 +1056,7 @@ void launch_group_prepass(const Ctx& c, hipStream_t s, uint32_t* grp_alive, uint
 // candidate is cut, or listed as a near tie, with 2e-5 to spare -- 20 x the rounding of an fp32 sum of a thousand terms.
 // Batches of fewer than kLocateMinFrames frames keep the three launches: there a frame's 17 workgroups are what fills the chip.
 constexpr int kLocateThreads = 512;       // measured (k frames/s, one MI355X): 256: 1056, 512: 1089, 1024: 1011-1033
+constexpr int kSeedPeek = 16;             // walk positions of every seed tile a wavefront looks at before it chooses which tile to evaluate first
 constexpr int kAnchorThetas = 3;          // thetas around the refinement's argmin the anchor scores (1: locate 0.26 -> 0.21 ms alone, full pass 0.36 -> 0.40: a wash)
 constexpr int kAnchorParts = (kLocateThreads / 64) / kAnchorThetas;  // wavefronts sharing a theta's walk
 constexpr int kLocateWaves = kLocateThreads / ILCC_WAVE;
@@ -1218,7 +1219,40 @@ __global__ __launch_bounds__(kLocateThreads) void k6_locate(Ctx c, LocatePlan lp
     const int nta = (lp.n_ty2 + kTile - 1) / kTile, ntb = (lp.n_tz2 + kTile - 1) / kTile, per = nta * ntb, n_tiles = n_th2 * per;
     Best best{__builtin_inff(), 0xFFFFFFFFu, 0xFFFFFFFFu};
     uint32_t best_ab = 0;
-    for (int t = wid; t < n_tiles; t += kLocateWaves) {
+    // The order of the tiles never changes the result (only provably losing candidates are cut, ties never), but it decides how
+    // soon the sample bound is tight.  Every wavefront therefore first looks at the first kSeedPeek walk positions of each of
+    // its tiles, evaluates the most promising one in full -- one of the eight is nearly always in the right basin -- and only then
+    // walks the others, which now die at their first tests.
+    int t_first = -1;
+    {
+      float peek_best = __builtin_inff();
+      for (int t = wid; t < n_tiles; t += kLocateWaves) {
+        const int k2 = t / per, q = t - k2 * per, ta = q / ntb, tb = q - ta * ntb;
+        const int ia = ta * kTile + my_a, ib = tb * kTile + my_b;
+        const float2* rot = s_rot + (size_t)k2 * lp.sample_cap;
+        const float ay = s_ay2[min(ia, lp.n_ty2 - 1)], az = s_az2[min(ib, lp.n_tz2 - 1)];
+        float A0 = 0.f, A1 = 0.f;
+        for (uint32_t at0 = n_in; at0 < min(Ms, n_in + (uint32_t)kSeedPeek); at0 += kSlices) {
+          const uint32_t at = at0 + (uint32_t)my_s;
+          if (at < Ms) {
+            const float2 v = rot[at];
+            accumulate<true>(PointTerms{v.x, v.y, s_hw[at]}, ay, az, Wh, Hh, delta2, A0, A1);
+          }
+        }
+        pts_done += min(Ms - n_in, (uint32_t)kSeedPeek);
+        float pm = (ia < lp.n_ty2 && ib < lp.n_tz2) ? fminf(quad_sum(A0), quad_sum(A1)) : __builtin_inff();
+#pragma unroll
+        for (int o = ILCC_WAVE / 2; o > 0; o >>= 1) pm = fminf(pm, __shfl_xor(pm, o, ILCC_WAVE));
+        if (pm < peek_best) {   // (wave-uniform)
+          peek_best = pm;
+          t_first = t;
+        }
+      }
+    }
+    const int n_mine = (n_tiles - wid + kLocateWaves - 1) / kLocateWaves;   // tiles of this wavefront
+    for (int it = (t_first >= 0 ? -1 : 0); it < n_mine; ++it) {
+      const int t = it < 0 ? t_first : wid + it * kLocateWaves;
+      if (it >= 0 && t == t_first) continue;
       const int k2 = t / per, q = t - k2 * per, ta = q / ntb, tb = q - ta * ntb;
       const int ia = ta * kTile + my_a, ib = tb * kTile + my_b;
       const bool owner = ia < lp.n_ty2 && ib < lp.n_tz2;
