@@ -293,8 +293,10 @@ def main():
     est.set_result_mode(N.RESULTS_COMPACT)
     # ilcc_reserve: the sensor is known, so the handle's on-chip capacities are set up front and the warm-up batches take the
     # same kernels as the timed ones (a fresh handle grows them after its first batch: INTEGRATION.md, "Sizing")
-    # (config 5: the bench's frames hold up to 6 170 labelled points)
-    est.reserve(6400, 20000) if args.config == 5 else est.reserve(2048, 2560)
+    # (labelled points per frame: the closest boards of the sensor model hold 1 784 (config 2) and 6 170 (config 5): the next
+    # multiple of 256 -- at 1 792 seven K6 workgroups fit a CU's LDS, at 2 048 six: 1 228 k vs 1 255 k frames/s)
+    res_lab = int(os.environ.get("ILCC_BENCH_RESERVE_LABELLED", "0")) or (6400 if args.config == 5 else 1792)   # (env: LDS staging A/B)
+    est.reserve(res_lab, 20000 if args.config == 5 else 2560)
     n_cand = params.n_th * params.n_ty * params.n_tz * 2
     depth = max(1, min(args.in_flight, int(os.environ.get("ILCC_BENCH_MAX_DEPTH", "4"))))
 

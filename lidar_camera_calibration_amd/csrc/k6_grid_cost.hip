@@ -71,7 +71,10 @@ static_assert(kBoxShiftSmall + kGroupShiftDelta >= 1 && kBoxShiftLarge + kGroupS
               "k6_group_prepass stages M >> (kBoxShift + kGroupShiftDelta) <= M / 2 points: launch_group_prepass sizes its LDS for that");
 constexpr int kBoxFirstRound = 32;                 // box pre-pass: points of the first round (an eighth of the sample, at least this many) when many tiles are alive ...
 constexpr int kBoxFirstRoundFrom = 8;              // ... = from this many tiles per wavefront on (8 lanes or fewer per tile)
-constexpr int kBoxSegment = 1024;                  // box pre-pass: tile ids per compaction round (the list of live tiles: 2 KB of LDS; a multiple of every workgroup size)
+// box pre-pass: tile ids per compaction round = the length of the list of live tiles in LDS, a multiple of the workgroup size (the
+// 256-thread instance: 512 B -- with 1 792 staged points a workgroup then needs 22.9 KB and SEVEN fit a CU's 160 KB)
+template <int THREADS>
+constexpr int kBoxSegment = THREADS <= 256 ? 256 : 1024;
 constexpr int kBoxTilesMax = 4096;                 // box pre-pass: tiles per workgroup its LDS bit mask holds
 constexpr float kBoxSafety = 1.f - 0x1p-12f;
 constexpr int kBoundRefresh = 256;                  // points between reloads of the frame's shared bound
@@ -193,7 +196,7 @@ __device__ __forceinline__ Best seed_argmin(const Ctx& c, uint32_t f, uint32_t& 
 // mask; k6_group_prepass over all tiles).  Round 5: the live tiles are COMPACTED into a list and the workgroup's lanes dealt out
 // over them -- P lanes per tile (a power of two, 2 ... 64), each on every P-th point of the sample -- so that all lanes work on
 // tiles that still need work; and when many tiles are alive a first round on the sample's first kBoxFirstRound points weeds out
-// the tiles far from the minimum (most of them) before the survivors get the whole sample.  Segments of kBoxSegment tile ids keep
+// the tiles far from the minimum (most of them) before the survivors get the whole sample.  Segments of kBoxSegment<THREADS> tile ids keep
 // the list small.  A tile's bound is a sum in an order that depends on P: kBoxSafety covers that (it is a lower bound in real
 // arithmetic whatever the order; see box_term).  Sets the tile's bit in s_dead when its bound exceeds lim_box; *s_alive = 1 when
 // a tile survives the whole sample.  cnt: two counters used in turn.  interval(u): the u-th point's (i_lo, i_hi, j_lo, j_hi).
@@ -207,13 +210,13 @@ __device__ __forceinline__ uint32_t box_prepass_rounds(int n_tiles, int ntb, int
   const int lane = lane_id();
   const int wid = __builtin_amdgcn_readfirstlane(wave_id());
   uint32_t wave_evals = 0, turn = 0;
-  for (int seg0 = 0; seg0 < n_tiles; seg0 += kBoxSegment) {
+  for (int seg0 = 0; seg0 < n_tiles; seg0 += kBoxSegment<THREADS>) {
     for (int round = 0; round < 2; ++round) {
       uint32_t* n_live = &cnt[turn & 1u];   // (two counters in turn: the next compaction's reset cannot overtake this one's readers)
       ++turn;
       if (threadIdx.x == 0) *n_live = 0u;
       __syncthreads();   // (also: s_dead initialised / the previous round's bits set; the previous list no longer read)
-      for (int q = seg0 + (int)threadIdx.x; q < min(seg0 + kBoxSegment, n_tiles); q += THREADS) {   // (kBoxSegment is a multiple of THREADS: whole wavefronts)
+      for (int q = seg0 + (int)threadIdx.x; q < min(seg0 + kBoxSegment<THREADS>, n_tiles); q += THREADS) {   // (the segment is a multiple of THREADS: whole wavefronts)
         const bool live = !((s_dead[q >> 5] >> (q & 31)) & 1u);
         const unsigned long long m = __ballot(live);
         uint32_t base = 0;
@@ -929,7 +932,7 @@ __global__ __launch_bounds__(THREADS) void k6_grid_cost(Ctx c, float* volume) {
   __shared__ uint32_t s_iters[THREADS / ILCC_WAVE];
   __shared__ uint32_t s_cnt[THREADS / ILCC_WAVE];
   __shared__ uint32_t s_dead[kBoxTilesMax / 32];   // box pre-pass: one bit per tile of the workgroup
-  __shared__ uint16_t s_live[kBoxSegment];         // box pre-pass: the tiles still alive, compacted
+  __shared__ uint16_t s_live[kBoxSegment<THREADS>];         // box pre-pass: the tiles still alive, compacted
   __shared__ uint32_t s_next;                      // next chunk of tiles to hand to a wavefront
   float2* s_ij = reinterpret_cast<float2*>(smem);
   float* s_hw = reinterpret_cast<float*>(smem + sizeof(float2) * (size_t)c.grid_lds_points);
@@ -959,7 +962,7 @@ __global__ __launch_bounds__(THREADS) void k6_group_prepass(Ctx c, uint32_t* grp
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ uint32_t s_iters[THREADS / ILCC_WAVE];
   __shared__ uint32_t s_dead3[kBoxTilesMax / 32];
-  __shared__ uint16_t s_live[kBoxSegment];   // the tiles still alive, compacted (box_prepass_rounds)
+  __shared__ uint16_t s_live[kBoxSegment<THREADS>];   // the tiles still alive, compacted (box_prepass_rounds)
   __shared__ uint32_t s_cnt2[2];
   __shared__ uint32_t s_any;
   constexpr int kBoxShift = (THREADS == kGridThreadsLarge && kGridThreadsLarge != kGridThreads) ? kBoxShiftLarge : kBoxShiftSmall;

@@ -13,7 +13,7 @@ clouds, clicks, gts, _ = synth.make_batch(F, seed=0xC0FFEE)
 d_c = torch.from_numpy(clouds).cuda(); d_k = torch.from_numpy(clicks).cuda()
 p = N.default_params(); p.solver = solver
 est = LidarCornersBatch(F, 28800, p)
-est.reserve(2048, 2560)
+est.reserve(1792, 2560)
 rows = []
 for r in range(reps):
     est.extract_device(d_c.data_ptr(), F, 28800, d_k.data_ptr())

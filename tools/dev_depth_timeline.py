@@ -28,7 +28,7 @@ if CONFIG == 5:
     params.ty_step = params.tz_step = 0.10 / 64
 est = LidarCornersBatch(F, n_points, params, device=0)
 est.set_result_mode(N.RESULTS_COMPACT)
-est.reserve(6000, 20000) if CONFIG == 5 else est.reserve(2048, 2560)
+est.reserve(6000, 20000) if CONFIG == 5 else est.reserve(1792, 2560)
 L = est._lib
 
 

@@ -22,7 +22,7 @@ dev = torch.device("cuda", 0)
 d_clouds = [torch.from_numpy(clouds.reshape(B, F, n_points, 4)[b]).to(dev) for b in range(B)]
 d_clicks = [torch.from_numpy(clicks.reshape(B, F, 3)[b]).to(dev) for b in range(B)]
 est = LidarCornersBatch(F, n_points, params, device=0)
-est.reserve(2048, 2560)
+est.reserve(1792, 2560)
 
 
 T = {"submit": 0.0, "wait": 0.0, "n": 0, "life": 0.0, "gpu": 0.0}

@@ -31,7 +31,7 @@ est = LidarCornersBatch(F, n, params)
 # every dispatch takes the steady-state kernels: the capacities are reserved exactly as bench.py reserves them (config 5:
 # 6000 labelled points = 72 KB per K6 workgroup, two per CU like the bench's; reserving the maximum, 8192 = 96 KB, would
 # profile a one-workgroup-per-CU full pass the bench never runs).  The first batch is still a warm-up (pmc_summary.py drops it).
-est.reserve(6400, 20000) if config == 5 else est.reserve(2048, 2560)
+est.reserve(6400, 20000) if config == 5 else est.reserve(1792, 2560)
 for _ in range(4):
     est.extract_device(d_c.data_ptr(), F, n, d_k.data_ptr())
 t = est.timing()
