@@ -31,8 +31,14 @@ __device__ __forceinline__ Box make_box(const Ctx& c, uint32_t f) {
   return b;
 }
 
+template <bool FINITE_BOX>
 __device__ __forceinline__ bool keep_point(const float4 q, const Box& b) {
-  // non-finite x/y/z are dropped by every PassThrough; limits are inclusive (:54,59,64)
+  // non-finite x/y/z are dropped by every PassThrough; limits are inclusive (:54,59,64).  Against a box of finite limits the
+  // inclusive comparisons alone say so: a NaN fails every one of them, an infinity the one against the finite limit beyond it
+  // -- the same truth table as "finite and not (below or above)" at half the instructions (K1 is HBM-bound alone, but beside the
+  // other batches' kernels its instructions count like everyone's).
+  if (FINITE_BOX)
+    return q.z >= b.lo[2] && q.z <= b.hi[2] && q.x >= b.lo[0] && q.x <= b.hi[0] && q.y >= b.lo[1] && q.y <= b.hi[1];
   const bool fin = isfinite(q.x) && isfinite(q.y) && isfinite(q.z);
   const bool in = !(q.z < b.lo[2] || q.z > b.hi[2]) && !(q.x < b.lo[0] || q.x > b.hi[0]) &&
                   !(q.y < b.lo[1] || q.y > b.hi[1]);
@@ -93,14 +99,26 @@ __global__ __launch_bounds__(kCropThreads) void k1_roi_count(Ctx c) {
         q[k] = make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
+    const bool finite_box = isfinite(b.lo[0]) && isfinite(b.hi[0]) && isfinite(b.lo[1]) && isfinite(b.hi[1]) && isfinite(b.lo[2]) && isfinite(b.hi[2]);
+    const uint32_t left = (uint32_t)(cend - cbeg);   // points of this chunk (<= kCropChunk)
+    if (finite_box && c.online_tier != 1u) {   // (uniform) the offline path: a finite ROI box, no count of the finite points
 #pragma unroll
-    for (int k = 0; k < kTrips; ++k) {
-      const uint64_t i = cbeg + (uint64_t)k * kCropThreads + threadIdx.x;
-      const bool keep = (i < cend) && keep_point(q[k], b);
-      const unsigned long long m = __ballot(keep);
-      if (lane_id() == 0) masks[k * (kCropThreads / ILCC_WAVE) + wave_id()] = m;   // order (trip, wavefront) = input order
-      cnt += keep ? 1u : 0u;
-      fin += ((i < cend) && isfinite(q[k].x) && isfinite(q[k].y) && isfinite(q[k].z)) ? 1u : 0u;
+      for (int k = 0; k < kTrips; ++k) {
+        const bool keep = ((uint32_t)k * kCropThreads + threadIdx.x < left) && keep_point<true>(q[k], b);
+        const unsigned long long m = __ballot(keep);
+        if (lane_id() == 0) masks[k * (kCropThreads / ILCC_WAVE) + wave_id()] = m;   // order (trip, wavefront) = input order
+        cnt += keep ? 1u : 0u;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < kTrips; ++k) {
+        const bool mine = (uint32_t)k * kCropThreads + threadIdx.x < left;
+        const bool keep = mine && keep_point<false>(q[k], b);
+        const unsigned long long m = __ballot(keep);
+        if (lane_id() == 0) masks[k * (kCropThreads / ILCC_WAVE) + wave_id()] = m;
+        cnt += keep ? 1u : 0u;
+        fin += (mine && isfinite(q[k].x) && isfinite(q[k].y) && isfinite(q[k].z)) ? 1u : 0u;
+      }
     }
   }
   __shared__ uint32_t sc[17];
