@@ -319,6 +319,13 @@ int32_t ilcc_fetch_results(ilcc_handle* h, uint32_t first, uint32_t n, ilcc_resu
 int32_t ilcc_chessboard_by_point_batch(ilcc_handle* h, const float* xyzi, const uint64_t* offsets,
                                        uint32_t n_frames, const float* points, int32_t min_plane_points,
                                        ilcc_result* out);
+/* The same call in two halves (like ilcc_submit_batch / ilcc_wait: up to four calls in flight per handle, the H2D copy of one
+ * overlapping the kernels of the others; `xyzi` and `points` must stay valid -- and should be pinned -- until the wait returns).
+ * ilcc_fetch_cloud / ilcc_fetch_classes then refer to the call last waited for.  For callers that hold more than one scan at a
+ * time (a recorded sequence); the online node (lidar_chessboard_online.cpp:91-101) has one and uses the call above. */
+int32_t ilcc_submit_chessboard_by_point(ilcc_handle* h, const float* xyzi, const uint64_t* offsets, uint32_t n_frames,
+                                        const float* points, int32_t* ticket);
+int32_t ilcc_wait_chessboard_by_point(ilcc_handle* h, int32_t ticket, int32_t min_plane_points, ilcc_result* out);
 /* color_by_gray_zone classes (LidarCornersEst.cpp:452-499) of the last batch's plane cloud:
  * 0 black (I < gray_zone[0]), 1 gray, 2 white (I > gray_zone[1]).  Returns the point count. */
 int64_t ilcc_fetch_classes(ilcc_handle* h, uint32_t frame, uint8_t* out_class, uint64_t cap_points);

@@ -29,7 +29,7 @@ CLOUD_ROI, CLOUD_CLUSTER, CLOUD_CHESSBOARD, CLOUD_PCA, CLOUD_OPTIM = range(5)
 EXPORTS = [
     "ilcc_abi_version", "ilcc_strerror", "ilcc_last_error", "ilcc_default_params",
     "ilcc_set_chessboard_param", "ilcc_create", "ilcc_destroy", "ilcc_set_params", "ilcc_reserve", "ilcc_extract",
-    "ilcc_extract_batch", "ilcc_extract_batch_device", "ilcc_submit_batch_device", "ilcc_submit_batch", "ilcc_wait", "ilcc_wait_records_device", "ilcc_fetch_cloud", "ilcc_fetch_labelled", "ilcc_fetch_walk", "ilcc_chessboard_by_point_batch", "ilcc_fetch_classes",
+    "ilcc_extract_batch", "ilcc_extract_batch_device", "ilcc_submit_batch_device", "ilcc_submit_batch", "ilcc_wait", "ilcc_wait_records_device", "ilcc_fetch_cloud", "ilcc_fetch_labelled", "ilcc_fetch_walk", "ilcc_chessboard_by_point_batch", "ilcc_submit_chessboard_by_point", "ilcc_wait_chessboard_by_point", "ilcc_fetch_classes",
     "ilcc_grid_cost", "ilcc_grid_solve", "ilcc_pattern_refine", "ilcc_get_theta_t", "ilcc_get_timing", "ilcc_reset_timing",
     "ilcc_save_corners2txt", "ilcc_read_lidar_corners",
     "ilcc_set_result_mode", "ilcc_wait_compact", "ilcc_record_floats", "ilcc_fetch_results",
@@ -173,6 +173,10 @@ def lib():
         L.ilcc_wait_records_device.restype = C.c_int32
         L.ilcc_chessboard_by_point_batch.argtypes = [vp, fp, C.POINTER(C.c_uint64), C.c_uint32, fp, C.c_int32, rp]
         L.ilcc_chessboard_by_point_batch.restype = C.c_int32
+        L.ilcc_submit_chessboard_by_point.argtypes = [vp, C.c_void_p, C.POINTER(C.c_uint64), C.c_uint32, C.c_void_p, C.POINTER(C.c_int32)]
+        L.ilcc_submit_chessboard_by_point.restype = C.c_int32
+        L.ilcc_wait_chessboard_by_point.argtypes = [vp, C.c_int32, C.c_int32, rp]
+        L.ilcc_wait_chessboard_by_point.restype = C.c_int32
         L.ilcc_fetch_classes.argtypes = [vp, C.c_uint32, C.POINTER(C.c_uint8), C.c_uint64]
         L.ilcc_fetch_classes.restype = C.c_int64
         L.ilcc_fetch_cloud.argtypes = [vp, C.c_uint32, C.c_int32, fp, C.c_uint64]

@@ -1315,6 +1315,23 @@ int32_t ilcc_extract(ilcc_handle* h, const float* xyzi, uint32_t n, const float 
   return ilcc_extract_batch(h, xyzi, off, 1, click, out);
 }
 
+namespace {
+// what get_chessboard_by_point reports beyond the front half's record: n_roi of the WHOLE cloud, the second-tier count, and
+// `if(outcloud->size() < 500 || find_board == false) return false;` (LidarCornersEst.cpp:111-112)
+void finish_chessboard_by_point(ilcc_handle* h, Slot& sl, uint32_t n_frames, int32_t min_plane_points, ilcc_result* out) {
+  // frames the first tier answered from a window of the cloud: n_roi is what the clustering of the WHOLE cloud runs on -- its
+  // finite points (K1 counted them on the way); the handle's own copy keeps the window's count, which is what ILCC_CLOUD_ROI holds
+  for (uint32_t f = 0; f < n_frames; ++f)
+    if (sl.h_online[f] == 0u && out[f].status != ILCC_NO_ROI_POINTS) out[f].n_roi = (int32_t)sl.h_online[h->max_frames + f];
+  for (uint32_t f = 0; f < n_frames; ++f) h->timing.online_second_tier_frames += sl.h_online[f] != 0u ? 1u : 0u;
+  for (uint32_t f = 0; f < n_frames; ++f)
+    if (out[f].status == ILCC_OK && (out[f].n_plane < min_plane_points || !out[f].found_board)) {
+      out[f].status = ILCC_BOARD_NOT_FOUND;
+      sl.h_res[f].status = ILCC_BOARD_NOT_FOUND;
+    }
+}
+}  // namespace
+
 int32_t ilcc_chessboard_by_point_batch(ilcc_handle* h, const float* xyzi, const uint64_t* offsets, uint32_t n_frames,
                                        const float* points, int32_t min_plane_points, ilcc_result* out) {
   if (!h || !xyzi || !points || !out) return ILCC_BAD_ARGUMENT;
@@ -1333,17 +1350,48 @@ int32_t ilcc_chessboard_by_point_batch(ilcc_handle* h, const float* xyzi, const 
   if (st != ILCC_OK) return st;
   st = finish(h, 0, out);
   if (st != ILCC_OK) return st;
-  // frames the first tier answered from a window of the cloud: n_roi is what the clustering of the WHOLE cloud runs on -- its
-  // finite points (K1 counted them on the way); the handle's own copy keeps the window's count, which is what ILCC_CLOUD_ROI holds
-  for (uint32_t f = 0; f < n_frames; ++f)
-    if (sl.h_online[f] == 0u && out[f].status != ILCC_NO_ROI_POINTS) out[f].n_roi = (int32_t)sl.h_online[h->max_frames + f];
-  for (uint32_t f = 0; f < n_frames; ++f) h->timing.online_second_tier_frames += sl.h_online[f] != 0u ? 1u : 0u;
-  // `if(outcloud->size() < 500 || find_board == false) return false;` (LidarCornersEst.cpp:111-112)
-  for (uint32_t f = 0; f < n_frames; ++f)
-    if (out[f].status == ILCC_OK && (out[f].n_plane < min_plane_points || !out[f].found_board)) {
-      out[f].status = ILCC_BOARD_NOT_FOUND;
-      sl.h_res[f].status = ILCC_BOARD_NOT_FOUND;
-    }
+  finish_chessboard_by_point(h, sl, n_frames, min_plane_points, out);
+  return ILCC_OK;
+}
+
+// The same call in two halves, like ilcc_submit_batch / ilcc_wait: up to four calls in flight per handle, the H2D copy of one
+// overlapping the kernels of the others (the two tiers need no host decision in between: the second tier's kernels skip the
+// frames the first has answered).  A tracker that hands over one scan at a time gains nothing; a recorded sequence does.
+int32_t ilcc_submit_chessboard_by_point(ilcc_handle* h, const float* xyzi, const uint64_t* offsets, uint32_t n_frames,
+                                        const float* points, int32_t* ticket) {
+  if (!h || !xyzi || !points || !ticket) return ILCC_BAD_ARGUMENT;
+  HIP_TRY(h, hipSetDevice(h->device));
+  int32_t st = check_offsets(h, offsets, n_frames);
+  if (st != ILCC_OK) return st;
+  const int si = h->next_slot;
+  Slot& sl = h->slots[si];
+  if (sl.busy) {
+    h->err = "every pipeline slot holds a batch: wait for the oldest ticket first";
+    return ILCC_CAPACITY;
+  }
+  st = alloc_slot(h, sl);
+  if (st != ILCC_OK) return st;
+  if (offsets[n_frames] > 0)
+    HIP_TRY(h, hipMemcpyAsync(sl.d_xyzi, xyzi, sizeof(float4) * offsets[n_frames], hipMemcpyHostToDevice, sl.stream));
+  HIP_TRY(h, hipMemcpyAsync(sl.d_clicks, points, sizeof(float) * 3 * n_frames, hipMemcpyHostToDevice, sl.stream));
+  st = enqueue(h, si, sl.d_xyzi, offsets, n_frames, sl.d_clicks, /*front_only=*/true, /*no_crop=*/true);
+  if (st != ILCC_OK) return st;
+  *ticket = si;
+  h->next_slot = (si + 1) % kSlots;
+  return ILCC_OK;
+}
+
+int32_t ilcc_wait_chessboard_by_point(ilcc_handle* h, int32_t ticket, int32_t min_plane_points, ilcc_result* out) {
+  if (!h || !out || ticket < 0 || ticket >= kSlots || !h->slots[ticket].busy) {
+    if (h) h->err = "ilcc_wait_chessboard_by_point: no batch in flight under this ticket";
+    return ILCC_BAD_ARGUMENT;
+  }
+  HIP_TRY(h, hipSetDevice(h->device));
+  Slot& sl = h->slots[ticket];
+  const uint32_t n_frames = sl.n_frames;
+  const int32_t st = finish(h, ticket, out);
+  if (st != ILCC_OK) return st;
+  finish_chessboard_by_point(h, sl, n_frames, min_plane_points, out);
   return ILCC_OK;
 }
 

@@ -368,6 +368,25 @@ class LidarCornersBatch:
             raise IlccError(st, self._err())
         return res
 
+    def submit_chessboard_by_point(self, xyzi_ptr: int, n_frames: int, n_points: int, points_ptr: int):
+        """Asynchronous ``chessboard_by_point`` from HOST buffers (raw addresses of pinned arrays that stay alive until
+        ``wait_chessboard_by_point``): up to 4 calls in flight, the copy of one overlapping the kernels of the others."""
+        offsets = np.arange(n_frames + 1, dtype=np.uint64) * np.uint64(n_points)
+        ticket = C.c_int32(-1)
+        st = self._lib.ilcc_submit_chessboard_by_point(self._h, C.c_void_p(xyzi_ptr), offsets.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                                       n_frames, C.c_void_p(points_ptr), C.byref(ticket))
+        if st != N.OK:
+            raise IlccError(st, self._err())
+        return ticket.value, n_frames
+
+    def wait_chessboard_by_point(self, ticket, min_plane_points: int = 500):
+        t, n_frames = ticket
+        res = (N.Result * n_frames)()
+        st = self._lib.ilcc_wait_chessboard_by_point(self._h, t, int(min_plane_points), res)
+        if st != N.OK:
+            raise IlccError(st, self._err())
+        return res
+
     def fetch_classes(self, frame: int) -> np.ndarray:
         n = self._lib.ilcc_fetch_classes(self._h, frame, None, 0)
         if n < 0:

@@ -962,6 +962,37 @@ def test_online_caller_get_chessboard_by_point(ob):
     m.close()
 
 
+def test_online_caller_in_flight_equals_the_synchronous_call():
+    """ilcc_submit_chessboard_by_point / ilcc_wait_chessboard_by_point (up to four calls in flight, H2D on each call's own
+    stream) return what ilcc_chessboard_by_point_batch returns for the same clouds -- every field of the records, the plane
+    clouds and the classes of the call last waited for -- also when the calls differ (three different batches in flight)."""
+    import torch
+    batches = []
+    for k in range(3):
+        clouds, _, _, poses = synth.make_batch(5, seed=1200 + k)
+        pts = np.stack([(p.centre + [0.03, -0.04, 0.02]) for p in poses]).astype(np.float32)
+        if k == 1:
+            pts[2] = [-3.0, 2.0, 5.0]                     # nothing in the window: second tier
+        batches.append((np.ascontiguousarray(clouds), pts))
+    p = N.default_params()
+    p.gray_rate = 2.4
+    e = LidarCornersBatch(5, 28800, p)
+    want = []
+    for clouds, pts in batches:
+        res = e.chessboard_by_point(clouds, pts)
+        want.append(([bytes(r) for r in res], [e.fetch_cloud(f, N.CLOUD_CHESSBOARD) for f in range(5)], [e.fetch_classes(f) for f in range(5)]))
+    pinned = [(torch.from_numpy(c).pin_memory(), torch.from_numpy(q).pin_memory()) for c, q in batches]
+    tickets = [e.submit_chessboard_by_point(c.data_ptr(), 5, 28800, q.data_ptr()) for c, q in pinned]
+    for k, t in enumerate(tickets):
+        res = e.wait_chessboard_by_point(t)
+        assert [bytes(r) for r in res] == want[k][0], k
+        for f in range(5):
+            assert np.array_equal(e.fetch_cloud(f, N.CLOUD_CHESSBOARD), want[k][1][f]), (k, f)
+            assert np.array_equal(e.fetch_classes(f), want[k][2][f]), (k, f)
+    assert sum(1 for r in res if r.status == 0) >= 3
+    e.close()
+
+
 def _patch(rng, centre, u, v, half_u, half_v, pitch, jitter=0.002):
     """points of a planar patch: a lattice of `pitch` metres spanned by the unit vectors u, v, a little noise along the normal"""
     a = np.arange(-half_u, half_u + 1e-9, pitch)
