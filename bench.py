@@ -54,7 +54,7 @@ import numpy as np
 # One HIP stream per batch in flight (4) + torch's streams: with the runtime's default of 4 hardware queues two
 # of them would share a queue and serialise.  Must be set before the HIP runtime initialises (i.e. before torch);
 # libilcc_hip.so does the same when it is loaded first.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)

@@ -11,4 +11,4 @@ from .lidar_corners_est import (IlccError, LidarCornersBatch, LidarCornersEst, r
 # onto GPU_MAX_HW_QUEUES hardware queues (default 4); streams that share a queue serialise.  This only takes
 # effect when the runtime has not been initialised yet (import this package -- or set the variable -- before torch).
 import os as _os
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")

@@ -2,7 +2,7 @@
 what a stage is worth: e.g. `refine_div=0` (K7r keeps the grid argmin: no pattern search), `ransac_hyp=8`, `n_th=31` ...
 usage: python tools/dev_pipeline_probe.py [steps=20] [name=value ...]"""
 import os, sys, time
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import bench
