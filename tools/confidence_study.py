@@ -1,5 +1,5 @@
 import json, os, sys, multiprocessing as mp
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 
 def job(args):

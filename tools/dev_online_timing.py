@@ -1,12 +1,14 @@
-import sys, time, numpy as np, torch
-sys.path.insert(0, '/root/repo')
+"""The online caller (get_chessboard_by_point on un-cropped clouds) synchronous and with 1 / 2 / 4 calls in flight: ms per call, host time per
+submit / wait, the H2D copy of a call alone, stage times.  EXTRA=1: beside another live handle.  (through gpurun from the repo root)"""
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from lidar_camera_calibration_amd import LidarCornersBatch
 from lidar_camera_calibration_amd import _native as N
 clouds, clicks, gts = bench.generate(2, 128, 0xC0FFEE, 16)
 F, n_points = 128, 28800
 p = N.default_params(); p.gray_rate = 2.4
-import os
 if os.environ.get('EXTRA'):
     big = LidarCornersBatch(1024, n_points, p, device=0); big.set_result_mode(N.RESULTS_COMPACT); big.reserve(1792, 2560)
     dd = torch.from_numpy(np.tile(clouds[:128].reshape(128, n_points, 4), (8, 1, 1))).cuda(); dk = torch.from_numpy(np.tile(clicks[:128].reshape(128, 3), (8, 1))).cuda()
