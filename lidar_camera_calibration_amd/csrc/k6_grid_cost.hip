@@ -1058,7 +1058,7 @@ void launch_group_prepass(const Ctx& c, hipStream_t s, uint32_t* grp_alive, uint
 // are added at the end), which the full pass cannot see: the bound only has to be the cost of SOME complete candidate, and a
 // candidate is cut, or listed as a near tie, with 2e-5 to spare -- 20 x the rounding of an fp32 sum of a thousand terms.
 // Batches of fewer than kLocateMinFrames frames keep the three launches: there a frame's 17 workgroups are what fills the chip.
-constexpr int kLocateThreads = 512;       // measured (k frames/s, one MI355X): 256: 1056, 512: 1089, 1024: 1011-1033
+constexpr int kLocateThreads = 384;       // 6 wavefronts = 3 anchor thetas x 2 parts of the walk, all busy in the anchor.  Measured (k frames/s / locate alone): 256: 1056, 512: 1089, 1024: 1011-1033 when it was built; on the final build 384: 1266 / 0.184 ms, 512: 1268 / 0.214 ms, 768: 1251 / 0.201 ms
 constexpr int kSeedPeek = 16;             // walk positions of every seed tile a wavefront looks at before it chooses which tile to evaluate first
 constexpr int kAnchorThetas = 3;          // thetas around the refinement's argmin the anchor scores (1: locate 0.26 -> 0.21 ms alone, full pass 0.36 -> 0.40: a wash)
 constexpr int kAnchorParts = (kLocateThreads / 64) / kAnchorThetas;  // wavefronts sharing a theta's walk
