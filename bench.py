@@ -206,6 +206,9 @@ def main():
     ap.add_argument("--ref-n1", type=float, default=0.0,
                     help="frames/s of the N=1 run: rank 0 then prints weak_scaling_efficiency = value / (N x ref)")
     ap.add_argument("--no-noise-floor", action="store_true", help="skip the sensor-noise sweep (noise_floor_mm)")
+    ap.add_argument("--solver", choices=("grid", "reference"), default="grid",
+                    help="reference: the TIMED region runs ILCC_SOLVER_REFERENCE_LOCAL (K7a instead of K6 + K7r) -- profiling runs of "
+                         "that mode (tools/gpu_profile_reference.sh); the headline and the driver's run are `grid`")
     args = ap.parse_args()
     ensure_world(args)
 
@@ -283,6 +286,8 @@ def main():
     else:
         board, n_points = synth.Board(), synth.vlp16().n_points
         params = N.default_params()            # ILCC_SOLVER_GRID: 61 x 40 x 40 candidates x 2 phases
+    if args.solver == "reference":
+        params.solver = N.SOLVER_REFERENCE_LOCAL
     bytes_per_frame = 16 * n_points + 12 * board.n_corners + 64          # 461 284 B for config 2
     clouds = clouds.reshape(B, F, n_points, 4)
     clicks = clicks.reshape(B, F, 3)
@@ -469,8 +474,8 @@ def main():
             / max(1.0, evals_per_launch)
         box_evals = tm.grid_cost_box_evals_sum / launches               # (point, tile) evaluations of the box pre-passes
         credited_lane_instr = evals_per_launch * valu_ops_per_eval + box_evals * K6_VALU_OPS_BOX
-        valu_rate = credited_lane_instr / (k6_ms_alone * 1e-3) / 1e12
-        valu_rate_pipe = credited_lane_instr / (k6_ms * 1e-3) / 1e12
+        valu_rate = credited_lane_instr / (max(k6_ms_alone, 1e-9) * 1e-3) / 1e12
+        valu_rate_pipe = credited_lane_instr / (max(k6_ms, 1e-9) * 1e-3) / 1e12
         pmc = k6_pmc(args.config, F)
         credited_wave_instr = credited_lane_instr / 64.0
         rocprof = k6_rocprof(args.config, credited_lane_instr)

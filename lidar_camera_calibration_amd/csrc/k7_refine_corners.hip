@@ -1,20 +1,22 @@
 // K7 refine_and_corners.
 //
-// K7a local_solve: one 256-thread workgroup (4 wavefronts) per (frame, colour phase).
-//  (1) picks the start: the argmin of the K6 per-workgroup partials (ILCC_SOLVER_GRID) or
-//      (0,0,0) (ILCC_SOLVER_REFERENCE_LOCAL, the reference's own start);
+// K7a local_solve (ILCC_SOLVER_REFERENCE_LOCAL): ONE WAVEFRONT per (frame, colour phase); a 256-thread workgroup holds
+//      kSolveWaves such solves (the two phases of a frame share one staged copy of its labelled points in LDS).
+//  (1) starts at (0,0,0), the reference's own start;
 //  (2) runs the reference's two local solves, pass A (useOutofBoard = true) then pass B (false)
 //      -- LidarCornersEst::get_corners, /root/reference/ilcc2/src/LidarCornersEst.cpp:398-409 --
 //      each a restatement of what ceres::Solve does for Optimization::get_theta_t
 //      (/root/reference/ilcc2/src/Optimization.cpp:94-160): TRUST_REGION, DOGLEG/SUBSPACE_DOGLEG,
 //      DENSE_NORMAL_CHOLESKY, HuberLoss(0.1) through Ceres' Corrector, Jacobi scaling, Ceres 1.14
-//      default tolerances.  The threads stride over the points (residual + Jacobian in double),
-//      sums are combined with a shuffle butterfly per wavefront and ONE barrier per evaluation
-//      (double-buffered LDS slots, fixed summation order) so every thread holds bitwise-identical
-//      totals, and the 3-parameter trust-region bookkeeping is executed redundantly by all
-//      threads: no thread-0 section, no divergence.  A solve is a chain of ~100 dependent
-//      evaluations, so latency -- not throughput -- is what this layout minimises; frames and
-//      phases run concurrently on different CUs.
+//      default tolerances.  The 64 lanes stride over the points (residual + Jacobian in double), sums are
+//      combined with a DPP / permlane butterfly (no LDS, no barrier: after the staging barrier the wavefronts of a
+//      workgroup never meet again), and the 3-parameter trust-region bookkeeping runs once per wavefront on
+//      wave-uniform values.  Round 6 (profiles/r06a_*): the 4-wavefront-per-solve layout of rounds 1-5 issued the
+//      dogleg FOUR times per iteration -- 60 % of the kernel's 1.02 G wave-instructions per 1024 frames -- and at 203
+//      VGPRs held two wavefronts per SIMD; the kernel was VALU-issue bound (VALU busy 70 %), not latency bound.
+//      The arithmetic is unchanged value for value: divisions by a divisor that is used many times (g; the dogleg's
+//      diagonal, Cholesky pivots, norms) are one true division for RN(1/d) plus Markstein's correction (exactly the
+//      correctly rounded quotient), sqrt(r * r) of Huber is |r| (exact in binary floating point).
 // K7r pattern_refine (ILCC_SOLVER_GRID): one 192-thread workgroup (three wavefronts, one per theta of the stencil) per frame.  Starts at the K6 grid argmin
 //      (near ties of the fp32 grid pass are first re-ordered on exact fixed-point costs), then a monotone
 //      pattern search on the pass-A cost and a check of the eight neighbouring basins -- the same
@@ -30,55 +32,92 @@
 namespace ilcc {
 
 // ------------------------------------------------------------------ residual (Optimization.h:31-107)
-struct Board {
+// a / d, correctly rounded, for a divisor that divides many numerators: y = RN(1 / d) costs one true division, every
+// quotient after that is q = RN(a y); r = a - q d (exact, one FMA); RN(q + r y) -- Markstein's theorem: with y the
+// correctly rounded reciprocal and q within an ulp of a / d the corrected quotient IS RN(a / d) (the sequence the
+// hardware's own v_div_* expansion ends with; tools/ubench/markstein_check.c compares it with `/` on 6e8 samples).
+// Numerators here are finite and far from the over/underflow range (board coordinates, trust-region bookkeeping).
+struct Divisor {
+  double d, y;
+};
+__device__ __forceinline__ Divisor make_divisor(double d) { return Divisor{d, 1.0 / d}; }
+__device__ __forceinline__ double div_by(double a, const Divisor& v) {
+  const double q = a * v.y;
+  const double r = __builtin_fma(-q, v.d, a);
+  return __builtin_fma(r, v.y, q);
+}
+
+struct Board {   // K7r / K7b
   double W, H, g, delta;
 };
+// K7a: the same board with the constants the residual needs
+struct SolveBoard {
+  double W, H, delta;
+  double Wg2, Hg2;   // W * g / 2.0, H * g / 2.0 (Optimization.h:45-46)
+  Divisor g;
+};
+__device__ __forceinline__ SolveBoard make_board(const ilcc_params& p) {
+  SolveBoard b;
+  b.W = (double)p.board_w;
+  b.H = (double)p.board_h;
+  b.delta = p.huber_delta;
+  b.Wg2 = b.W * p.grid_length / 2.0;
+  b.Hg2 = b.H * p.grid_length / 2.0;
+  b.g = make_divisor(p.grid_length);
+  return b;
+}
 
-// raw residual; jac = d r / d(theta, ty, tz) when JAC.  cs = (cos theta, sin theta).
+// raw residual; jac = d r / d(theta, ty, tz) when JAC.  cs = (cos theta, sin theta).  Value for value the oracle's
+// residual_cs (oracle/ilcc_oracle.c): (floor(i) even) is read off the integer instead of floor(ifl / 2) * 2 == ifl,
+// ceil(i) of a non-integer i is floor(i) + 1, d i / d theta = -(s y + c z) / g = -rz / g and d j / d theta = ry / g
+// reuse the rotated point (the same products, the same sums), +-1 / g is +-RN(1 / g).
 template <bool JAC>
 __device__ __forceinline__ double residual(const double x[3], double c, double s, double y, double z,
-                                           const Board& bd, bool tlw, bool laser_white, bool use_oob,
+                                           const SolveBoard& bd, bool tlw, bool laser_white, bool use_oob,
                                            double jac[3]) {
   const double ry = c * y - s * z;
   const double rz = s * y + c * z;
   const double r1 = ry + x[1];
   const double r2 = rz + x[2];
-  const double i = (r1 + bd.W * bd.g / 2.0) / bd.g;
-  const double j = (r2 + bd.H * bd.g / 2.0) / bd.g;
+  const double i = div_by(r1 + bd.Wg2, bd.g);
+  const double j = div_by(r2 + bd.Hg2, bd.g);
   double si = 0, sj = 0, res = 0;
   if (i > 0 && i < bd.W && j > 0 && j < bd.H) {
     const double ifl = floor(i), jfl = floor(j);
-    const double ii = floor(ifl / 2.0) * 2.0, jj = floor(jfl / 2.0) * 2.0;
-    bool white = !tlw;
-    if (ifl == ii && jfl == jj) white = tlw;
-    if (ifl != ii && jfl != jj) white = tlw;
+    const bool same_parity = ((((int)ifl) ^ ((int)jfl)) & 1) == 0;   // both even or both odd (:57-60)
+    const bool white = same_parity ? tlw : !tlw;
     if (laser_white != white) {
-      double ie, je;
-      if (i - ifl > 0.5) { ie = ceil(i) - i; si = -1; } else { ie = i - ifl; si = 1; }
-      if (j - jfl > 0.5) { je = ceil(j) - j; sj = -1; } else { je = j - jfl; sj = 1; }
+      const double fi = i - ifl, fj = j - jfl;
+      const bool ui = fi > 0.5, uj = fj > 0.5;
+      const double ie = ui ? (ifl + 1.0) - i : fi;
+      const double je = uj ? (jfl + 1.0) - j : fj;
+      si = ui ? -1.0 : 1.0;
+      sj = uj ? -1.0 : 1.0;
       res = ie + je;
     }
   } else if (use_oob) {
-    double ie, je;
-    if (fabs(i) < fabs(i - bd.W)) { ie = fabs(i); si = (i < 0) ? -1 : 1; }
-    else { ie = fabs(i - bd.W); si = (i - bd.W < 0) ? -1 : 1; }
-    if (fabs(j) < fabs(j - bd.H)) { je = fabs(j); sj = (j < 0) ? -1 : 1; }
-    else { je = fabs(j - bd.H); sj = (j - bd.H < 0) ? -1 : 1; }
+    const double iw = i - bd.W, jh = j - bd.H;
+    const bool ni = fabs(i) < fabs(iw), nj = fabs(j) < fabs(jh);
+    const double ie = ni ? fabs(i) : fabs(iw);
+    const double je = nj ? fabs(j) : fabs(jh);
+    si = ((ni ? i : iw) < 0) ? -1.0 : 1.0;
+    sj = ((nj ? j : jh) < 0) ? -1.0 : 1.0;
     res = ie + je;
   }
   if (JAC) {
-    const double dith = (-s * y - c * z) / bd.g, djth = (c * y - s * z) / bd.g;
+    const double dith = -div_by(rz, bd.g), djth = div_by(ry, bd.g);
     jac[0] = si * dith + sj * djth;
-    jac[1] = si / bd.g;
-    jac[2] = sj / bd.g;
+    jac[1] = si * bd.g.y;
+    jac[2] = sj * bd.g.y;
   }
   return res;
 }
 
-__device__ __forceinline__ void huber(double a, double s, double& rho0, double& rho1) {
+// HuberLoss(a) on s = r * r with r >= 0 (the residual is a sum of distances): sqrt(s) is r itself -- for binary floating point
+// sqrt(RN(r * r)) == |r| barring over/underflow (Boldo 2015; the oracle calls sqrt) -- so no square root is taken
+__device__ __forceinline__ void huber(double a, double r, double s, double& rho0, double& rho1) {
   const double b = a * a;
   if (s > b) {
-    const double r = sqrt(s);
     rho0 = 2.0 * a * r - b;
     rho1 = a / r;
     if (rho1 < 2.2250738585072014e-308) rho1 = 2.2250738585072014e-308;
@@ -89,21 +128,19 @@ __device__ __forceinline__ void huber(double a, double s, double& rho0, double& 
 }
 
 // ------------------------------------------------------------------ wavefront-wide evaluation
-constexpr int kSolveWaves = kSolveThreads / ILCC_WAVE;
+constexpr int kSolveWaves = kSolveThreads / ILCC_WAVE;   // solves per K7a workgroup
+constexpr int kSolveLdsMax = 144 * 1024;                 // K7a: dynamic LDS bound (a CU has 160 KB)
 
 struct Problem {
   const float2* yz;      // LDS or global
   const uint8_t* lab;
   uint32_t n;
-  Board bd;
+  SolveBoard bd;
   bool tlw, oob;
-  double* red;           // LDS: 2 x kSolveWaves x 10 doubles (double-buffered partial sums)
-  int* flip;             // per-thread toggle (register copy lives in the caller)
 };
 
 // v[lane ^ MASK] for a 64-bit value, in registers only: v_permlane32_swap / v_permlane16_swap (gfx950) and
-// DPP row rotations / quad permutes on the two dwords -- no ds_bpermute round trips.  (An evaluate() reduces
-// ten doubles over six butterfly steps: 120 LDS permutes before, ~200 VALU instructions now.)
+// DPP row rotations / quad permutes on the two dwords -- no ds_bpermute round trips.
 template <int CTRL, int BANK = 0xf>
 __device__ __forceinline__ uint32_t dpp_u32(uint32_t old, uint32_t v) {
   return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, 0xf, BANK, false);
@@ -139,7 +176,7 @@ __device__ __forceinline__ unsigned long long xor_lane_u64(unsigned long long b)
   return ((unsigned long long)hi << 32) | lo;
 }
 // butterfly in the order 32, 16, 8, 4, 2, 1: identical in every lane (each step adds the same two operands
-// in both partners), and bit-identical to the __shfl_xor butterfly it replaces
+// in both partners)
 __device__ __forceinline__ double wave_allsum(double v) {
   v += xor_lane_f64<32>(v);
   v += xor_lane_f64<16>(v);
@@ -151,7 +188,8 @@ __device__ __forceinline__ double wave_allsum(double v) {
 }
 
 // sums[0] = cost ; if JAC: sums[1..3] = J^T r, sums[4..9] = upper J^T J (00,01,02,11,12,22),
-// with Ceres' Corrector applied (rows scaled by sqrt(rho')).  Same value in every lane.
+// with Ceres' Corrector applied (rows scaled by sqrt(rho')).  One wavefront: lane l takes the points l, l + 64, ...;
+// the same value in every lane on return.
 template <bool JAC>
 __device__ __forceinline__ void evaluate(const Problem& q, const double x[3], double sums[10]) {
   double sn, cs;
@@ -159,13 +197,14 @@ __device__ __forceinline__ void evaluate(const Problem& q, const double x[3], do
   double acc[10];
 #pragma unroll
   for (int k = 0; k < 10; ++k) acc[k] = 0.0;
-  for (uint32_t p = threadIdx.x; p < q.n; p += blockDim.x) {
+#pragma unroll 2
+  for (uint32_t p = lane_id(); p < q.n; p += ILCC_WAVE) {
     const float2 v = q.yz[p];
     double jac[3];
     const double res = residual<JAC>(x, cs, sn, (double)v.x, (double)v.y, q.bd, q.tlw, q.lab[p] != 0,
                                      q.oob, jac);
     double r0, r1;
-    huber(q.bd.delta, res * res, r0, r1);
+    huber(q.bd.delta, res, res * res, r0, r1);
     acc[0] += 0.5 * r0;
     if (JAC) {
       const double sr = sqrt(r1);
@@ -184,34 +223,14 @@ __device__ __forceinline__ void evaluate(const Problem& q, const double x[3], do
   }
   constexpr int NV = JAC ? 10 : 1;
 #pragma unroll
-  for (int k = 0; k < NV; ++k) acc[k] = wave_allsum(acc[k]);
-  if (blockDim.x == ILCC_WAVE) {
-#pragma unroll
-    for (int k = 0; k < NV; ++k) sums[k] = acc[k];
-    return;
-  }
-  // wavefronts -> LDS -> everyone, fixed order; the slot alternates so one barrier per call is enough
-  *q.flip ^= 1;
-  double* slot = q.red + (*q.flip) * (kSolveWaves * 10);
-  if (lane_id() == 0) {
-#pragma unroll
-    for (int k = 0; k < NV; ++k) slot[wave_id() * 10 + k] = acc[k];
-  }
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < NV; ++k) {
-    double t = slot[k];
-#pragma unroll
-    for (int w = 1; w < kSolveWaves; ++w) t += slot[w * 10 + k];
-    sums[k] = t;
-  }
+  for (int k = 0; k < NV; ++k) sums[k] = wave_allsum(acc[k]);
 }
 
-// ------------------------------------------------------------------ dogleg bookkeeping (per lane, uniform)
+// ------------------------------------------------------------------ dogleg bookkeeping (wave-uniform values)
 struct Dog {
   double radius, mu;
   int reuse;
-  double d0, d1, d2;        // diagonal
+  Divisor d0, d1, d2;       // diagonal (divides the gradient, the basis and every step)
   double g0, g1, g2;        // scaled gradient
   double n0, n1, n2;        // Gauss-Newton step (scaled space)
   double alpha, step_norm;
@@ -220,6 +239,10 @@ struct Dog {
   double sg0, sg1, sB00, sB01, sB11;
   double A00, A01, A02, A11, A12, A22;   // J^T J of the column-scaled Jacobian
   double r0, r1, r2;                     // J^T r of the column-scaled Jacobian
+  // min_on_circle's radius-independent half (eigen-decomposition of the 2x2 subspace model), computed at the first
+  // boundary step of a linearisation point and kept while the rejected steps only shrink the radius
+  int eig_ready;
+  double e_l1, e_l2, e_v1x, e_v1y, e_v2x, e_v2y, e_g1, e_g2, e_gn;
 };
 
 // (A + diag(e)) x = b by Cholesky; false on a non-positive pivot (Eigen LLT NumericalIssue)
@@ -227,31 +250,33 @@ __device__ __forceinline__ bool chol3_solve(double a00, double a01, double a02, 
                                             double a22, double b0, double b1, double b2, double& x0,
                                             double& x1, double& x2) {
   if (!(a00 > 0.0)) return false;
-  const double l00 = sqrt(a00);
-  const double l10 = a01 / l00, l20 = a02 / l00;
+  const Divisor l00 = make_divisor(sqrt(a00));
+  const double l10 = div_by(a01, l00), l20 = div_by(a02, l00);
   const double s11 = a11 - l10 * l10;
   if (!(s11 > 0.0)) return false;
-  const double l11 = sqrt(s11);
-  const double l21 = (a12 - l20 * l10) / l11;
+  const Divisor l11 = make_divisor(sqrt(s11));
+  const double l21 = div_by(a12 - l20 * l10, l11);
   const double s22 = a22 - l20 * l20 - l21 * l21;
   if (!(s22 > 0.0)) return false;
-  const double l22 = sqrt(s22);
-  const double y0 = b0 / l00;
-  const double y1 = (b1 - l10 * y0) / l11;
-  const double y2 = (b2 - l20 * y0 - l21 * y1) / l22;
-  x2 = y2 / l22;
-  x1 = (y1 - l21 * x2) / l11;
-  x0 = (y0 - l10 * x1 - l20 * x2) / l00;
+  const Divisor l22 = make_divisor(sqrt(s22));
+  const double y0 = div_by(b0, l00);
+  const double y1 = div_by(b1 - l10 * y0, l11);
+  const double y2 = div_by(b2 - l20 * y0 - l21 * y1, l22);
+  x2 = div_by(y2, l22);
+  x1 = div_by(y1 - l21 * x2, l11);
+  x0 = div_by(y0 - l10 * x1 - l20 * x2, l00);
   return isfinite(x0) && isfinite(x1) && isfinite(x2);
 }
 
 // argmin of 1/2 y'By + g'y on |y| = radius, B symmetric PSD 2x2 (Ceres: quartic roots; here
-// eigen-decomposition + Newton on the secular equation, More-Sorensen).
-__device__ __forceinline__ void min_on_circle(double B00, double B01, double B11, double gx, double gy,
-                                              double radius, double& yx, double& yy) {
+// eigen-decomposition + Newton on the secular equation, More-Sorensen; oracle/ilcc_oracle.c min_on_circle).
+// First half: everything that does not depend on the radius.
+__device__ __forceinline__ void circle_eigen(Dog& s) {
+  const double B00 = s.sB00, B01 = s.sB01, B11 = s.sB11, gx = s.sg0, gy = s.sg1;
   const double d = 0.5 * (B00 - B11), e = B01;
   const double h = sqrt(d * d + e * e), mean = 0.5 * (B00 + B11);
-  const double l1 = mean - h, l2 = mean + h;
+  s.e_l1 = mean - h;
+  s.e_l2 = mean + h;
   double v2x, v2y;
   if (h == 0.0) {
     v2x = 1.0;
@@ -274,11 +299,24 @@ __device__ __forceinline__ void min_on_circle(double B00, double B01, double B11
     }
   }
   const double v1x = -v2y, v1y = v2x;
-  const double g1 = v1x * gx + v1y * gy, g2 = v2x * gx + v2y * gy;
-  const double gn = sqrt(g1 * g1 + g2 * g2);
+  s.e_v1x = v1x;
+  s.e_v1y = v1y;
+  s.e_v2x = v2x;
+  s.e_v2y = v2y;
+  s.e_g1 = v1x * gx + v1y * gy;
+  s.e_g2 = v2x * gx + v2y * gy;
+  s.e_gn = sqrt(s.e_g1 * s.e_g1 + s.e_g2 * s.e_g2);
+  s.eig_ready = 1;
+}
+// Second half: the multiplier for this radius
+__device__ __forceinline__ void min_on_circle(Dog& s, double radius, double& yx, double& yy) {
+  if (!s.eig_ready) circle_eigen(s);
+  const double l1 = s.e_l1, l2 = s.e_l2, g1 = s.e_g1, g2 = s.e_g2;
+  const Divisor rad = make_divisor(radius);
+  const double gnr = div_by(s.e_gn, rad);
   double lo = fmax(0.0, -l1);
-  lo = fmax(lo, gn / radius - l2);
-  const double hi = gn / radius - l1;
+  lo = fmax(lo, gnr - l2);
+  const double hi = gnr - l1;
   double lam = lo;
   if (!(l1 + lam > 0.0)) lam = lo + 1e-12 * fmax(1.0, fabs(hi));
   for (int it = 0; it < 60; ++it) {
@@ -287,7 +325,7 @@ __device__ __forceinline__ void min_on_circle(double B00, double B01, double B11
     const double ny = sqrt(y1 * y1 + y2 * y2);
     const double qq = g1 * g1 / (a1 * a1 * a1) + g2 * g2 / (a2 * a2 * a2);
     if (!(qq > 0.0) || !isfinite(ny)) break;
-    const double dl = (ny * ny / qq) * ((ny - radius) / radius);
+    const double dl = (ny * ny / qq) * div_by(ny - radius, rad);
     double nl = lam + dl;
     if (!(l1 + nl > 0.0)) nl = 0.5 * (lam + fmax(0.0, -l1));
     if (fabs(nl - lam) <= 1e-15 * fmax(1.0, fabs(nl))) {
@@ -304,11 +342,12 @@ __device__ __forceinline__ void min_on_circle(double B00, double B01, double B11
     ny = radius;
   }
   if (ny > 0.0) {
-    y1 *= radius / ny;
-    y2 *= radius / ny;
+    const double k = radius / ny;
+    y1 *= k;
+    y2 *= k;
   }
-  yx = v1x * y1 + v2x * y2;
-  yy = v1y * y1 + v2y * y2;
+  yx = s.e_v1x * y1 + s.e_v2x * y2;
+  yy = s.e_v1y * y1 + s.e_v2y * y2;
 }
 
 __device__ __forceinline__ double nrm3(double a, double b, double c) { return sqrt(a * a + b * b + c * c); }
@@ -316,17 +355,17 @@ __device__ __forceinline__ double nrm3(double a, double b, double c) { return sq
 __device__ __forceinline__ void dogleg_traditional(Dog& s, double& s0, double& s1, double& s2) {
   const double gnn = nrm3(s.n0, s.n1, s.n2), gn_ = nrm3(s.g0, s.g1, s.g2);
   if (gnn <= s.radius) {
-    s0 = s.n0 / s.d0;
-    s1 = s.n1 / s.d1;
-    s2 = s.n2 / s.d2;
+    s0 = div_by(s.n0, s.d0);
+    s1 = div_by(s.n1, s.d1);
+    s2 = div_by(s.n2, s.d2);
     s.step_norm = gnn;
     return;
   }
   if (gn_ * s.alpha >= s.radius) {
     const double k = -(s.radius / gn_);
-    s0 = k * s.g0 / s.d0;
-    s1 = k * s.g1 / s.d1;
-    s2 = k * s.g2 / s.d2;
+    s0 = div_by(k * s.g0, s.d0);
+    s1 = div_by(k * s.g1, s.d1);
+    s2 = div_by(k * s.g2, s.d2);
     s.step_norm = s.radius;
     return;
   }
@@ -337,9 +376,9 @@ __device__ __forceinline__ void dogleg_traditional(Dog& s, double& s0, double& s
   const double cc = bdota - a2n;
   const double d = sqrt(cc * cc + bma2 * (s.radius * s.radius - a2n));
   const double beta = (cc <= 0) ? (d - cc) / bma2 : (s.radius * s.radius - a2n) / (d + cc);
-  s0 = (a0 + beta * (s.n0 - a0)) / s.d0;
-  s1 = (a1 + beta * (s.n1 - a1)) / s.d1;
-  s2 = (a2 + beta * (s.n2 - a2)) / s.d2;
+  s0 = div_by(a0 + beta * (s.n0 - a0), s.d0);
+  s1 = div_by(a1 + beta * (s.n1 - a1), s.d1);
+  s2 = div_by(a2 + beta * (s.n2 - a2), s.d2);
   s.step_norm = s.radius;
 }
 
@@ -356,21 +395,22 @@ __device__ __forceinline__ double qform(const Dog& s, double u0, double u1, doub
 __device__ __forceinline__ bool dogleg_compute_step(Dog& s, double& s0, double& s1, double& s2) {
   if (!s.reuse) {
     s.reuse = 1;
-    s.d0 = sqrt(fmin(fmax(s.A00, 1e-6), 1e32));
-    s.d1 = sqrt(fmin(fmax(s.A11, 1e-6), 1e32));
-    s.d2 = sqrt(fmin(fmax(s.A22, 1e-6), 1e32));
-    s.g0 = s.r0 / s.d0;
-    s.g1 = s.r1 / s.d1;
-    s.g2 = s.r2 / s.d2;
+    s.eig_ready = 0;
+    s.d0 = make_divisor(sqrt(fmin(fmax(s.A00, 1e-6), 1e32)));
+    s.d1 = make_divisor(sqrt(fmin(fmax(s.A11, 1e-6), 1e32)));
+    s.d2 = make_divisor(sqrt(fmin(fmax(s.A22, 1e-6), 1e32)));
+    s.g0 = div_by(s.r0, s.d0);
+    s.g1 = div_by(s.r1, s.d1);
+    s.g2 = div_by(s.r2, s.d2);
     {
-      const double u0 = s.g0 / s.d0, u1 = s.g1 / s.d1, u2 = s.g2 / s.d2;
+      const double u0 = div_by(s.g0, s.d0), u1 = div_by(s.g1, s.d1), u2 = div_by(s.g2, s.d2);
       const double num = s.g0 * s.g0 + s.g1 * s.g1 + s.g2 * s.g2;
       s.alpha = num / qform(s, u0, u1, u2, u0, u1, u2);
     }
     bool ok = false;
     while (s.mu < 1.0) {
       const double sm = sqrt(s.mu);
-      const double e0 = s.d0 * sm, e1 = s.d1 * sm, e2 = s.d2 * sm;
+      const double e0 = s.d0.d * sm, e1 = s.d1.d * sm, e2 = s.d2.d * sm;
       if (chol3_solve(s.A00 + e0 * e0, s.A01, s.A02, s.A11 + e1 * e1, s.A12, s.A22 + e2 * e2, s.r0, s.r1, s.r2,
                       s.n0, s.n1, s.n2)) {
         ok = true;
@@ -379,33 +419,35 @@ __device__ __forceinline__ bool dogleg_compute_step(Dog& s, double& s0, double& 
       s.mu *= 10.0;
     }
     if (!ok) return false;
-    s.n0 *= -s.d0;
-    s.n1 *= -s.d1;
-    s.n2 *= -s.d2;
+    s.n0 *= -s.d0.d;
+    s.n1 *= -s.d1.d;
+    s.n2 *= -s.d2.d;
     {
       const double q0 = s.g0 * s.g0 + s.g1 * s.g1 + s.g2 * s.g2;
       const double q1 = s.n0 * s.n0 + s.n1 * s.n1 + s.n2 * s.n2;
       const bool gfirst = q0 >= q1;
-      const double nf = sqrt(fmax(q0, q1));
+      const double nfv = sqrt(fmax(q0, q1));
+      const Divisor nf = make_divisor(nfv);
       const double f0 = (gfirst ? s.g0 : s.n0), f1 = (gfirst ? s.g1 : s.n1), f2 = (gfirst ? s.g2 : s.n2);
       const double t0 = (gfirst ? s.n0 : s.g0), t1 = (gfirst ? s.n1 : s.g1), t2 = (gfirst ? s.n2 : s.g2);
-      const double v00 = f0 / nf, v01 = f1 / nf, v02 = f2 / nf;
+      const double v00 = div_by(f0, nf), v01 = div_by(f1, nf), v02 = div_by(f2, nf);
       const double dot = t0 * v00 + t1 * v01 + t2 * v02;
       double v10 = t0 - dot * v00, v11 = t1 - dot * v01, v12 = t2 - dot * v02;
-      const double nr = nrm3(v10, v11, v12);
-      s.one_dim = !(nr > 3.0 * 2.220446049250313e-16 * nf);
+      const double nrv = nrm3(v10, v11, v12);
+      s.one_dim = !(nrv > 3.0 * 2.220446049250313e-16 * nfv);
       if (!s.one_dim) {
-        v10 /= nr;
-        v11 /= nr;
-        v12 /= nr;
+        const Divisor nr = make_divisor(nrv);
+        v10 = div_by(v10, nr);
+        v11 = div_by(v11, nr);
+        v12 = div_by(v12, nr);
         s.b00 = v00;
         s.b10 = v01;
         s.b20 = v02;
         s.b01 = v10;
         s.b11 = v11;
         s.b21 = v12;
-        const double ua0 = v00 / s.d0, ua1 = v01 / s.d1, ua2 = v02 / s.d2;
-        const double ub0 = v10 / s.d0, ub1 = v11 / s.d1, ub2 = v12 / s.d2;
+        const double ua0 = div_by(v00, s.d0), ua1 = div_by(v01, s.d1), ua2 = div_by(v02, s.d2);
+        const double ub0 = div_by(v10, s.d0), ub1 = div_by(v11, s.d1), ub2 = div_by(v12, s.d2);
         s.sg0 = v00 * s.g0 + v01 * s.g1 + v02 * s.g2;
         s.sg1 = v10 * s.g0 + v11 * s.g1 + v12 * s.g2;
         s.sB00 = qform(s, ua0, ua1, ua2, ua0, ua1, ua2);
@@ -416,34 +458,34 @@ __device__ __forceinline__ bool dogleg_compute_step(Dog& s, double& s0, double& 
   }
   const double gnn = nrm3(s.n0, s.n1, s.n2);
   if (gnn <= s.radius) {
-    s0 = s.n0 / s.d0;
-    s1 = s.n1 / s.d1;
-    s2 = s.n2 / s.d2;
+    s0 = div_by(s.n0, s.d0);
+    s1 = div_by(s.n1, s.d1);
+    s2 = div_by(s.n2, s.d2);
     s.step_norm = gnn;
     return true;
   }
   if (s.one_dim) {
     const double k = -(s.radius / nrm3(s.g0, s.g1, s.g2));
-    s0 = k * s.g0 / s.d0;
-    s1 = k * s.g1 / s.d1;
-    s2 = k * s.g2 / s.d2;
+    s0 = div_by(k * s.g0, s.d0);
+    s1 = div_by(k * s.g1, s.d1);
+    s2 = div_by(k * s.g2, s.d2);
     s.step_norm = s.radius;
     return true;
   }
   double yx, yy;
-  min_on_circle(s.sB00, s.sB01, s.sB11, s.sg0, s.sg1, s.radius, yx, yy);
+  min_on_circle(s, s.radius, yx, yy);
   if (!isfinite(yx) || !isfinite(yy)) {
     dogleg_traditional(s, s0, s1, s2);
     return true;
   }
-  s0 = (s.b00 * yx + s.b01 * yy) / s.d0;
-  s1 = (s.b10 * yx + s.b11 * yy) / s.d1;
-  s2 = (s.b20 * yx + s.b21 * yy) / s.d2;
+  s0 = div_by(s.b00 * yx + s.b01 * yy, s.d0);
+  s1 = div_by(s.b10 * yx + s.b11 * yy, s.d1);
+  s2 = div_by(s.b20 * yx + s.b21 * yy, s.d2);
   s.step_norm = s.radius;
   return true;
 }
 
-// TrustRegionMinimizer::Minimize for 3 parameters; every lane runs the same control flow.
+// TrustRegionMinimizer::Minimize for 3 parameters, one wavefront, every lane on the same control flow.
 #ifdef ILCC_K7_TIMING
 __device__ unsigned long long g_k7_t[4];
 #define K7_T0 const unsigned long long k7t0 = __builtin_readcyclecounter()
@@ -453,29 +495,45 @@ __device__ unsigned long long g_k7_t[4];
 #define K7_ACC(k) do {} while (0)
 #endif
 
-__device__ int trust_region_minimize(const Problem& q, double x[3], double& final_cost, int max_iter) {
+// One call site per evaluate<> flavour: the Jacobian pass of the start and of every accepted step is the `relinearise`
+// block at the head of the loop (DoglegStrategy::StepAccepted's radius / mu updates do not read it, so running them
+// first changes nothing) -- the kernel's code stays within the instruction cache.
+__device__ __forceinline__ int trust_region_minimize(const Problem& q, double x[3], double& final_cost, int max_iter) {
   if (q.n == 0) {
     final_cost = 0.0;
     return 0;
   }
   double sums[10];
-  evaluate<true>(q, x, sums);
   Dog s;
   s.radius = 1e4;
   s.mu = 1e-8;
   s.reuse = 0;
   s.step_norm = 0.0;
   s.one_dim = 0;
-  double x_cost = sums[0];
-  double x_norm = nrm3(x[0], x[1], x[2]);
-  double gr0 = sums[1], gr1 = sums[2], gr2 = sums[3];
-  // jacobi scaling from the initial Jacobian, kept for the whole solve
-  const double sc0 = 1.0 / (1.0 + sqrt(sums[4])), sc1 = 1.0 / (1.0 + sqrt(sums[7])),
-               sc2 = 1.0 / (1.0 + sqrt(sums[9]));
+  s.eig_ready = 0;
+  double x_cost = 0.0, x_norm = 0.0;
+  double gr0 = 0.0, gr1 = 0.0, gr2 = 0.0;
+  double sc0 = 0.0, sc1 = 0.0, sc2 = 0.0;   // jacobi scaling from the initial Jacobian, kept for the whole solve
   int iter = 0, invalid = 0;
-  bool fresh = true;
+  bool relinearise = true, first = true;
   for (;;) {
-    if (fresh) {
+    if (relinearise) {
+      {
+        K7_T0;
+        evaluate<true>(q, x, sums);
+        K7_ACC(2);
+      }
+      x_cost = sums[0];
+      x_norm = nrm3(x[0], x[1], x[2]);
+      gr0 = sums[1];
+      gr1 = sums[2];
+      gr2 = sums[3];
+      if (first) {
+        sc0 = 1.0 / (1.0 + sqrt(sums[4]));
+        sc1 = 1.0 / (1.0 + sqrt(sums[7]));
+        sc2 = 1.0 / (1.0 + sqrt(sums[9]));
+        first = false;
+      }
       s.A00 = sums[4] * sc0 * sc0;
       s.A01 = sums[5] * sc0 * sc1;
       s.A02 = sums[6] * sc0 * sc2;
@@ -485,7 +543,7 @@ __device__ int trust_region_minimize(const Problem& q, double x[3], double& fina
       s.r0 = gr0 * sc0;
       s.r1 = gr1 * sc1;
       s.r2 = gr2 * sc2;
-      fresh = false;
+      relinearise = false;
     }
     // FinalizeIterationAndCheckIfMinimizerCanContinue
     if (iter >= max_iter) break;
@@ -530,17 +588,7 @@ __device__ int trust_region_minimize(const Problem& q, double x[3], double& fina
       x[0] = cand[0];
       x[1] = cand[1];
       x[2] = cand[2];
-      x_norm = nrm3(x[0], x[1], x[2]);
-      {
-        K7_T0;
-        evaluate<true>(q, x, sums);
-        K7_ACC(2);
-      }
-      x_cost = sums[0];
-      gr0 = sums[1];
-      gr1 = sums[2];
-      gr2 = sums[3];
-      fresh = true;
+      relinearise = true;
       if (rel < 0.25) s.radius *= 0.5;                         // DoglegStrategy::StepAccepted
       if (rel > 0.75) s.radius = fmax(s.radius, 3.0 * s.step_norm);
       if (s.radius > 1e16) s.radius = 1e16;
@@ -560,62 +608,42 @@ __device__ __forceinline__ bool partial_less(const GridPartial& a, const GridPar
   return a.cost < b.cost || (a.cost == b.cost && (a.d2 < b.d2 || (a.d2 == b.d2 && a.flat < b.flat)));
 }
 
-template <bool LDS_POINTS>
-__device__ void solve_body(const Ctx& c, SolveRec* rec, float2* s_yz, uint8_t* s_lab, double* s_red) {
-  const uint32_t f = blockIdx.x, slot = blockIdx.y;
-  SolveRec* out = &rec[2 * f + slot];
-  const uint64_t beg = c.off[f];
-  const uint32_t n = c.n_lab[f];
-
-  int flip = 0;
-  Problem q;
-  q.n = n;
-  q.bd = Board{(double)c.p.board_w, (double)c.p.board_h, c.p.grid_length, c.p.huber_delta};
-  q.red = s_red;
-  q.flip = &flip;
-  if (LDS_POINTS) {
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-      s_yz[i] = c.yz[beg + i];
-      s_lab[i] = c.lab[beg + i];
-    }
-    __syncthreads();
-    q.yz = s_yz;
-    q.lab = s_lab;
-  } else {
-    q.yz = c.yz + beg;
-    q.lab = c.lab + beg;
-  }
-
+// one wavefront: pass A then pass B of (frame f, phase slot) on the points q.yz / q.lab
+__device__ __forceinline__ void solve_wave(const Ctx& c, Problem& q, uint32_t f, uint32_t slot, SolveRec* out) {
   double x[3] = {0.0, 0.0, 0.0};
   int phase = (int)slot;
   if (c.p.phase_mode != 2) {
     phase = (c.p.phase_mode == 1) ? 1 : 0;
   }
-
-  double ca = 0, cb = 0;
   q.tlw = phase != 0;
-  q.oob = true;    // pass A (LidarCornersEst.cpp:403-405)
-  const int ia = trust_region_minimize(q, x, ca, c.p.max_iterations);
-  q.oob = false;   // pass B (:406-408)
-  const int ib = trust_region_minimize(q, x, cb, c.p.max_iterations);
+  double cost[2] = {0.0, 0.0};
+  int iters[2] = {0, 0};
+#pragma nounroll
+  for (int pass = 0; pass < 2; ++pass) {
+    q.oob = pass == 0;   // pass A: useOutofBoard (LidarCornersEst.cpp:403-405), pass B: not (:406-408)
+    double fc = 0.0;
+    const int it = trust_region_minimize(q, x, fc, c.p.max_iterations);
+    cost[pass] = fc;
+    iters[pass] = it;
+  }
 #ifdef ILCC_K7_TIMING
   if (blockIdx.x == 0 && threadIdx.x == 0) {
-    printf("K7a f0 slot %d: iters %d + %d; cycles dogleg %llu, evaluate<false> %llu, evaluate<true> %llu\n", (int)blockIdx.y, ia, ib, g_k7_t[0], g_k7_t[1], g_k7_t[2]);
+    printf("K7a f0 slot %d: iters %d + %d; cycles dogleg %llu, evaluate<false> %llu, evaluate<true> %llu\n", (int)slot, iters[0], iters[1], g_k7_t[0], g_k7_t[1], g_k7_t[2]);
     g_k7_t[0] = g_k7_t[1] = g_k7_t[2] = 0;
   }
 #endif
   q.oob = true;
   double cs[10];
   evaluate<false>(q, x, cs);
-  if (threadIdx.x == 0) {
+  if (lane_id() == 0) {
     out->x[0] = x[0];
     out->x[1] = x[1];
     out->x[2] = x[2];
-    out->cost_a = ca;
-    out->cost_b = cb;
+    out->cost_a = cost[0];
+    out->cost_b = cost[1];
     out->sel = cs[0];
-    out->iters_a = ia;
-    out->iters_b = ib;
+    out->iters_a = iters[0];
+    out->iters_b = iters[1];
     out->phase = phase;
     out->valid = 1;
     out->margin = 0.0;
@@ -624,20 +652,47 @@ __device__ void solve_body(const Ctx& c, SolveRec* rec, float2* s_yz, uint8_t* s
   }
 }
 
-__global__ __launch_bounds__(kSolveThreads) void k7a_local_solve(Ctx c, SolveRec* rec) {
+// grid: ceil(n_frames * n_slots / kSolveWaves) workgroups; wavefront w of workgroup b runs solve b * kSolveWaves + w =
+// (frame, slot) = (solve / n_slots, solve % n_slots): with two slots the wavefronts 2k and 2k + 1 share a frame and its
+// staged points.  Dynamic LDS: (kSolveWaves / n_slots) frames x grid_lds_points x 9 bytes.
+__global__ __launch_bounds__(kSolveThreads) void k7a_local_solve(Ctx c, SolveRec* rec, int n_slots) {
   extern __shared__ __align__(16) unsigned char smem[];
-  __shared__ double s_red[2 * kSolveWaves * 10];
-  const uint32_t f = blockIdx.x;
-  if (c.res[f].status != ILCC_OK) {
-    if (threadIdx.x == 0) rec[2 * f + blockIdx.y].valid = 0;
+  const uint32_t wave = (uint32_t)wave_id();
+  const uint32_t solve = blockIdx.x * (uint32_t)kSolveWaves + wave;
+  const uint32_t f = solve / (uint32_t)n_slots, slot = solve % (uint32_t)n_slots;
+  const bool live = f < c.n_frames && c.res[f].status == ILCC_OK;
+  const uint32_t n = live ? c.n_lab[f] : 0u;
+  const bool in_lds = n <= c.grid_lds_points;
+  // staging: the n_slots wavefronts of a frame copy its points together
+  const uint32_t local_frame = wave / (uint32_t)n_slots;
+  float2* s_yz = reinterpret_cast<float2*>(smem) + (size_t)local_frame * c.grid_lds_points;
+  uint8_t* s_lab = smem + sizeof(float2) * (size_t)c.grid_lds_points * (size_t)(kSolveWaves / n_slots) + (size_t)local_frame * c.grid_lds_points;
+  const uint64_t beg = live ? c.off[f] : 0u;
+  if (live && in_lds) {
+    for (uint32_t i = slot * ILCC_WAVE + (uint32_t)lane_id(); i < n; i += (uint32_t)n_slots * ILCC_WAVE) {
+      s_yz[i] = c.yz[beg + i];
+      s_lab[i] = c.lab[beg + i];
+    }
+  }
+  __syncthreads();   // the only barrier: from here on every wavefront is on its own
+  if (f >= c.n_frames) return;
+  SolveRec* out = &rec[2 * f + slot];
+  if (!live) {
+    if (lane_id() == 0) out->valid = 0;
     return;
   }
-  float2* s_yz = reinterpret_cast<float2*>(smem);
-  uint8_t* s_lab = smem + sizeof(float2) * (size_t)c.grid_lds_points;
-  if (c.n_lab[f] <= c.grid_lds_points)
-    solve_body<true>(c, rec, s_yz, s_lab, s_red);
-  else
-    solve_body<false>(c, rec, s_yz, s_lab, s_red);
+  Problem q;
+  q.n = n;
+  q.bd = make_board(c.p);
+  if (in_lds) {
+    q.yz = s_yz;
+    q.lab = s_lab;
+    solve_wave(c, q, f, slot, out);
+  } else {   // a frame above the handle's LDS capacity (it grows after the batch): the points stay in HBM / L2
+    q.yz = c.yz + beg;
+    q.lab = c.lab + beg;
+    solve_wave(c, q, f, slot, out);
+  }
 }
 
 // ------------------------------------------------------------------ K7r pattern refine (ILCC_SOLVER_GRID)
@@ -1293,20 +1348,16 @@ __global__ __launch_bounds__(kSolveThreads) void k7b_corners(Ctx c, const SolveR
   if (tid == 0 && c.p.solver == ILCC_SOLVER_GRID && c.p.ambiguity_eps > 0.0 && best.margin < c.p.ambiguity_eps) r->status = ILCC_AMBIGUOUS;
 }
 
-// test entry: one solve on frame 0's labelled points (global memory)
-__global__ __launch_bounds__(kSolveThreads) void k7_local_solve_test(Ctx c, int tlw, int use_oob, double* theta_t,
+// test entry: one solve (one wavefront) on frame 0's labelled points (global memory)
+__global__ __launch_bounds__(ILCC_WAVE) void k7_local_solve_test(Ctx c, int tlw, int use_oob, double* theta_t,
                                                                  double* cost_iters) {
   Problem q;
   q.yz = c.yz;
   q.lab = c.lab;
   q.n = c.n_lab[0];
-  q.bd = Board{(double)c.p.board_w, (double)c.p.board_h, c.p.grid_length, c.p.huber_delta};
+  q.bd = make_board(c.p);
   q.tlw = tlw != 0;
   q.oob = use_oob != 0;
-  __shared__ double s_red[2 * kSolveWaves * 10];
-  int flip = 0;
-  q.red = s_red;
-  q.flip = &flip;
   double x[3] = {theta_t[0], theta_t[1], theta_t[2]};
   double cost = 0;
   const int it = trust_region_minimize(q, x, cost, c.p.max_iterations);
@@ -1321,7 +1372,9 @@ __global__ __launch_bounds__(kSolveThreads) void k7_local_solve_test(Ctx c, int 
 
 hipError_t set_kernel_attributes_k7() {
   const int cap = (int)((sizeof(float2) + 1) * (size_t)kGridLdsPointsMax);
-  hipError_t e = hipFuncSetAttribute((const void*)k7a_local_solve, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+  // (K7a stages up to kSolveWaves frames per workgroup; launch_refine_corners falls back to the global-memory path -- LDS capacity 0 --
+  // when they would not fit the 160 KB of a CU)
+  hipError_t e = hipFuncSetAttribute((const void*)k7a_local_solve, hipFuncAttributeMaxDynamicSharedMemorySize, kSolveLdsMax);
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k7r_pattern_refine, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
   return e;
 }
@@ -1339,14 +1392,20 @@ void launch_pattern_refine_test(const Ctx& c, hipStream_t s, RefineOut* d_io) {
 
 void launch_refine_corners(const Ctx& c, hipStream_t s) {
   const int n_slots = (c.p.solver == ILCC_SOLVER_REFERENCE_LOCAL && c.p.phase_mode == 2) ? 2 : 1;
-  const size_t lds = (sizeof(float2) + 1) * (size_t)c.grid_lds_points;
-  hipLaunchKernelGGL(k7a_local_solve, dim3(c.n_frames, n_slots), dim3(kSolveThreads), lds, s, c, c.solve_rec);
+  Ctx ck = c;
+  size_t lds = (sizeof(float2) + 1) * (size_t)c.grid_lds_points * (size_t)(kSolveWaves / n_slots);
+  if (lds > (size_t)kSolveLdsMax) {   // very large frames: the points stay in HBM / L2
+    ck.grid_lds_points = 0;
+    lds = 0;
+  }
+  const uint32_t solves = c.n_frames * (uint32_t)n_slots;
+  hipLaunchKernelGGL(k7a_local_solve, dim3((solves + kSolveWaves - 1) / kSolveWaves), dim3(kSolveThreads), lds, s, ck, c.solve_rec, n_slots);
   hipLaunchKernelGGL(k7b_corners, dim3(c.n_frames), dim3(kSolveThreads), 0, s, c, c.solve_rec, n_slots);
 }
 
 void launch_local_solve(const Ctx& c, hipStream_t s, int32_t tlw, int32_t use_oob, double* theta_t,
                         double* cost_iters) {
-  hipLaunchKernelGGL(k7_local_solve_test, dim3(1), dim3(kSolveThreads), 0, s, c, tlw, use_oob, theta_t, cost_iters);
+  hipLaunchKernelGGL(k7_local_solve_test, dim3(1), dim3(ILCC_WAVE), 0, s, c, tlw, use_oob, theta_t, cost_iters);
 }
 
 // K9 pack_records: ilcc_result[] (device) -> fixed-size float records [n_frames, ILCC_RECORD_HEADER + 3 * n_corners]

@@ -3,7 +3,8 @@ time -- per-dispatch counters of every kernel of the path without bench.py's oth
 two) is a warm-up that tools/pmc_summary.py drops: round 3's config-5 file averaged a first dispatch in that issued 4.3 x the K6
 instructions -- its handle was reserved for 4500 labelled points and these frames hold up to ~5.4 k, so the frames above the
 reserved capacity walked their points through L2 until the handle had grown.
-usage: pmc_target.py [frames_per_batch=512] [config=2|5]      (the batch sizes bench.py runs: 1024 / 128)"""
+usage: pmc_target.py [frames_per_batch=512] [config=2|5] [solver=1|0]     (the batch sizes bench.py runs: 1024 / 128;
+solver 0 = ILCC_SOLVER_REFERENCE_LOCAL: K7a instead of K6 + K7r)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -13,6 +14,7 @@ from lidar_camera_calibration_amd import _native as N
 config = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 F = int(sys.argv[1]) if len(sys.argv) > 1 else (1024 if config == 2 else 128)
 params = N.default_params()
+params.solver = int(sys.argv[3]) if len(sys.argv) > 3 else N.SOLVER_GRID
 if config == 5:      # BASELINE configs[4], as bench.py --config 5 sets it up
     lidar = synth.hdl64()
     clouds, clicks, _, _ = synth.make_batch(F, lidar, synth.Board(9, 12, 0.10), seed=0xC0FFEE, range_m=(2.0, 3.0),
