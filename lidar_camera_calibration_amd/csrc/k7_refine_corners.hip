@@ -130,6 +130,10 @@ __device__ __forceinline__ void huber(double a, double r, double s, double& rho0
 // ------------------------------------------------------------------ wavefront-wide evaluation
 constexpr int kSolveWaves = kSolveThreads / ILCC_WAVE;   // solves per K7a workgroup
 constexpr int kSolveLdsMax = 144 * 1024;                 // K7a: dynamic LDS bound (a CU has 160 KB)
+#ifndef ILCC_K7A_WIDE_MAX
+#define ILCC_K7A_WIDE_MAX 256
+#endif
+constexpr int kSolveWideMaxFrames = ILCC_K7A_WIDE_MAX;    // K7a: batches up to this size give every solve a whole workgroup
 
 struct Problem {
   const float2* yz;      // LDS or global
@@ -137,6 +141,8 @@ struct Problem {
   uint32_t n;
   SolveBoard bd;
   bool tlw, oob;
+  double* red;           // WIDE only -- LDS: 2 x kSolveRedDoubles (double-buffered partial sums)
+  int* flip;             // WIDE only -- per-thread toggle (register copy lives in the caller)
 };
 
 // v[lane ^ MASK] for a 64-bit value, in registers only: v_permlane32_swap / v_permlane16_swap (gfx950) and
@@ -188,42 +194,93 @@ __device__ __forceinline__ double wave_allsum(double v) {
 }
 
 // sums[0] = cost ; if JAC: sums[1..3] = J^T r, sums[4..9] = upper J^T J (00,01,02,11,12,22),
-// with Ceres' Corrector applied (rows scaled by sqrt(rho')).  One wavefront: lane l takes the points l, l + 64, ...;
-// the same value in every lane on return.
+// with Ceres' Corrector applied (rows scaled by sqrt(rho')).  The same value in every lane on return.
+// ONE summation order for both layouts, so that a frame's result does not depend on the size of the batch it came in:
+// lane l owns the points l, l + 64, l + 128, ...; the point l + 64 m goes to the lane's partial sum a[m mod 4] (each
+// partial adds its points in increasing order); the lane's sum is ((a0 + a1) + a2) + a3; the 64 lane sums are
+// combined by the butterfly.
+//   WIDE = false: one wavefront per solve.  The cost alone keeps the four partials in registers (one walk over the
+//   points); the Jacobian pass (one evaluation in six) walks the four residue classes one after the other.
+//   WIDE = true (small batches, where latency counts and the chip is not full): the whole 256-thread workgroup works
+//   on ONE solve, wavefront w computes the partials a[w]; wavefronts -> LDS -> everyone, ONE barrier per call
+//   (double-buffered slots); every thread then runs the trust-region bookkeeping redundantly.
 template <bool JAC>
-__device__ __forceinline__ void evaluate(const Problem& q, const double x[3], double sums[10]) {
-  double sn, cs;
-  sincos(x[0], &sn, &cs);
-  double acc[10];
+__device__ __forceinline__ void add_point(const Problem& q, const double x[3], double cs, double sn, uint32_t p, double acc[10]) {
+  const float2 v = q.yz[p];
+  double jac[3];
+  const double res = residual<JAC>(x, cs, sn, (double)v.x, (double)v.y, q.bd, q.tlw, q.lab[p] != 0, q.oob, jac);
+  double r0, r1;
+  huber(q.bd.delta, res, res * res, r0, r1);
+  acc[0] += 0.5 * r0;
+  if (JAC) {
+    const double sr = sqrt(r1);
+    const double rc = sr * res;
+    const double j0 = sr * jac[0], j1 = sr * jac[1], j2 = sr * jac[2];
+    acc[1] += j0 * rc;
+    acc[2] += j1 * rc;
+    acc[3] += j2 * rc;
+    acc[4] += j0 * j0;
+    acc[5] += j0 * j1;
+    acc[6] += j0 * j2;
+    acc[7] += j1 * j1;
+    acc[8] += j1 * j2;
+    acc[9] += j2 * j2;
+  }
+}
+// the partial sums a[w] of this lane: points first, first + 256, ...
+template <bool JAC>
+__device__ __forceinline__ void accumulate_class(const Problem& q, const double x[3], double cs, double sn, uint32_t first,
+                                                 double acc[10]) {
 #pragma unroll
   for (int k = 0; k < 10; ++k) acc[k] = 0.0;
 #pragma unroll 2
-  for (uint32_t p = lane_id(); p < q.n; p += ILCC_WAVE) {
-    const float2 v = q.yz[p];
-    double jac[3];
-    const double res = residual<JAC>(x, cs, sn, (double)v.x, (double)v.y, q.bd, q.tlw, q.lab[p] != 0,
-                                     q.oob, jac);
-    double r0, r1;
-    huber(q.bd.delta, res, res * res, r0, r1);
-    acc[0] += 0.5 * r0;
-    if (JAC) {
-      const double sr = sqrt(r1);
-      const double rc = sr * res;
-      const double j0 = sr * jac[0], j1 = sr * jac[1], j2 = sr * jac[2];
-      acc[1] += j0 * rc;
-      acc[2] += j1 * rc;
-      acc[3] += j2 * rc;
-      acc[4] += j0 * j0;
-      acc[5] += j0 * j1;
-      acc[6] += j0 * j2;
-      acc[7] += j1 * j1;
-      acc[8] += j1 * j2;
-      acc[9] += j2 * j2;
-    }
-  }
+  for (uint32_t p = first; p < q.n; p += (uint32_t)(4 * ILCC_WAVE)) add_point<JAC>(q, x, cs, sn, p, acc);
+}
+
+constexpr int kSolveRedDoubles = 10 * 4 * ILCC_WAVE;   // WIDE: one exchange buffer (10 sums x 4 partials x 64 lanes)
+
+template <bool JAC, bool WIDE>
+__device__ __forceinline__ void evaluate(const Problem& q, const double x[3], double sums[10]) {
+  static_assert(kSolveThreads == 4 * ILCC_WAVE, "the summation order is defined on four partial sums per lane");
+  double sn, cs;
+  sincos(x[0], &sn, &cs);
   constexpr int NV = JAC ? 10 : 1;
+  const uint32_t lane = (uint32_t)lane_id();
+  double tot[10];
+  if (WIDE) {
+    double acc[10];
+    accumulate_class<JAC>(q, x, cs, sn, threadIdx.x, acc);
+    *q.flip ^= 1;
+    double* slot = q.red + (*q.flip) * kSolveRedDoubles;
 #pragma unroll
-  for (int k = 0; k < NV; ++k) sums[k] = wave_allsum(acc[k]);
+    for (int k = 0; k < NV; ++k) slot[(k * 4 + wave_id()) * ILCC_WAVE + lane] = acc[k];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const double* sk = slot + k * 4 * ILCC_WAVE + lane;
+      tot[k] = ((sk[0] + sk[ILCC_WAVE]) + sk[2 * ILCC_WAVE]) + sk[3 * ILCC_WAVE];
+    }
+  } else if (JAC) {
+#pragma nounroll
+    for (int w = 0; w < 4; ++w) {
+      double acc[10];
+      accumulate_class<true>(q, x, cs, sn, (uint32_t)w * ILCC_WAVE + lane, acc);
+#pragma unroll
+      for (int k = 0; k < NV; ++k) tot[k] = (w == 0) ? acc[k] : tot[k] + acc[k];
+    }
+  } else {
+    double a0[10], a1[10], a2[10], a3[10];   // ([0] only: the cost)
+    a0[0] = a1[0] = a2[0] = a3[0] = 0.0;
+    for (uint32_t p = lane; p < q.n; p += (uint32_t)(4 * ILCC_WAVE)) {
+      add_point<false>(q, x, cs, sn, p, a0);
+      if (p + ILCC_WAVE < q.n) add_point<false>(q, x, cs, sn, p + ILCC_WAVE, a1);
+      if (p + 2 * ILCC_WAVE < q.n) add_point<false>(q, x, cs, sn, p + 2 * ILCC_WAVE, a2);
+      if (p + 3 * ILCC_WAVE < q.n) add_point<false>(q, x, cs, sn, p + 3 * ILCC_WAVE, a3);
+    }
+    tot[0] = ((a0[0] + a1[0]) + a2[0]) + a3[0];
+  }
+#pragma unroll
+  for (int k = 0; k < NV; ++k) sums[k] = wave_allsum(tot[k]);
 }
 
 // ------------------------------------------------------------------ dogleg bookkeeping (wave-uniform values)
@@ -498,6 +555,7 @@ __device__ unsigned long long g_k7_t[4];
 // One call site per evaluate<> flavour: the Jacobian pass of the start and of every accepted step is the `relinearise`
 // block at the head of the loop (DoglegStrategy::StepAccepted's radius / mu updates do not read it, so running them
 // first changes nothing) -- the kernel's code stays within the instruction cache.
+template <bool WIDE>
 __device__ __forceinline__ int trust_region_minimize(const Problem& q, double x[3], double& final_cost, int max_iter) {
   if (q.n == 0) {
     final_cost = 0.0;
@@ -520,7 +578,7 @@ __device__ __forceinline__ int trust_region_minimize(const Problem& q, double x[
     if (relinearise) {
       {
         K7_T0;
-        evaluate<true>(q, x, sums);
+        evaluate<true, WIDE>(q, x, sums);
         K7_ACC(2);
       }
       x_cost = sums[0];
@@ -575,7 +633,7 @@ __device__ __forceinline__ int trust_region_minimize(const Problem& q, double x[
     double cs[10];
     {
       K7_T0;
-      evaluate<false>(q, cand, cs);
+      evaluate<false, WIDE>(q, cand, cs);
       K7_ACC(1);
     }
     const double cand_cost = cs[0];
@@ -608,7 +666,8 @@ __device__ __forceinline__ bool partial_less(const GridPartial& a, const GridPar
   return a.cost < b.cost || (a.cost == b.cost && (a.d2 < b.d2 || (a.d2 == b.d2 && a.flat < b.flat)));
 }
 
-// one wavefront: pass A then pass B of (frame f, phase slot) on the points q.yz / q.lab
+// pass A then pass B of (frame f, phase slot) on the points q.yz / q.lab: one wavefront (WIDE = false) or the whole workgroup
+template <bool WIDE>
 __device__ __forceinline__ void solve_wave(const Ctx& c, Problem& q, uint32_t f, uint32_t slot, SolveRec* out) {
   double x[3] = {0.0, 0.0, 0.0};
   int phase = (int)slot;
@@ -622,7 +681,7 @@ __device__ __forceinline__ void solve_wave(const Ctx& c, Problem& q, uint32_t f,
   for (int pass = 0; pass < 2; ++pass) {
     q.oob = pass == 0;   // pass A: useOutofBoard (LidarCornersEst.cpp:403-405), pass B: not (:406-408)
     double fc = 0.0;
-    const int it = trust_region_minimize(q, x, fc, c.p.max_iterations);
+    const int it = trust_region_minimize<WIDE>(q, x, fc, c.p.max_iterations);
     cost[pass] = fc;
     iters[pass] = it;
   }
@@ -634,8 +693,8 @@ __device__ __forceinline__ void solve_wave(const Ctx& c, Problem& q, uint32_t f,
 #endif
   q.oob = true;
   double cs[10];
-  evaluate<false>(q, x, cs);
-  if (lane_id() == 0) {
+  evaluate<false, WIDE>(q, x, cs);
+  if (WIDE ? threadIdx.x == 0 : lane_id() == 0) {
     out->x[0] = x[0];
     out->x[1] = x[1];
     out->x[2] = x[2];
@@ -687,11 +746,50 @@ __global__ __launch_bounds__(kSolveThreads) void k7a_local_solve(Ctx c, SolveRec
   if (in_lds) {
     q.yz = s_yz;
     q.lab = s_lab;
-    solve_wave(c, q, f, slot, out);
+    solve_wave<false>(c, q, f, slot, out);
   } else {   // a frame above the handle's LDS capacity (it grows after the batch): the points stay in HBM / L2
     q.yz = c.yz + beg;
     q.lab = c.lab + beg;
-    solve_wave(c, q, f, slot, out);
+    solve_wave<false>(c, q, f, slot, out);
+  }
+}
+
+// Small batches (n_frames <= kSolveWideMaxFrames: fewer solves than SIMDs): one 256-thread workgroup per (frame, slot), the
+// layout of rounds 1-5 on this round's arithmetic -- 128 frames alone on the chip: 0.62 ms (round 5), 1.11 ms (one wavefront per
+// solve), see profiles/README.md for this variant.  Both layouts add the same terms in the same order (evaluate<>): a frame's
+// result does not depend on the batch it came in.
+__global__ __launch_bounds__(kSolveThreads) void k7a_local_solve_wide(Ctx c, SolveRec* rec) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  __shared__ double s_red[2 * kSolveRedDoubles];
+  const uint32_t f = blockIdx.x, slot = blockIdx.y;
+  SolveRec* out = &rec[2 * f + slot];
+  if (c.res[f].status != ILCC_OK) {
+    if (threadIdx.x == 0) out->valid = 0;
+    return;
+  }
+  float2* s_yz = reinterpret_cast<float2*>(smem);
+  uint8_t* s_lab = smem + sizeof(float2) * (size_t)c.grid_lds_points;
+  const uint64_t beg = c.off[f];
+  const uint32_t n = c.n_lab[f];
+  int flip = 0;
+  Problem q;
+  q.n = n;
+  q.bd = make_board(c.p);
+  q.red = s_red;
+  q.flip = &flip;
+  if (n <= c.grid_lds_points) {
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+      s_yz[i] = c.yz[beg + i];
+      s_lab[i] = c.lab[beg + i];
+    }
+    __syncthreads();
+    q.yz = s_yz;
+    q.lab = s_lab;
+    solve_wave<true>(c, q, f, slot, out);
+  } else {
+    q.yz = c.yz + beg;
+    q.lab = c.lab + beg;
+    solve_wave<true>(c, q, f, slot, out);
   }
 }
 
@@ -1360,7 +1458,7 @@ __global__ __launch_bounds__(ILCC_WAVE) void k7_local_solve_test(Ctx c, int tlw,
   q.oob = use_oob != 0;
   double x[3] = {theta_t[0], theta_t[1], theta_t[2]};
   double cost = 0;
-  const int it = trust_region_minimize(q, x, cost, c.p.max_iterations);
+  const int it = trust_region_minimize<false>(q, x, cost, c.p.max_iterations);
   if (threadIdx.x == 0) {
     theta_t[0] = x[0];
     theta_t[1] = x[1];
@@ -1375,6 +1473,7 @@ hipError_t set_kernel_attributes_k7() {
   // (K7a stages up to kSolveWaves frames per workgroup; launch_refine_corners falls back to the global-memory path -- LDS capacity 0 --
   // when they would not fit the 160 KB of a CU)
   hipError_t e = hipFuncSetAttribute((const void*)k7a_local_solve, hipFuncAttributeMaxDynamicSharedMemorySize, kSolveLdsMax);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k7a_local_solve_wide, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k7r_pattern_refine, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
   return e;
 }
@@ -1392,6 +1491,12 @@ void launch_pattern_refine_test(const Ctx& c, hipStream_t s, RefineOut* d_io) {
 
 void launch_refine_corners(const Ctx& c, hipStream_t s) {
   const int n_slots = (c.p.solver == ILCC_SOLVER_REFERENCE_LOCAL && c.p.phase_mode == 2) ? 2 : 1;
+  if (c.n_frames <= (uint32_t)kSolveWideMaxFrames) {
+    const size_t lds1 = (sizeof(float2) + 1) * (size_t)c.grid_lds_points;
+    hipLaunchKernelGGL(k7a_local_solve_wide, dim3(c.n_frames, n_slots), dim3(kSolveThreads), lds1, s, c, c.solve_rec);
+    hipLaunchKernelGGL(k7b_corners, dim3(c.n_frames), dim3(kSolveThreads), 0, s, c, c.solve_rec, n_slots);
+    return;
+  }
   Ctx ck = c;
   size_t lds = (sizeof(float2) + 1) * (size_t)c.grid_lds_points * (size_t)(kSolveWaves / n_slots);
   if (lds > (size_t)kSolveLdsMax) {   // very large frames: the points stay in HBM / L2

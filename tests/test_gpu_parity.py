@@ -298,6 +298,39 @@ def test_local_solver_matches_oracle(ob, est, frames, tlw, oob):
     assert it == 0 and c == 0.0 and t[0] == 0.1
 
 
+def test_reference_solver_one_wavefront_per_solve_equals_the_workgroup_layout(ob):
+    """K7a has two layouts: batches above 256 frames give every (frame, phase) solve ONE wavefront (four solves per
+    workgroup, no barrier after staging), smaller batches a whole 256-thread workgroup.  Both add the terms in the same
+    order: a frame's record is bit-identical whichever batch it came in, and both walk the oracle's iterations."""
+    F = 272
+    clouds, clicks, _, _ = synth.make_batch(F, seed=0xBEEF)
+    p = N.default_params()
+    p.solver = N.SOLVER_REFERENCE_LOCAL
+    e = LidarCornersBatch(F, 28800, p)
+    big = e.extract(clouds, clicks)
+    big = [(r.status, r.iters_a, r.iters_b, tuple(r.theta_t), r.cost_a, r.cost_b, r.sel_cost, r.phase, r.corners_array().copy()) for r in big]
+    small = e.extract(clouds[100:124], clicks[100:124])
+    n_ok = 0
+    for k, r in enumerate(small):
+        b = big[100 + k]
+        assert (r.status, r.iters_a, r.iters_b, tuple(r.theta_t), r.cost_a, r.cost_b, r.sel_cost, r.phase) == b[:8], k
+        assert np.array_equal(r.corners_array(), b[8])
+        n_ok += r.status == N.OK
+    assert n_ok >= 20
+    op = _oparams(ob, N.SOLVER_REFERENCE_LOCAL)
+    for f in list(range(0, 8)) + [271]:
+        o = ob.extract(clouds[f], clicks[f], op)
+        b = big[f]
+        assert b[0] == o.status
+        if o.status != N.OK:
+            continue
+        assert (b[1], b[2], b[7]) == (o.iters_a, o.iters_b, o.phase), f
+        assert np.allclose(b[3], o.theta_t, atol=1e-7)
+        assert b[4] == pytest.approx(o.cost_a, rel=1e-9, abs=1e-12) and b[5] == pytest.approx(o.cost_b, rel=1e-9, abs=1e-12)
+        assert np.abs(b[8] - ob.result_corners(o)).max() < 1e-5
+    e.close()
+
+
 def test_pattern_refine_kernel_matches_the_oracle_exactly(ob, est, frames):
     """K7r alone (ilcc_pattern_refine) vs orc_pattern_refine on the labelled points of real frames, from the grid
     argmin and from displaced starts (incl. one square off with the colours swapped -> a basin hop): lattice
