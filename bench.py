@@ -67,7 +67,7 @@ VALU_ISSUE_PEAK_T = 78.6
 # tools/k6_isa_count.sh in the gfx950 assembly of the term functions (probe kernels in csrc/k6_grid_cost.hip, the library's
 # compile flags): border-class point (out-of-board logic included) / interior-class point (it cannot leave the board under
 # any translation of the grid).  Bound tests, tile prologues, address arithmetic and staging are NOT credited.  The
-# committed output of the script is profiles/r03_k6_isa_count.json; tests/test_host_logic.py::test_k6_credit_matches_the_isa
+# committed output of the script is profiles/r06_k6_isa_count.json (with the opcode histogram); tests/test_host_logic.py::test_k6_credit_matches_the_isa
 # re-runs the script and fails when these constants, that file and the current source disagree.
 K6_VALU_OPS_BORDER = 29.0
 K6_VALU_OPS_INTERIOR = 15.0
@@ -75,14 +75,18 @@ K6_VALU_OPS_INTERIOR = 15.0
 K6_VALU_OPS_BOX = 24.0
 # PMC passes of the K6 stage at the batch sizes this bench runs (tools/gpu_pmc.sh -> profiles/): per-launch counters of one
 # batch alone on the chip.  roofline.traffic and roofline.issued_vs_credited are computed from these files at run time.
-PMC_FILES = {(2, 1024): ("profiles/r05_pmc_cfg2_1024f.csv", "profiles/r04_pmc_cfg2_1024f.csv"),
+PMC_FILES = {(2, 1024): ("profiles/r06_pmc_cfg2_1024f.csv", "profiles/r05_pmc_cfg2_1024f.csv", "profiles/r04_pmc_cfg2_1024f.csv"),
              (2, 512): ("profiles/r04_pmc_cfg2_512f.csv", "profiles/r03_pmc_cfg2_512f.csv"),
-             (5, 128): ("profiles/r05_pmc_cfg5_128f.csv",),
+             (5, 128): ("profiles/r06_pmc_cfg5_128f.csv", "profiles/r05_pmc_cfg5_128f.csv"),
              (5, 64): ("profiles/r04_pmc_cfg5_64f.csv",)}   # (round 3's config-5 file averaged a cold first dispatch in: not used)
 # rocprofv3 --kernel-trace --stats of this bench's own command (tools/gpu_profile.sh): pipelined (4 batches in flight) and
 # --in-flight 1 (one batch alone on the chip).  roofline.rocprof recomputes `frac` from their per-kernel averages.
-KSTATS_FILES = {2: ("profiles/r05_kernel_stats_bench_20_5.csv", "profiles/r05_kernel_stats_bench_inflight1.csv"),
-                5: ("profiles/r05_kernel_stats_config5.csv", "profiles/r05_kernel_stats_config5_inflight1.csv")}
+KSTATS_FILES = {2: (("profiles/r06_kernel_stats_bench_20_5.csv", "profiles/r05_kernel_stats_bench_20_5.csv"),
+                    ("profiles/r06_kernel_stats_bench_inflight1.csv", "profiles/r05_kernel_stats_bench_inflight1.csv")),
+                5: (("profiles/r06_kernel_stats_config5.csv", "profiles/r05_kernel_stats_config5.csv"),
+                    ("profiles/r06_kernel_stats_config5_inflight1.csv", "profiles/r05_kernel_stats_config5_inflight1.csv"))}
+# the term's opcode histogram priced per issue class (tools/k6_issue_ceiling.py): roofline.mix_ceiling
+ISSUE_CEILING_FILE = "profiles/r06_k6_issue_ceiling.json"
 
 
 def k6_pmc(config, frames_per_batch):
@@ -100,7 +104,9 @@ def k6_pmc(config, frames_per_batch):
         return None
     f = lambda r, k: float(r[k]) if r.get(k) not in (None, "") else 0.0
     per = lambda r: f(r, "launches_per_batch") or 1.0
-    full = max(rows, key=lambda r: f(r, "SQ_INSTS_VALU"))
+    # the full pass = the k6_grid_cost instance that issues most (config 5's common pre-pass issues MORE than the full pass: round 5's
+    # issue_utilisation_full_pass_alone of that config was the pre-pass's)
+    full = max([r for r in rows if "k6_grid_cost" in r["kernel"]] or rows, key=lambda r: f(r, "SQ_INSTS_VALU"))
     return {"file": path,
             "traffic_bytes": int(sum(per(r) * (2.0 * f(r, "FETCH_SIZE") + f(r, "WRITE_SIZE")) * 1024.0 for r in rows)),
             "valu_wave_instr": sum(per(r) * f(r, "SQ_INSTS_VALU") for r in rows),
@@ -114,10 +120,11 @@ def k6_rocprof(config, credited_lane_instr_per_batch):
     (= calls of k5w_walk_order, one per batch), pipelined and with one batch alone on the chip."""
     import csv
     out = {}
-    for tag, path in zip(("pipelined", "in_flight_1"), KSTATS_FILES.get(config, ())):
-        full = os.path.join(ROOT, path)
-        if not os.path.exists(full):
+    for tag, paths in zip(("pipelined", "in_flight_1"), KSTATS_FILES.get(config, ())):
+        path = next((q for q in paths if os.path.exists(os.path.join(ROOT, q))), None)
+        if not path:
             continue
+        full = os.path.join(ROOT, path)
         rows = list(csv.DictReader(open(full)))
         k6 = [r for r in rows if any(k in r.get("Name", "") for k in ("k6_grid_cost", "k6_locate", "k6_anchor", "k6_group_prepass", "k6_triple_prepass"))]
         batches = next((int(r["Calls"]) for r in rows if "k5w_walk_order" in r.get("Name", "")), 0)
@@ -129,6 +136,24 @@ def k6_rocprof(config, credited_lane_instr_per_batch):
                     "kernels_us_per_batch": {r["Name"].replace("ilcc::", "").replace("void ", "")[:40]: round(float(r["TotalDurationNs"]) / batches / 1e3, 1) for r in k6},
                     "what": "THIS run's credited work over the committed profile's per-batch K6 time"}
     return out or None
+
+
+def k6_mix_ceiling(evals_border, evals_interior, box_evals):
+    """The issue ceiling of THIS run's credited instruction mix: every credited instruction priced at its class's issue cost (full
+    rate: one wave64 instruction per SIMD every 2 cycles = 78.6 T lane-instr/s chip-wide; floor / fract / min / max / med3 / v_cmp /
+    v_cndmask / packed ops: half of that) -- tools/k6_issue_ceiling.py's histogram of the term's gfx950 assembly.  Returns
+    (ceiling in T lane-instr/s, the same priced at the rates the micro-benchmark measured, file) or None."""
+    path = os.path.join(ROOT, ISSUE_CEILING_FILE)
+    if not os.path.exists(path):
+        return None
+    c = json.load(open(path))["classes"]
+    n = {"border": evals_border, "interior": evals_interior, "box": box_evals}
+    instr = sum(n[k] * c[k]["valu_instr"] for k in n)
+    if instr <= 0:
+        return None
+    units = sum(n[k] * c[k]["issue_units_nominal"] for k in n)
+    t_meas = sum(n[k] * c[k]["valu_instr"] / c[k]["mix_ceiling_measured_T"] for k in n)
+    return VALU_ISSUE_PEAK_T * instr / units, instr / t_meas, ISSUE_CEILING_FILE
 
 
 def _gen_chunk(args):
@@ -195,7 +220,11 @@ def main():
     ap.add_argument("--config", type=int, default=2, choices=(2, 5),
                     help="2: BASELINE configs[1] frames (the headline); 5: configs[4], the dense-cloud fine-grid run")
     ap.add_argument("--frames-per-batch", type=int, default=0, help="default 1024 (config 2) / 128 (config 5)")
-    ap.add_argument("--batches-per-step", type=int, default=0, help="distinct batches per step and GPU: default 1")
+    ap.add_argument("--batches-per-step", type=int, default=0, help="batches per step and GPU: default 1")
+    ap.add_argument("--distinct-batches", type=int, default=0,
+                    help="distinct batches resident per GPU that the steps rotate through (default 4: step s submits batch s mod 4, "
+                         "no step repeats its predecessor's data); at least --batches-per-step")
+    ap.add_argument("--no-config5-leg", action="store_true", help="skip the short config-5 leg of the default run (config5_value / config5_frac)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline time budget (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the H2D-inclusive / reference-mode legs (profiling runs)")
@@ -228,6 +257,11 @@ def main():
     F = args.frames_per_batch or (1024 if args.config == 2 else 128)
     B = max(1, args.batches_per_step or 1)
     FS = F * B                                        # frames per step and GPU
+    # distinct batches resident per GPU: step s submits the batches (s * B + b) mod NB -- round 5 walked the SAME 1024 frames every
+    # step (the labelled points, walk layouts and bounds of step s were bit-identical to step s - 1's); four distinct batches = 1.9 GB
+    # of config-2 input per GPU
+    NB = max(B, args.distinct_batches or 4)
+    NB = (NB + B - 1) // B * B                        # whole steps
 
     # synthetic inputs first (forked workers; nothing has touched the HIP runtime yet).  Weak scaling: every rank
     # owns its own FS frames (seeds disjoint per rank)
@@ -239,8 +273,12 @@ def main():
     # than 2 workers per rank when the host has the cores for it (a 1-worker rank takes ~6 s for its 1024 frames)
     local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
     workers = int(os.environ.get("ILCC_BENCH_GEN_WORKERS", "0")) or max(2 if cores >= 2 * local_world else 1, min(16, cores // local_world))
-    clouds, clicks, gts = generate(args.config, FS, 0xC0FFEE + rank * FS, workers)
+    clouds, clicks, gts = generate(args.config, NB * F, 0xC0FFEE + rank * NB * F, workers)
     t_gen = time.perf_counter() - t_gen
+    # the short config-5 leg of the default run (BASELINE's roofline run made driver-visible: roofline.config5_value / config5_frac)
+    c5_inputs = None
+    if world == 1 and args.config == 2 and not (args.no_extra_legs or args.no_config5_leg):
+        c5_inputs = generate(5, 256, 0xC0FFEE, workers)
     # inputs of the sensor-noise sweep (noise_floor_mm): generated now, before anything touches the HIP runtime (forked workers)
     noise_inputs = None
     if world == 1 and args.config == 2 and not (args.no_extra_legs or args.no_noise_floor):
@@ -264,6 +302,18 @@ def main():
                          % (local_world, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # host-side placement: this rank's cores = the NUMA node of its GPU, BEFORE any pinned buffer is allocated
+    # (first touch).  The ranks of one node share the host's memory bandwidth: 8(d)'s metric at N = 8 is that bandwidth's to lose
+    from lidar_camera_calibration_amd.sharding import pin_rank_to_gpu_numa
+    all_cpus = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else []
+    try:
+        pr = torch.cuda.get_device_properties(local_rank)
+        pci = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+    except Exception:
+        pci = None
+    placement = pin_rank_to_gpu_numa(pci, apply=not os.environ.get("ILCC_BENCH_NO_PIN"))
+    print("bench placement: rank %d device %d pci %s numa_node %d cpus %d pinned %s"
+          % (rank, local_rank, placement["pci"], placement["numa_node"], placement["cpus"], placement["pinned"]), file=sys.stderr, flush=True)
     rec_dev = dev if backend == "nccl" else torch.device("cpu")
     if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -277,22 +327,18 @@ def main():
 
     if args.config == 5:
         board, n_points = synth.Board(9, 12, 0.10), synth.hdl64().n_points
-        params = N.default_params()
-        params.board_w, params.board_h, params.grid_length = 9, 12, 0.10
-        params.n_th = params.n_ty = params.n_tz = 129
-        params.th_min, params.th_step = -16.0 * np.pi / 180.0, 0.25 * np.pi / 180.0
-        params.ty_min = params.tz_min = -0.10
-        params.ty_step = params.tz_step = 0.10 / 64
+        params = config5_params(N)
     else:
         board, n_points = synth.Board(), synth.vlp16().n_points
         params = N.default_params()            # ILCC_SOLVER_GRID: 61 x 40 x 40 candidates x 2 phases
     if args.solver == "reference":
         params.solver = N.SOLVER_REFERENCE_LOCAL
     bytes_per_frame = 16 * n_points + 12 * board.n_corners + 64          # 461 284 B for config 2
-    clouds = clouds.reshape(B, F, n_points, 4)
-    clicks = clicks.reshape(B, F, 3)
-    d_clouds = [torch.from_numpy(clouds[b]).to(dev) for b in range(B)]
-    d_clicks = [torch.from_numpy(clicks[b]).to(dev) for b in range(B)]
+    clouds = clouds.reshape(NB, F, n_points, 4)
+    clicks = clicks.reshape(NB, F, 3)
+    gts = gts.reshape(NB, F, *gts.shape[1:])
+    d_clouds = [torch.from_numpy(clouds[b]).to(dev) for b in range(NB)]
+    d_clicks = [torch.from_numpy(clicks[b]).to(dev) for b in range(NB)]
     est = LidarCornersBatch(F, n_points, params, device=local_rank)
     # result traffic: the 500-byte gather records only (ILCC_RESULTS_COMPACT); the full 3.3 KB records stay in HBM
     est.set_result_mode(N.RESULTS_COMPACT)
@@ -334,12 +380,16 @@ def main():
             side.synchronize()
         return gathered
 
-    def run(n_steps, clouds_ptrs, step_times=None, keep=None, host_clicks=None, depth_override=None):
+    def run(n_steps, clouds_ptrs, step_times=None, keep=None, host_clicks=None, depth_override=None, last_on=None):
         """n_steps steps of B batches each, up to `depth` batches in flight (the library's submit/wait pipeline: the
-        latency-bound stages of one batch overlap with the grid search of another).  keep: list that receives the
-        compact records of the LAST step, batch by batch.  host_clicks: the inputs are pinned HOST buffers and every batch's
-        H2D copy is enqueued on the batch's own stream (ilcc_submit_batch)."""
+        latency-bound stages of one batch overlap with the grid search of another).  Step s submits the distinct batches
+        (rot + s * B + b) mod NB.  keep: list that receives the compact records of the LAST step, batch by batch.  last_on: the
+        distinct batch the last step's first batch must be (the legs that compare per-frame results end on the same frames).
+        host_clicks: the inputs are pinned HOST buffers and every batch's H2D copy is enqueued on the batch's own stream
+        (ilcc_submit_batch)."""
         inflight = []
+        nb = len(clouds_ptrs)
+        rot = 0 if last_on is None else (last_on - (n_steps - 1) * B) % nb
 
         def finish():
             ticket, s, b = inflight.pop(0)
@@ -361,10 +411,11 @@ def main():
 
         for s in range(n_steps):
             for b in range(B):
+                k = (rot + s * B + b) % nb
                 if host_clicks is not None:
-                    inflight.append((est.submit_host(clouds_ptrs[b], F, n_points, host_clicks[b]), s, b))
+                    inflight.append((est.submit_host(clouds_ptrs[k], F, n_points, host_clicks[k]), s, b))
                 else:
-                    inflight.append((est.submit_device(clouds_ptrs[b], F, n_points, d_clicks[b].data_ptr()), s, b))
+                    inflight.append((est.submit_device(clouds_ptrs[k], F, n_points, d_clicks[k].data_ptr()), s, b))
                 if len(inflight) == (depth_override or depth):
                     finish()
         while inflight:
@@ -415,6 +466,9 @@ def main():
     if dist_on:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    last0 = ((args.steps - 1) * B) % NB               # the distinct batches the last step walked: last0 ... last0 + B - 1
+    gts = gts[last0:last0 + B].reshape(FS, *gts.shape[2:])
+    clouds_last, clicks_last = clouds[last0:last0 + B], clicks[last0:last0 + B]   # (what the per-frame legs below re-run and compare)
     if dist_on:
         t = torch.tensor([elapsed], dtype=torch.float64, device=rec_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -438,7 +492,7 @@ def main():
     # the same pipeline with every batch starting in pinned HOST memory (SURVEY.md 8d counts that copy): every rank, its own link
     h2d = None
     if not args.no_extra_legs:
-        h2d = h2d_inclusive_leg(torch, dist if dist_on else None, rec_dev, est, clouds, d_clicks, F, B, FS, n_points, world,
+        h2d = h2d_inclusive_leg(torch, dist if dist_on else None, rec_dev, est, clouds, d_clicks, F, NB, B, FS, n_points, world,
                                 args.steps, run, warm)
     gen_per_rank = [round(t_gen, 2)]
     if dist_on:
@@ -479,6 +533,7 @@ def main():
         pmc = k6_pmc(args.config, F)
         credited_wave_instr = credited_lane_instr / 64.0
         rocprof = k6_rocprof(args.config, credited_lane_instr)
+        mix = k6_mix_ceiling(evals_per_launch - evals_interior, evals_interior, box_evals)
         # K1's count pass: the path's HBM-bound kernel (reads every input point exactly once)
         k1_ms_alone = tm_alone.roi_count_ms_sum / max(1, tm_alone.batches)
         k1_GBps = 16.0 * n_points * F / (k1_ms_alone * 1e-3) / 1e9 if k1_ms_alone > 0 else None
@@ -506,8 +561,11 @@ def main():
                 if args.config == 2 else
                 ("configs[4] 64-ring cloud 131072 pts, 11x8 board @0.10 m, 129^3 x 2 grid; step = %d frames/GPU in %d batches of %d"
                  % (FS, B, F)),
-                "workload_detail": "synthetic frames, one random board pose each; %.0f MB of distinct input per GPU and step%s"
-                                   % (FS * n_points * 16 / 1e6, " (> the 256 MB Infinity Cache)" if FS * n_points * 16 > 256e6 else ""),
+                "workload_detail": "%d distinct batches resident per GPU (%.2f GB), step s walks batch s mod %d: no step repeats its predecessor's "
+                                   "data; %.0f MB of input per GPU and step%s; synthetic frames, one random board pose each"
+                                   % (NB, NB * F * n_points * 16 / 1e9, NB // B, FS * n_points * 16 / 1e6,
+                                      " (> the 256 MB Infinity Cache)" if FS * n_points * 16 > 256e6 else ""),
+                "distinct_batches": NB,
                 "frames_per_step_per_gpu": FS,
                 "frames_per_batch": F,
                 "points_per_frame": n_points,
@@ -532,6 +590,7 @@ def main():
             "input_generation_s": round(t_gen, 2),
             "input_generation_s_per_rank": gen_per_rank,
             "input_generation_workers": workers,
+            "host_placement": placement,
             "max_corner_error_mm_vs_ground_truth": 1e3 * float(err_ok.max()) if len(err_ok) else None,
             "median_corner_error_mm_vs_ground_truth": 1e3 * float(np.median(err_ok)) if len(err_ok) else None,
             "p99_corner_error_mm_vs_ground_truth": 1e3 * float(np.percentile(err_ok, 99)) if len(err_ok) else None,
@@ -549,7 +608,8 @@ def main():
                                                ("roi_crop", "cluster", "ransac_plane", "plane_frame_hist", "grid_cost",
                                                 "refine_corners", "total")},
             "roofline": {
-                "kernel": "k6_grid_cost (5 launches per batch: seed, refinement, anchor, k6_group_prepass, full pass)",
+                # the first 24 scalars are what the driver's record keeps (BENCH_rNN.json parsed.roofline): the contract figures first
+                "kernel": "k6_grid_cost (launches per batch: k6_locate [or seed, refinement, anchor], k6_group_prepass, full pass)",
                 "bound": "valu",
                 "achieved": valu_rate,
                 "peak": VALU_ISSUE_PEAK_T,
@@ -558,12 +618,33 @@ def main():
                 "frac_what": "credited lane-instr of one batch's K6 launches / k6_ms_alone (HIP events, ONE batch in flight) / peak"
                              if tm_alone is not tm or depth == 1 else
                              "credited lane-instr of one batch's K6 launches / the timed region's event spans (--no-alone-leg) / peak",
-                "alone_leg": tm_alone is not tm or depth == 1,
-                "traffic": pmc["traffic_bytes"] if pmc else None,
                 "k6_ms_alone": k6_ms_alone,
+                "frac_rocprof_alone": rocprof["in_flight_1"]["frac_this_run"] if rocprof and "in_flight_1" in rocprof else None,
+                "frac_whole_step": credited_lane_instr * B / (elapsed / args.steps) / 1e12 / VALU_ISSUE_PEAK_T,
+                "traffic": pmc["traffic_bytes"] if pmc else None,
+                # HBM (north_star's figure): the algorithmic bytes of SURVEY.md 8(d) over the whole step, and K1's count pass alone
+                "hbm_frac": fps / max(1, world) * bytes_per_frame / 1e9 / HBM_PEAK_GBPS,
+                "k1_hbm_frac": k1_GBps / HBM_PEAK_GBPS if k1_GBps else None,
+                # SURVEY.md 8(d)'s metric as written (H2D copy inside), filled in below when that leg runs
+                "h2d_inclusive_frames_per_s": None,
+                "link_frac": None,
+                "link_bound_frames_per_s": None,
+                "uncredited_share": 1.0 - credited_wave_instr / pmc["valu_wave_instr"] if pmc else None,
+                "wave_instr_per_frame": pmc["valu_wave_instr"] / F if pmc else None,
+                # the issue ceiling of the credited instruction mix (half-rate floor / fract / min / max / cmp / cndmask priced at 2 units)
+                "mix_ceiling": mix[0] if mix else None,
+                "frac_of_mix_ceiling": valu_rate / mix[0] if mix else None,
+                # the mode with reference-path parity and BASELINE's roofline run (config 5), filled in below when those legs run
+                "reference_mode_frames_per_s": None,
+                "reference_mode_link_frac": None,
+                "config5_frames_per_s": None,
+                "config5_frac": None,
+                # ---- everything below is beyond the 24 scalars the driver keeps
+                "alone_leg": tm_alone is not tm or depth == 1,
+                "mix_ceiling_at_measured_rates": mix[1] if mix else None,
+                "frac_of_mix_ceiling_at_measured_rates": valu_rate / mix[1] if mix else None,
+                "mix_ceiling_file": mix[2] if mix else None,
                 "k6_ms_pipelined": k6_ms,
-                "launch_ms": k6_ms,                                            # (alias of k6_ms_pipelined: rounds 1-4's name, tools/ read it)
-                "full_pass_ms": tm.grid_cost_full_ms_sum / launches,          # (alias of k6_full_pass_ms_pipelined)
                 "k6_locate_ms_alone": tm_alone.grid_cost_locate_ms_sum / la,
                 "k6_prepass_ms_alone": tm_alone.grid_cost_prepass_ms_sum / la,
                 "k6_full_pass_ms_alone": tm_alone.grid_cost_full_ms_sum / la,
@@ -572,16 +653,14 @@ def main():
                 "k6_full_pass_ms_pipelined": tm.grid_cost_full_ms_sum / launches,
                 "frac_pipelined": valu_rate_pipe / VALU_ISSUE_PEAK_T,
                 "frac_of_stage_span": credited_lane_instr / (k6_span_ms * 1e-3) / 1e12 / VALU_ISSUE_PEAK_T if k6_span_ms > 0 else None,
-                "frac_whole_step": credited_lane_instr * B / (elapsed / args.steps) / 1e12 / VALU_ISSUE_PEAK_T,
-                "frac_rocprof_alone": rocprof["in_flight_1"]["frac_this_run"] if rocprof and "in_flight_1" in rocprof else None,
                 "frac_rocprof_pipelined": rocprof["pipelined"]["frac_this_run"] if rocprof and "pipelined" in rocprof else None,
                 "k6_ms_rocprof_alone": rocprof["in_flight_1"]["k6_ms_per_batch"] if rocprof and "in_flight_1" in rocprof else None,
                 "k6_ms_rocprof_pipelined": rocprof["pipelined"]["k6_ms_per_batch"] if rocprof and "pipelined" in rocprof else None,
                 "rocprof_files": ", ".join(v["file"] for v in rocprof.values()) if rocprof else None,
                 "credited_lane_instr_per_batch": credited_lane_instr,
                 "issued_wave_instr_per_batch": pmc["valu_wave_instr"] if pmc else None,
-                "uncredited_share": 1.0 - credited_wave_instr / pmc["valu_wave_instr"] if pmc else None,
-                "wave_instr_per_frame": pmc["valu_wave_instr"] / F if pmc else None,
+                # issued VALU wave-instructions of the full pass / what the chip issues in its duration at one wave64 instruction per
+                # SIMD every TWO cycles (1024 SIMDs; MI355X_MICROARCH.md) -- round 5's DESIGN text priced this against a 4-cycle ceiling
                 "issue_utilisation_full_pass_alone": (2.0 * pmc["full_pass"]["valu_wave_instr"] /
                                                       max(1.0, 1024.0 * pmc["full_pass"]["gui_active_cycles_per_xcd"])) if pmc else None,
                 "pmc_file": pmc["file"] if pmc else None,
@@ -596,23 +675,17 @@ def main():
                 "stage_span_ms": k6_span_ms,
                 "walk_order_k5w_ms": tm.walk_order_ms_sum / launches,
                 "step_ms_alone": step_ms_alone,
-                # HBM (north_star's figure): the algorithmic bytes of SURVEY.md 8(d) over the whole step, and K1's count pass alone
                 "hbm_algorithmic_bytes_per_batch": k6_bytes,
                 "hbm_GBps_whole_path": fps / max(1, world) * bytes_per_frame / 1e9,
-                "hbm_frac": fps / max(1, world) * bytes_per_frame / 1e9 / HBM_PEAK_GBPS,
                 "k1_count_ms_alone": k1_ms_alone,
                 "k1_hbm_GBps": k1_GBps,
-                "k1_hbm_frac": k1_GBps / HBM_PEAK_GBPS if k1_GBps else None,
                 "hbm_peak_GBps": HBM_PEAK_GBPS,
-                # SURVEY.md 8(d)'s metric as written (H2D copy inside), filled in below when that leg runs
-                "h2d_inclusive_frames_per_s": None,
                 "link_GBps_achieved": None,
                 "link_GBps_raw_hipMemcpy": None,
-                "link_bound_frames_per_s": None,
-                "link_frac": None,
                 "note": "VALU-bound by construction (points in LDS, no MFMA).  credited = executed evaluations x %g / %g VALU instr "
                         "(border / interior class) + box evaluations x %g (tools/k6_isa_count.sh: the terms only).  frac FALLS when "
-                        "pruning removes credited work: track wave_instr_per_frame and k6_ms_alone instead" % (
+                        "pruning removes credited work: track wave_instr_per_frame and k6_ms_alone instead.  mix_ceiling: the same credited "
+                        "instructions priced per issue class (tools/k6_issue_ceiling.py)" % (
                             K6_VALU_OPS_BORDER, K6_VALU_OPS_INTERIOR, K6_VALU_OPS_BOX),
                 "rocprof": rocprof,
                 "issued_vs_credited": {
@@ -643,17 +716,30 @@ def main():
         if world == 1 and not args.no_extra_legs:
             out["grid_vs_reference_path_mm"], gpu_ref = reference_mode_leg(N, est, params, dptrs, d_clicks, res, F, B, FS, run,
                                                                             warm, args.steps, synth, gts, board,
-                                                                            h2d["hptrs"] if h2d else None, h2d["hclicks"] if h2d else None)
+                                                                            h2d["hptrs"] if h2d else None, h2d["hclicks"] if h2d else None,
+                                                                            last_on=last0)
             out["reference_local_mode"] = out["grid_vs_reference_path_mm"].pop("reference_local_mode")
-            out["single_frame_latency_ms"] = single_frame_latency(N, params, clouds, clicks, n_points, local_rank)
+            rl = out["reference_local_mode"]
+            out["roofline"]["reference_mode_frames_per_s"] = rl["value"]
+            if h2d and rl.get("value_h2d_inclusive"):
+                out["roofline"]["reference_mode_link_frac"] = rl["value_h2d_inclusive"] / h2d["link_bound_frames_per_s"]
+                rl["link_frac"] = out["roofline"]["reference_mode_link_frac"]
+            if c5_inputs is not None:
+                out["config5"] = config5_leg(N, synth, c5_inputs, local_rank)
+                out["roofline"]["config5_frames_per_s"] = out["config5"]["value"]
+                out["roofline"]["config5_frac"] = out["config5"]["frac"]
+            out["single_frame_latency_ms"] = single_frame_latency(N, params, clouds_last, clicks_last, n_points, local_rank)
             if args.config == 2:
-                out["half_resolution_grid_variant"] = half_grid_leg(N, est, params, dptrs, FS, run, warm, args.steps, synth, gts, board)
+                out["half_resolution_grid_variant"] = half_grid_leg(N, est, params, dptrs, FS, run, warm, args.steps, synth, gts, board,
+                                                                    last_on=last0)
             if args.config == 2:
-                out["online_caller"] = online_caller_leg(N, params, clouds.reshape(FS, n_points, 4), gts, n_points, local_rank)
+                out["online_caller"] = online_caller_leg(N, params, clouds_last.reshape(FS, n_points, 4), gts, n_points, local_rank)
             if noise_inputs is not None:
                 out["noise_floor_mm"] = noise_floor_leg(N, params, synth, board, n_points, local_rank, noise_inputs)
             if not args.no_cpu_baseline and args.config == 2:
-                out["cpu_baseline"] = cpu_baseline(clouds.reshape(FS, n_points, 4), clicks.reshape(FS, 3), gts, board,
+                if all_cpus and hasattr(os, "sched_setaffinity"):
+                    os.sched_setaffinity(0, all_cpus)      # the CPU baseline's all-cores leg uses every core of the box again
+                out["cpu_baseline"] = cpu_baseline(clouds_last.reshape(FS, n_points, 4), clicks_last.reshape(FS, 3), gts, board,
                                                    args.cpu_seconds, gpu_ref)
                 cb = out["cpu_baseline"]
                 dv = cb.get("gpu_vs_cpu_corner_deviation_mm") or {}
@@ -675,7 +761,7 @@ def main():
 
 
 def reference_mode_leg(N, est, params, dptrs, d_clicks, res_grid, F, B, FS, run, warm, steps, synth, gts, board,
-                       hptrs=None, hclicks=None):
+                       hptrs=None, hclicks=None, last_on=None):
     """The reference's own trajectory on the GPU (ILCC_SOLVER_REFERENCE_LOCAL: two Ceres-style solves from zero per
     colour phase, LidarCornersEst.cpp:398-409), through the SAME pipelined harness: its frames/s, and how far the
     headline GRID mode's corners are from it frame by frame (the reference's 50+50 iterations do not converge, so the
@@ -691,16 +777,18 @@ def reference_mode_leg(N, est, params, dptrs, d_clicks, res_grid, F, B, FS, run,
     last = []
     t0 = time.perf_counter()
     n = max(3, steps // 2)
-    run(n, dptrs, keep=last)
+    run(n, dptrs, keep=last, last_on=last_on)      # (ends on the distinct batch the headline's last step walked: same frames)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     res_ref = [Rec(r, board.n_corners) for batch in last for r in batch]
     dt_h2d = None
-    if hptrs is not None:            # the same mode with every batch crossing PCIe inside the timed region
-        run(2, hptrs, host_clicks=hclicks)
+    n_h2d = None
+    if hptrs is not None:            # the same mode with every batch crossing PCIe inside the timed region: the headline's H2D leg
+        warm(hptrs, 2, host_clicks=hclicks)       # exactly (same steady-state rule, same number of steps: a step is 8 ms of link time, and
+        n_h2d = max(5, steps)                      # round 5's 2 + 10 steps measured the pipeline's fill and drain into it: 0.79 of the link)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        run(n, hptrs, host_clicks=hclicks)
+        run(n_h2d, hptrs, host_clicks=hclicks)
         torch.cuda.synchronize()
         dt_h2d = time.perf_counter() - t0
     est.set_params(params)
@@ -721,7 +809,7 @@ def reference_mode_leg(N, est, params, dptrs, d_clicks, res_grid, F, B, FS, run,
         "max_excluding_frames_flagged_ambiguous": 1e3 * float(dev[both_ok].max()) if both_ok.any() else None,
         "reference_local_mode": {
             "value": FS * n / dt, "unit": "frames/s", "steps": n, "ms_per_step": 1e3 * dt / n,
-            "value_h2d_inclusive": FS * n / dt_h2d if dt_h2d else None,
+            "value_h2d_inclusive": FS * n_h2d / dt_h2d if dt_h2d else None, "steps_h2d_inclusive": n_h2d,
             "what": "ILCC_SOLVER_REFERENCE_LOCAL: the reference's own trajectory (2 phases x (pass A + pass B) trust-region solves "
                     "from zero) on the GPU -- the mode whose corners match the reference CPU path (gpu_vs_cpu_port_corner_deviation_mm: "
                     "north_star's 1e-3 m clause); the headline ILCC_SOLVER_GRID mode finds a lower cost and lands elsewhere "
@@ -734,6 +822,79 @@ def reference_mode_leg(N, est, params, dptrs, d_clicks, res_grid, F, B, FS, run,
         },
     }
     return blk, gpu_ref
+
+
+def config5_params(N):
+    """BASELINE configs[4]: 11 x 8 corners @0.10 m, ty, tz in [-g, g] step g/64 (129 x 129), theta in [-16, 16] deg step
+    0.25 deg (129): 2 146 689 candidates x 2 phases."""
+    p = N.default_params()
+    p.board_w, p.board_h, p.grid_length = 9, 12, 0.10
+    p.n_th = p.n_ty = p.n_tz = 129
+    p.th_min, p.th_step = -16.0 * np.pi / 180.0, 0.25 * np.pi / 180.0
+    p.ty_min = p.tz_min = -0.10
+    p.ty_step = p.tz_step = 0.10 / 64
+    return p
+
+
+def k6_credit(tm):
+    """Credited lane-instructions of ONE batch's K6 launches from the library's counters (executed evaluations by class, box evaluations)."""
+    la = max(1, tm.grid_cost_launches)
+    evals, interior, box = tm.grid_cost_evals_sum / la, tm.grid_cost_evals_interior_sum / la, tm.grid_cost_box_evals_sum / la
+    return K6_VALU_OPS_INTERIOR * interior + K6_VALU_OPS_BORDER * (evals - interior) + K6_VALU_OPS_BOX * box
+
+
+def config5_leg(N, synth, inputs, device, steps=10):
+    """BASELINE's roofline run (configs[4]: 64-ring 131 072-point clouds, 11 x 8 board @0.10 m, 129^3 x 2 grid) as a SHORT leg of the
+    default run, so that the driver's record carries it (roofline.config5_frames_per_s / config5_frac): two distinct 128-frame batches
+    resident, four in flight, `steps` steps timed after a warm-up; then one batch at a time for the K6 launches' exclusive durations.
+    `python bench.py --config 5` is the full version (H2D-inclusive leg, reference mode, rocprof cross-checks)."""
+    import torch
+    from lidar_camera_calibration_amd import LidarCornersBatch
+    clouds, clicks, gts = inputs
+    lidar, board = synth.hdl64(), synth.Board(9, 12, 0.10)
+    F = 128
+    nb = len(clouds) // F
+    est = LidarCornersBatch(F, lidar.n_points, config5_params(N), device=device)
+    est.set_result_mode(N.RESULTS_COMPACT)
+    est.reserve(6400, 20000)
+    d_c = [torch.from_numpy(clouds[b * F:(b + 1) * F]).cuda() for b in range(nb)]
+    d_k = [torch.from_numpy(clicks[b * F:(b + 1) * F]).cuda() for b in range(nb)]
+
+    def run(n, depth):
+        inflight, last = [], None
+        for s in range(n):
+            inflight.append(est.submit_device(d_c[s % nb].data_ptr(), F, lidar.n_points, d_k[s % nb].data_ptr()))
+            if len(inflight) == depth:
+                last = est.wait_compact(inflight.pop(0))
+        while inflight:
+            last = est.wait_compact(inflight.pop(0))
+        return last
+    run(8, 4)
+    torch.cuda.synchronize()
+    est.reset_timing()
+    t0 = time.perf_counter()
+    rec = run(steps, 4)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    est.reset_timing()
+    run(4, 1)
+    torch.cuda.synchronize()
+    tm = est.timing()
+    k6_ms = tm.grid_cost_kernel_ms_sum / max(1, tm.grid_cost_launches)
+    credited = k6_credit(tm)
+    lastb = (steps - 1) % nb
+    res = [Rec(r, board.n_corners) for r in rec]
+    ok = [f for f in range(F) if res[f].status == N.OK]
+    err = np.array([synth.corner_error(res[f].corners_array(), gts[lastb * F + f], board) for f in ok])
+    est.close()
+    return {"value": steps * F / dt, "unit": "frames/s", "ms_per_step": 1e3 * dt / steps, "steps": steps, "frames_per_batch": F,
+            "distinct_batches": nb, "k6_ms_alone": k6_ms, "frac": credited / (max(k6_ms, 1e-9) * 1e-3) / 1e12 / VALU_ISSUE_PEAK_T,
+            "credited_lane_instr_per_batch": credited, "frames_ok": "%d/%d" % (len(ok), F),
+            "median_corner_error_mm_vs_ground_truth": 1e3 * float(np.median(err)) if len(err) else None,
+            "bytes_per_frame": 16 * lidar.n_points + 12 * board.n_corners + 64,
+            "hbm_frac": steps * F / dt * (16 * lidar.n_points + 12 * board.n_corners + 64) / 1e9 / HBM_PEAK_GBPS,
+            "what": "configs[4], inputs resident, four batches in flight; frac = credited lane-instr of one batch's K6 launches / their "
+                    "summed duration with ONE batch in flight / the 78.6 T issue peak"}
 
 
 class Rec:
@@ -889,7 +1050,7 @@ def single_frame_latency(N, params, clouds, clicks, n_points, device):
     return out
 
 
-def half_grid_leg(N, est, params, dptrs, FS, run, warm, steps, synth, gts, board):
+def half_grid_leg(N, est, params, dptrs, FS, run, warm, steps, synth, gts, board, last_on=None):
     """NOT the headline: the same pipeline with the exhaustive grid at HALF the resolution per axis (31 x 20 x 20 x 2 =
     24 800 candidates: theta step 1 deg, translation step g/10) and the refinement lattice kept at the same final
     resolution (refine_div 32).  The pattern search's capture range covers the coarser cells: accuracy statistics are
@@ -908,7 +1069,7 @@ def half_grid_leg(N, est, params, dptrs, FS, run, warm, steps, synth, gts, board
     last = []
     n = max(3, steps // 2)
     t0 = time.perf_counter()
-    run(n, dptrs, keep=last)
+    run(n, dptrs, keep=last, last_on=last_on)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     est.set_params(params)
@@ -925,15 +1086,15 @@ def half_grid_leg(N, est, params, dptrs, FS, run, warm, steps, synth, gts, board
             "note": "reported beside the headline, never as `value`: `value` keeps SURVEY.md 8(d)'s suggested 61x40x40 grid"}
 
 
-def h2d_inclusive_leg(torch, dist, rec_dev, est, clouds, d_clicks, F, B, FS, n_points, world, steps, run, warm):
+def h2d_inclusive_leg(torch, dist, rec_dev, est, clouds, d_clicks, F, NB, B, FS, n_points, world, steps, run, warm):
     """SURVEY.md 8(d)'s metric as written: the same pipeline, same steps, but every batch starts in pinned HOST memory and
     crosses PCIe inside the timed region.  Every rank runs it (each GPU has its own link); the timed region is bracketed
     by barriers and the MAX over ranks counts, like `value`.  Explicit copies (ilcc_submit_batch: hipMemcpyAsync on the
     batch's own stream, in front of its kernels) are the figure; at N = 1 the zero-copy variant (K1 reads the pinned
     buffer over PCIe) and what hipMemcpy alone delivers on the link are measured beside it."""
     import time
-    pinned = [torch.from_numpy(clouds[b]).pin_memory() for b in range(B)]
-    pinned_clicks = [d_clicks[b].cpu().pin_memory() for b in range(B)]
+    pinned = [torch.from_numpy(clouds[b]).pin_memory() for b in range(NB)]      # the same NB distinct batches, rotated through
+    pinned_clicks = [d_clicks[b].cpu().pin_memory() for b in range(NB)]
     nbytes = int(pinned[0].numel() * 4)
     hptrs = [t.data_ptr() for t in pinned]
     hclicks = [t.data_ptr() for t in pinned_clicks]
@@ -972,7 +1133,7 @@ def h2d_inclusive_leg(torch, dist, rec_dev, est, clouds, d_clicks, F, B, FS, n_p
     def raw_copies(k):
         with torch.cuda.stream(cs):
             for b in range(k):
-                bufs[b % nbuf].copy_(pinned[b % B], non_blocking=True)
+                bufs[b % nbuf].copy_(pinned[b % NB], non_blocking=True)
             cs.synchronize()
     raw_copies(2)
     raw = 16 * nbytes / timed(lambda: raw_copies(16)) / 1e9

@@ -349,9 +349,10 @@ int64_t ilcc_fetch_walk(ilcc_handle* h, uint32_t frame, float* out_yz, uint8_t* 
 int32_t ilcc_grid_cost(ilcc_handle* h, const float* yz, const uint8_t* label, uint32_t m,
                        int32_t use_oob, float* cost_out, int32_t* best_index, float* best_cost);
 
-/* The GRID solver exactly as the pipeline runs it -- walk layout, the launches that locate the minimum, common pre-pass, full pass
- * with its near-tie list, then the refinement with the near-tie recount and its first-round shortcut -- on caller-supplied labelled
- * points (host buffers).  Out: the grid argmin and its fp32 cost, the refined lattice point (units of step / refine_div from the
+/* The GRID solver as the pipeline runs it on a SMALL batch -- walk layout, the three launches that locate the minimum (seed,
+ * refinement, anchor rounds; batches of >= 512 frames fuse them into k6_locate, whose equality with the three launches is a test
+ * of its own: test_fused_locate_equals_the_three_launches), common pre-pass, full pass with its near-tie list, then the refinement
+ * with the near-tie recount and its first-round shortcut -- on caller-supplied labelled points (host buffers).  Out: the grid argmin and its fp32 cost, the refined lattice point (units of step / refine_div from the
  * grid's minima), phase, fixed-point costs (units of 2^-40) of the result and of the cheapest neighbouring basin, rounds, hops,
  * ILCC_FLAG_* and the near-tie count.  Test/diagnostic entry (adversarial inputs for the fp32 ranking). */
 int32_t ilcc_grid_solve(ilcc_handle* h, const float* yz, const uint8_t* label, uint32_t m, int32_t* grid_index, float* grid_cost,

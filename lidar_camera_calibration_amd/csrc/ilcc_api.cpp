@@ -66,6 +66,7 @@ struct Slot {
   std::vector<uint64_t> off;
   uint32_t n_frames = 0;
   bool busy = false, grid = false;
+  bool online = false;   // the batch in flight came from ilcc_submit_chessboard_by_point (no crop, front end only): its wait applies the by-point epilogue
   bool h_res_valid = false;  // h_res holds the last completed batch's full (trimmed) records
   bool compact = false;      // what was enqueued with the batch in flight: the K9 records (true) or the trimmed full records
   uint32_t rec_corners = 0;  // corners per K9 record of that batch
@@ -94,6 +95,7 @@ struct ilcc_handle {
   double* d_solve = nullptr;   // 3 theta_t + 2 (cost, iterations) for the test entries
   RefineOut* d_refine_io = nullptr;
   uint32_t grid_lds_points = 1024;   // grows with the frames seen (finish()); frames above it take the global-memory path
+  uint64_t group_prepass_skipped = 0;   // batches whose grid was eligible for k6_group_prepass but whose mask buffers were too small (a sizing bug if ever non-zero: ilcc_last_error reports it)
   uint32_t cluster_lds_points = 2048;   // K2's LDS capacity for cell-sorted ROI points per frame: grows likewise (<= 4096); larger frames sort into HBM
   uint32_t cluster_cells_cap = kClusterCellsMin;   // K2's LDS capacity in occupied cells per frame: grows with what the batches needed
   uint32_t list_grid = 1024;         // workgroups of the online caller's second-tier kernels (4 x the device's CUs)
@@ -289,6 +291,7 @@ void warn_hw_queues_once(int slot_index) {
 
 // K6's common pre-pass: does the handle's grid qualify, and what its output needs per frame
 struct GroupPrepassPlan {
+  bool box = false;   // the grid is eligible for the box pre-passes at all (the ONE place that decides it)
   bool on = false;
   uint32_t groups = 0, words = 0;   // theta groups per frame = ceil(n_th / kThetaGroup); mask words per group = ceil(tiles / 32)
 };
@@ -302,6 +305,7 @@ GroupPrepassPlan group_prepass_plan(const ilcc_params& p) {
   const bool centre_in = p.ty_min > -0.45 * p.board_w * gl && ty_hi < 0.45 * p.board_w * gl && p.tz_min > -0.45 * p.board_h * gl &&
                          tz_hi < 0.45 * p.board_h * gl;
   const uint32_t n_tiles = (uint32_t)(((p.n_ty + 3) / 4) * ((p.n_tz + 3) / 4));
+  g.box = box;
   g.on = box && p.n_th >= kThetaGroup && centre_in && n_tiles <= 4096u;
   g.groups = (uint32_t)((p.n_th + kThetaGroup - 1) / kThetaGroup);
   g.words = (n_tiles + 31u) / 32u;
@@ -673,8 +677,7 @@ int32_t enqueue_grid_search(ilcc_handle* h, Slot& sl, int si, const Ctx& c, hipS
   }
   HIP_TRY(h, hipEventRecord(sl.k6ev[3], s));   // behind the anchor: the common pre-pass gets an event span of its own
   const GroupPrepassPlan gp = group_prepass_plan(h->p);
-  // box pre-pass (k6_grid_cost.hip): its monotonicity argument needs a tile's box narrower than one square on both axes
-  full.box_points = (prune && 3.0 * h->p.ty_step < 0.9 * h->p.grid_length && 3.0 * h->p.tz_step < 0.9 * h->p.grid_length) ? (uint32_t)ILCC_BOX_POINTS : 0u;
+  full.box_points = gp.box ? (uint32_t)ILCC_BOX_POINTS : 0u;   // (eligibility: group_prepass_plan, which also sized the buffers)
   // k6_group_prepass: one box pre-pass for kThetaGroup consecutive thetas, launched HERE -- behind the anchor (it needs the
   // frame's bound), in front of the wait for the previous batch's full pass, so it runs beside that pass like the other small
   // launches.  Its buffers were sized for (max_frames, this grid) by alloc_slot / ilcc_set_params.
@@ -685,6 +688,8 @@ int32_t enqueue_grid_search(ilcc_handle* h, Slot& sl, int si, const Ctx& c, hipS
     launch_group_prepass(full, s, sl.d_grp_alive, sl.d_grp_mask);
     full.grp_alive = sl.d_grp_alive;
     full.grp_mask = sl.d_grp_mask;
+  } else if (full.box_points != 0u && gp.on) {
+    ++h->group_prepass_skipped;   // eligible grid, buffers too small for this batch (never expected: size_group_prepass sized them)
   }
   HIP_TRY(h, hipEventRecord(sl.ev[7], s));
   // The FULL passes of different slots are chained so that they never share the chip (two passes side by side both run at half
@@ -781,6 +786,7 @@ int32_t enqueue_impl(ilcc_handle* h, int si, const float4* d_xyzi, const uint64_
   }
   HIP_TRY(h, hipMemcpyAsync(sl.h_iters, sl.d_iters, sizeof(unsigned long long) * kBatchWords, hipMemcpyDeviceToHost, s));
   sl.busy = true;
+  sl.online = no_crop;
   return ILCC_OK;
 }
 
@@ -904,7 +910,14 @@ int32_t finish(ilcc_handle* h, int si, ilcc_result* out, float* out_compact = nu
   // rounded up to 256 points.  (Not to a power of two: 1 781 points -- the largest of the bench frames -- need 21.8 KB per K6
   // workgroup at 1 792 and 24.9 KB at 2 048: seven instead of six workgroups per CU -- which, the kernel being VALU-bound,
   // measured no difference: 248.8 k vs 250 k frames/s.)
+  // ... but never, on its own, past the capacity at which TWO workgroups of the K6 full pass still share a CU's 160 KB (12 bytes per
+  // staged point + the (ty, tz) tables + ~3 KB of static LDS: 6 400 points for both BASELINE grids).  Round 6: a stream of 64-ring
+  // frames whose closest boards hold 6 682 labelled points (the first 128 frames: 6 170) grew the staging to 6 912 points, ONE
+  // workgroup per CU, and every frame's full pass took 1.15 ms instead of 0.74 ms per 128 frames.  The few frames above the capacity
+  // walk their points through L2 (grid_cost_body<LDS_POINTS = false>); ilcc_reserve may still ask for more, explicitly.
+  const uint32_t two_per_cu = (uint32_t)(((160u * 1024u / 2u) - 3072u - 4u * (uint32_t)(h->p.n_ty + h->p.n_tz)) / 12u) & ~255u;
   uint32_t want = std::min<uint32_t>((uint32_t)kGridLdsPointsMax, std::max<uint32_t>(1024u, (max_lab + 255u) & ~255u));
+  want = std::min<uint32_t>(want, std::max<uint32_t>(1024u, two_per_cu));
   if (want > h->grid_lds_points) h->grid_lds_points = want;
   // the same for K2's one-workgroup LDS path (ROI points per frame, steps of 512): what it does not hold of a CU's 160 KiB
   // is room for K6 workgroups of other batches
@@ -1208,11 +1221,21 @@ int32_t ilcc_submit_batch(ilcc_handle* h, const float* xyzi, const uint64_t* off
   return ILCC_OK;
 }
 
+// A ticket belongs to the call family that issued it: ilcc_submit_chessboard_by_point's batches skip the crop and
+// the search, and only their own wait applies the by-point epilogue (plane >= min_plane_points, whole-cloud n_roi); the other way
+// round that epilogue would read staging no copy of the batch has filled.  The batch stays in flight.
+static int32_t wrong_ticket_kind(ilcc_handle* h, const char* fn, bool ticket_is_online) {
+  h->err = std::string(fn) + (ticket_is_online ? ": this ticket came from ilcc_submit_chessboard_by_point: wait with ilcc_wait_chessboard_by_point"
+                                               : ": this ticket came from ilcc_submit_batch[_device]: wait with ilcc_wait / ilcc_wait_compact / ilcc_wait_records_device");
+  return ILCC_BAD_ARGUMENT;
+}
+
 int32_t ilcc_wait(ilcc_handle* h, int32_t ticket, ilcc_result* out) {
   if (!h || !out || ticket < 0 || ticket >= kSlots || !h->slots[ticket].busy) {
     if (h) h->err = "ilcc_wait: no batch in flight under this ticket";
     return ILCC_BAD_ARGUMENT;
   }
+  if (h->slots[ticket].online) return wrong_ticket_kind(h, "ilcc_wait", true);
   HIP_TRY(h, hipSetDevice(h->device));
   return finish(h, ticket, out);
 }
@@ -1223,6 +1246,7 @@ int32_t ilcc_wait_records_device(ilcc_handle* h, int32_t ticket, ilcc_result* ou
     if (h) h->err = "ilcc_wait_records_device: bad argument or no batch in flight under this ticket";
     return ILCC_BAD_ARGUMENT;
   }
+  if (h->slots[ticket].online) return wrong_ticket_kind(h, "ilcc_wait_records_device", true);
   HIP_TRY(h, hipSetDevice(h->device));
   return finish(h, ticket, out, nullptr, static_cast<float*>(d_records), n_corners, tag_base);
 }
@@ -1248,6 +1272,7 @@ int32_t ilcc_wait_compact(ilcc_handle* h, int32_t ticket, float* records, uint64
     if (h) h->err = "ilcc_wait_compact: no batch in flight under this ticket";
     return ILCC_BAD_ARGUMENT;
   }
+  if (h->slots[ticket].online) return wrong_ticket_kind(h, "ilcc_wait_compact", true);
   {
     const Slot& sl = h->slots[ticket];   // the record width was fixed when the batch was submitted
     const uint64_t need = (uint64_t)sl.n_frames * ((uint64_t)ILCC_RECORD_HEADER + 3ull * sl.rec_corners);
@@ -1386,6 +1411,7 @@ int32_t ilcc_wait_chessboard_by_point(ilcc_handle* h, int32_t ticket, int32_t mi
     if (h) h->err = "ilcc_wait_chessboard_by_point: no batch in flight under this ticket";
     return ILCC_BAD_ARGUMENT;
   }
+  if (!h->slots[ticket].online) return wrong_ticket_kind(h, "ilcc_wait_chessboard_by_point", false);
   HIP_TRY(h, hipSetDevice(h->device));
   Slot& sl = h->slots[ticket];
   const uint32_t n_frames = sl.n_frames;

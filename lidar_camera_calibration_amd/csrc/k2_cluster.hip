@@ -693,6 +693,7 @@ constexpr uint32_t kHashEmpty = 0xFFFFFFFFu;
 constexpr uint32_t kHashPointsMax = 65536u;            // frames above this keep the point-level path (table at most half full)
 static_assert(2u * kHashPointsMax <= (uint32_t)kClusterHashSize, "hash table capacity");
 
+constexpr uint32_t kHashMinFramePoints = 256;   // hashed-block path: 4 words per input point hold the smallest (1024-word) block table
 struct HashFrame {
   float lox, loy, loz, inv;
   int32_t nbx, nby;       // blocks per axis (x, y); keys are bx + nbx * (by + nby * bz)
@@ -788,6 +789,9 @@ __device__ bool hashed_cluster_frame(const Ctx& c, uint32_t f, uint32_t* sc) {
   const HashViews v = hash_views(c, f);
   const uint32_t M = v.M;
   if (M == 0u || M > kHashPointsMax) return false;
+  // the block arrays (tbase / tlo / thi: at least 1024 words each) live in the frame's OWN slices of board / pca / optim, four
+  // words per INPUT point: a frame of fewer than 256 input points cannot hold them (it wrote into its neighbour's)
+  if (c.off[f + 1] - c.off[f] < (uint64_t)kHashMinFramePoints) return false;
   const uint32_t tid = threadIdx.x, kT = blockDim.x;
   const int nwv = (int)(kT / ILCC_WAVE);
   const float tol2 = (float)(c.p.cluster_tol * c.p.cluster_tol);
@@ -1287,7 +1291,8 @@ __global__ __launch_bounds__(1024) void k2h_setup(Ctx c, ListedFrame* frames) {
   g.lox = lo.x; g.loy = lo.y; g.loz = lo.z;
   g.inv = 1.0f / ((float)c.p.cluster_tol * kFineCellOverTol);
   const float ex = (hi.x - lo.x) * g.inv, ey = (hi.y - lo.y) * g.inv, ez = (hi.z - lo.z) * g.inv;
-  bool ok = M > 0u && M <= kHashPointsMax && ex < 8192.f && ey < 8192.f && ez < 8192.f;   // (a NaN extent fails the comparisons)
+  bool ok = M > 0u && M <= kHashPointsMax && ex < 8192.f && ey < 8192.f && ez < 8192.f &&   // (a NaN extent fails the comparisons)
+            c.off[f + 1] - c.off[f] >= (uint64_t)kHashMinFramePoints;   // (the 1024-word block arrays fit the frame's slices)
   if (ok) {
     const int nx = (int)floorf(ex) + 5, ny = (int)floorf(ey) + 5, nz = (int)floorf(ez) + 5;
     g.nbx = (nx + 3) >> 2;

@@ -972,7 +972,7 @@ __device__ __forceinline__ int stencil_sweep(const Ctx& c, const Board& bd, cons
     };
     const uint32_t n_slices = (uint32_t)(waves_per_theta * ILCC_WAVE);
     // the silence test needs ty[0] <= ty[2] and tz[0] <= tz[2] (pattern-search rounds: centre -/+ stride, steps > 0)
-    const bool skip_silent = !parity && ty[0] <= ty[2] && tz[0] <= tz[2] && c.p.ty_step > 0.0 && c.p.tz_step > 0.0;
+    const bool skip_silent = !parity && ty[0] <= ty[1] && ty[1] <= ty[2] && tz[0] <= tz[1] && tz[1] <= tz[2] && c.p.ty_step > 0.0 && c.p.tz_step > 0.0;   // (monotone in BOTH steps: the middle value's cell lies between the outer two's)
     if (skip_silent) {
       uint32_t* queue = sh.queue[wid];
       uint32_t head = 0, tail = 0;   // wave-uniform

@@ -5,7 +5,11 @@
 // split into contiguous shards of ceil(F / G); every rank runs the whole path on its shard (H2D copy on the batch's own
 // stream, records packed on the GPU by K9) and ONE ncclGather (rccl.h) ships the fixed-size records from each GPU's HBM
 // to rank 0's, which checks tag + content word of every record and writes the process_data files.
-//   ilcc_corners_mgpu <yaml|-> <out_prefix> <n_gpus, 0 = all> {<cloud.bin> <cx> <cy> <cz>}...
+//   ilcc_corners_mgpu [--accept-ambiguous] [--accept-low-coverage] <yaml|-> <out_prefix> <n_gpus, 0 = all> {<cloud.bin> <cx> <cy> <cz>}...
+// A corner file is written for a frame under the library's accept rule (include/ilcc_hip.h, "accepting a frame": status ==
+// ILCC_OK and ILCC_FLAG_LOW_COVERAGE clear -- the operator's `r` key of the reference, LidarCornersEst.cpp:415-441), with the same
+// two switches as ilcc_corners (ilcc_corners_cli.cpp) and the class mirror: --accept-ambiguous also takes ILCC_AMBIGUOUS
+// records, --accept-low-coverage takes flagged ones.
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
 
@@ -160,8 +164,21 @@ int run_rank(RankJob* j) {
 
 int main(int argc, char** argv) {
   (void)setenv("GPU_MAX_HW_QUEUES", "8", /*overwrite=*/0);   // host-side, before the first HIP call (include/ilcc_hip.h)
+  bool accept_ambiguous = false, accept_low_coverage = false;
+  const char* prog = argv[0];
+  while (argc > 1 && std::strncmp(argv[1], "--", 2) == 0) {
+    if (std::strcmp(argv[1], "--accept-ambiguous") == 0) accept_ambiguous = true;
+    else if (std::strcmp(argv[1], "--accept-low-coverage") == 0) accept_low_coverage = true;
+    else {
+      std::fprintf(stderr, "unknown option: %s\n", argv[1]);
+      return 2;
+    }
+    ++argv;
+    --argc;
+  }
   if (argc < 8 || (argc - 4) % 4 != 0) {
-    std::fprintf(stderr, "usage: %s <yaml|-> <out_prefix> <n_gpus, 0 = all> {<cloud.bin> <cx> <cy> <cz>}...\n", argv[0]);
+    std::fprintf(stderr, "usage: %s [--accept-ambiguous] [--accept-low-coverage] <yaml|-> <out_prefix> <n_gpus, 0 = all> "
+                         "{<cloud.bin> <cx> <cy> <cz>}...\n", prog);
     return 2;
   }
   const std::string yaml = argv[1], prefix = argv[2];
@@ -225,7 +242,7 @@ int main(int argc, char** argv) {
 
   // rank 0: every frame's record must sit at its own position (tag = global frame index) with intact contents
   const RankJob& root = jobs[0];
-  uint32_t written = 0;
+  uint32_t written = 0, rejected = 0;
   for (uint32_t f = 0; f < F; ++f) {
     const uint32_t r = f / per, k = f - r * per;
     const float* rec = root.gathered.data() + ((size_t)r * per + k) * root.width;
@@ -234,15 +251,24 @@ int main(int argc, char** argv) {
       return 1;
     }
     const int status = (int)rec[0], nc = (int)rec[1];
+    const uint32_t flags = (uint32_t)rec[18];
     const std::string file = prefix + "_lidar_" + std::to_string(f + 1) + ".txt";   // get_lidar_corners.cpp:197
+    // the accept rule of include/ilcc_hip.h (what LidarCornersEst::get_corners of the class mirror applies)
+    const bool accepted = (status == ILCC_OK || (accept_ambiguous && status == ILCC_AMBIGUOUS)) &&
+                          (accept_low_coverage || !(flags & ILCC_FLAG_LOW_COVERAGE));
     bool ok = false;
-    if (status == ILCC_OK) {
+    if (accepted) {
       ok = ilcc_save_corners2txt(rec + ILCC_RECORD_HEADER, (uint32_t)nc, file.c_str()) == ILCC_OK;
       written += ok ? 1u : 0u;
+    } else if (status == ILCC_OK || status == ILCC_AMBIGUOUS) {
+      ++rejected;
     }
-    std::printf("frame %u rank %u status %d corners %d margin %.6g file %s\n", f + 1, r, status, nc, (double)rec[15],
+    std::printf("frame %u rank %u status %d flags %u corners %d margin %.6g file %s\n", f + 1, r, status, flags, nc, (double)rec[15],
                 ok ? file.c_str() : "-");
   }
   std::printf("gathered %u records from %d GPU(s) with one ncclGather; %u files written\n", F, world, written);
+  if (rejected)
+    std::printf("%u frame(s) with corners rejected by the accept rule (ambiguous basin / low coverage: --accept-ambiguous, "
+                "--accept-low-coverage)\n", rejected);
   return 0;
 }

@@ -163,3 +163,60 @@ def run_sharded(extract_fn, clouds: np.ndarray, clicks: np.ndarray, world: int, 
     g = g[g[:, 0] >= 0][:f_total]
     verify_records(g, np.arange(len(g)))               # every frame's record, intact, at its own position
     return g
+
+
+# ---------------------------------------------------------------- host-side placement of a rank (8 ranks share one host)
+def parse_cpulist(text: str) -> List[int]:
+    """`0-63,128-191` (sysfs cpulist) -> [0, ..., 63, 128, ..., 191]."""
+    cpus: List[int] = []
+    for part in text.strip().split(","):
+        part = part.strip()
+        if not part:
+            continue
+        if "-" in part:
+            lo, hi = part.split("-", 1)
+            cpus.extend(range(int(lo), int(hi) + 1))
+        else:
+            cpus.append(int(part))
+    return cpus
+
+
+def gpu_numa_node(pci_address: str, sysfs: str = "/sys") -> int:
+    """NUMA node of the PCI function `dddd:bb:dd.f` (-1: unknown / the platform does not say)."""
+    import os
+    try:
+        with open(os.path.join(sysfs, "bus", "pci", "devices", pci_address.lower(), "numa_node")) as fh:
+            return int(fh.read().strip())
+    except (OSError, ValueError):
+        return -1
+
+
+def pin_rank_to_gpu_numa(pci_address: Optional[str], sysfs: str = "/sys", apply: bool = True) -> dict:
+    """Pin THIS process to the cores of the NUMA node its GPU hangs off, so that the rank's pinned input buffers (allocated
+    after this call: first touch) and its submit thread sit next to the GPU's PCIe root -- at N = 8 the ranks of one node
+    share the host's memory bandwidth and a buffer on the far socket crosses the inter-socket link on every H2D copy.
+    Returns {"pci", "numa_node", "cpus" (count), "pinned"}; does nothing (pinned False) when the node is unknown."""
+    import os
+    info = {"pci": pci_address, "numa_node": -1, "cpus": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 0,
+            "pinned": False}
+    if not pci_address:
+        return info
+    node = gpu_numa_node(pci_address, sysfs)
+    info["numa_node"] = node
+    if node < 0:
+        return info
+    try:
+        with open(os.path.join(sysfs, "devices", "system", "node", "node%d" % node, "cpulist")) as fh:
+            cpus = parse_cpulist(fh.read())
+    except OSError:
+        return info
+    if hasattr(os, "sched_getaffinity"):
+        allowed = os.sched_getaffinity(0)
+        cpus = [c for c in cpus if c in allowed]
+    if not cpus:
+        return info
+    info["cpus"] = len(cpus)
+    if apply and hasattr(os, "sched_setaffinity"):
+        os.sched_setaffinity(0, cpus)
+        info["pinned"] = True
+    return info

@@ -1036,6 +1036,33 @@ def _patch(rng, centre, u, v, half_u, half_v, pitch, jitter=0.002):
     return np.concatenate([pts, rng.uniform(5, 90, (len(pts), 1))], axis=1).astype(np.float32)
 
 
+def test_a_ticket_is_waited_for_by_its_own_call_family():
+    """tickets carry their kind.  A ticket of ilcc_submit_chessboard_by_point refused by ilcc_wait / ilcc_wait_compact
+    (they would skip the by-point epilogue), a ticket of ilcc_submit_batch refused by ilcc_wait_chessboard_by_point (it would run that
+    epilogue on staging no copy has filled); the refused batch stays in flight and its own wait still delivers it."""
+    from lidar_camera_calibration_amd import IlccError
+    clouds, clicks, gts, _ = synth.make_batch(4, seed=77)
+    pts = np.ascontiguousarray(gts.mean(axis=1), dtype=np.float32)
+    e = LidarCornersBatch(4, 28800, N.default_params())
+    want = [(r.status, r.n_plane) for r in e.chessboard_by_point(clouds, pts)]
+    c, k = np.ascontiguousarray(clouds), np.ascontiguousarray(pts)
+    t = e.submit_chessboard_by_point(c.ctypes.data, 4, 28800, k.ctypes.data)
+    with pytest.raises(IlccError) as ei:
+        e.wait(t)
+    assert ei.value.status == N.BAD_ARGUMENT and "ilcc_wait_chessboard_by_point" in str(ei.value)
+    with pytest.raises(IlccError):
+        e.wait_compact(t)
+    assert [(r.status, r.n_plane) for r in e.wait_chessboard_by_point(t)] == want
+    ck = np.ascontiguousarray(clicks)
+    ref = [(r.status, r.n_plane, r.n_roi) for r in e.extract(clouds, clicks)]
+    t = e.submit_host(c.ctypes.data, 4, 28800, ck.ctypes.data)
+    with pytest.raises(IlccError) as ei:
+        e.wait_chessboard_by_point(t)
+    assert ei.value.status == N.BAD_ARGUMENT and "ilcc_submit_batch" in str(ei.value)
+    assert [(r.status, r.n_plane, r.n_roi) for r in e.wait(t)] == ref
+    e.close()
+
+
 def test_online_caller_two_tiers_agree_with_the_oracle_on_the_tier_boundary(ob):
     """The online caller answers from a +-1.25 m window around the click when it can PROVE the window's answer is the whole
     cloud's, and reruns the frame on the whole cloud otherwise (k2_cluster.hip, fine_cluster_frame's first-tier checks).  Scenes
@@ -1302,6 +1329,48 @@ def test_sparse_wide_roi_takes_the_hashed_block_path(ob):
     assert r.n_cluster >= 100 and len(got) == r.n_cluster
     if r.status in (N.OK, N.AMBIGUOUS):
         assert np.abs(r.corners_array() - ob.result_corners(o)).max() < 1e-6
+
+
+def test_tiny_wide_frames_do_not_write_into_their_neighbours(ob):
+    """the hashed-block path keeps its block arrays (>= 1024 words each) in the frame's own slices of the handle's
+    buffers, 4 words per INPUT point -- a frame of fewer than 256 input points spread over a bounding grid larger than K2's
+    cell bitmap used to write up to 1024 words past its slice, into the next frame's tables (past the allocation for the last
+    frame).  Such frames take the point-level search now.  A ragged batch alternating tiny wide frames with full frames: every
+    frame's stage counts and cluster cloud equal the oracle's, run twice (the corruption was a race)."""
+    board = synth.Board()
+    rng = np.random.default_rng(5)
+    clouds, clicks = [], []
+    for k in range(7):   # (tiny, full, tiny, full, tiny, full, tiny: the last frame's tables would end past the allocation)
+        pose = synth.pose_from_fixture(k % 6)
+        cloud = synth.make_frame(synth.vlp16(), board, pose, 31 + k)
+        click = synth.make_click(pose, 31 + k)
+        if k % 2 == 0:   # ~200 input points: ~150 on the board (a >= 100-point cluster), the rest spread over 12 x 12 x 6 m
+            d = np.linalg.norm(cloud[:, :3] - click[None, :], axis=1)
+            near = np.flatnonzero(d < 0.45)[:150]
+            far = rng.choice(np.flatnonzero(d > 1.5), 60, replace=False)
+            cloud = np.ascontiguousarray(cloud[np.sort(np.concatenate([near, far]))])
+            assert len(cloud) < 256
+        clouds.append(cloud)
+        clicks.append(click)
+    p = N.default_params()
+    p.roi_half[0], p.roi_half[1], p.roi_half[2] = 6.0, 6.0, 3.0
+    op = ob.default_params()
+    op.solver = ob.SOLVER_GRID
+    op.roi_half[0], op.roi_half[1], op.roi_half[2] = 6.0, 6.0, 3.0
+    offsets = np.concatenate([[0], np.cumsum([len(c) for c in clouds])]).astype(np.uint64)
+    flat = np.ascontiguousarray(np.concatenate(clouds))
+    e = LidarCornersBatch(len(clouds), max(len(c) for c in clouds), p)
+    want = [ob.extract(clouds[f], clicks[f], op, want_clouds=True) for f in range(len(clouds))]
+    for _ in range(2):
+        res = e.extract(flat, np.stack(clicks), offsets)
+        for f, r in enumerate(res):
+            o = want[f][0]
+            assert (r.status, r.n_roi, r.n_cluster, r.n_plane) == (o.status, o.n_roi, o.n_cluster, o.n_plane), f
+            if r.n_cluster:
+                roi_idx = ob.roi_crop(clouds[f], clicks[f], op)
+                clu_idx, _ = ob.cluster(clouds[f][roi_idx], clicks[f], op)
+                assert np.array_equal(e.fetch_cloud(f, N.CLOUD_CLUSTER), clouds[f][roi_idx][clu_idx]), f
+    e.close()
 
 
 def test_parameter_validation_and_second_handle():

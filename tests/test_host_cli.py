@@ -177,6 +177,30 @@ def test_cpp_multi_gpu_driver_gathers_with_rccl(tmp_path, golden_dir):
         ok, st, _ = _python_mirror_file(cloud, click, yaml, str(py), N.SOLVER_GRID)
         assert ok and int(f["status"]) == st == N.OK
         assert open(f["file"], "rb").read() == py.read_bytes()
+    # the accept rule (include/ilcc_hip.h): a frame whose record carries ILCC_FLAG_LOW_COVERAGE (the upper third of the board
+    # occluded) gets no file unless --accept-low-coverage is given -- what the class mirror, the node and ilcc_corners do
+    board = synth.Board()
+    pose = synth.pose_from_fixture(0)
+    cloud = synth.make_frame(synth.vlp16(), board, pose, 0xC0FFEE)
+    click = synth.make_click(pose, 0xC0FFEE)
+    up = np.array(pose.v if abs(pose.v[2]) > abs(pose.u[2]) else pose.u)
+    up = up * np.sign(up[2])
+    keep = ((cloud[:, :3] - pose.centre) @ up < 0.18) | (np.linalg.norm(cloud[:, :3] - pose.centre, axis=1) > 1.0)
+    cut = np.ascontiguousarray(cloud[keep])
+    raw = tmp_path / "cut.bin"
+    cut.tofile(raw)
+    tail = [str(raw), *("%.9g" % v for v in click), str(tmp_path / "f0.bin"), *("%.9g" % v for v in frames[0][1])]
+    for switches, want_files in (([], None), (["--accept-ambiguous"], None), (["--accept-low-coverage", "--accept-ambiguous"], 2)):
+        r = subprocess.run([mgpu, *switches, yaml, str(tmp_path / ("acc%d" % len(switches))), "1", *tail],
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        ln = [x.split() for x in r.stdout.splitlines() if x.startswith("frame ")]
+        f0 = dict(zip(ln[0][2::2], ln[0][3::2]))
+        assert int(f0["status"]) in (N.OK, N.AMBIGUOUS) and int(f0["flags"]) & N.FLAG_LOW_COVERAGE and int(f0["corners"]) == 35
+        if want_files is None:
+            assert f0["file"] == "-" and "1 files written" in r.stdout and "rejected by the accept rule" in r.stdout
+        else:
+            assert os.path.exists(f0["file"]) and "%d files written" % want_files in r.stdout
     # a rank whose local work fails still joins the collective: the driver exits with an error, it does not hang
     # (round-2 advisor finding); the LAST rank fails, so that on an N-GPU node the other ranks really wait for it
     env = dict(os.environ, ILCC_MGPU_FAIL_RANK=str(ndev - 1))
@@ -227,6 +251,12 @@ def test_bench_plain_invocation_with_gpus_2_launches_two_ranks():
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 500
     assert "bench preflight: backend gloo, world 2; ranks [0, 1]" in err, err[-2000:]
     assert "re-executing as" in err
+    # every rank reports where it runs: its GPU's PCI address, that GPU's NUMA node and the cores it pinned itself to
+    import re
+    place = re.findall(r"bench placement: rank (\d) device 0 pci ([0-9a-f:.]+) numa_node (-?\d+) cpus (\d+) pinned (True|False)", err)
+    assert sorted(p[0] for p in place) == ["0", "1"], err[-2000:]
+    assert all((p[4] == "True") == (int(p[2]) >= 0) and int(p[3]) >= 1 for p in place), place
+    assert out["host_placement"]["pci"] == place[0][1]
 
 
 def test_bench_refuses_more_ranks_than_devices():

@@ -114,14 +114,14 @@ def test_bench_reads_its_roofline_inputs_from_committed_profiles():
 
 def test_k6_credit_matches_the_isa():
     """bench.py credits each executed K6 evaluation with the VALU instruction count of the term: the constants there, the
-    committed profiles/r03_k6_isa_count.json and a fresh run of tools/k6_isa_count.sh on the current source (hipcc -S,
+    committed profiles/r06_k6_isa_count.json and a fresh run of tools/k6_isa_count.sh on the current source (hipcc -S,
     no GPU needed) must agree -- the credit is regenerated, not asserted."""
     import json
     import re
     import shutil
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    committed = json.load(open(os.path.join(root, "profiles", "r03_k6_isa_count.json")))
+    committed = json.load(open(os.path.join(root, "profiles", "r06_k6_isa_count.json")))
     src = open(os.path.join(root, "bench.py")).read()
     border = float(re.search(r"^K6_VALU_OPS_BORDER = ([0-9.]+)", src, re.M).group(1))
     interior = float(re.search(r"^K6_VALU_OPS_INTERIOR = ([0-9.]+)", src, re.M).group(1))
@@ -327,3 +327,21 @@ def test_bench_gpus_flag_never_silently_runs_one_rank():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], capture_output=True, text=True, timeout=300,
                        env=dict(env, WORLD_SIZE="2", RANK="0"), cwd=ROOT)
     assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr and not r.stdout.strip()
+
+
+def test_rank_placement_reads_the_gpus_numa_node(tmp_path):
+    """sharding.pin_rank_to_gpu_numa: PCI address -> numa_node -> that node's cpulist (a fake sysfs tree; nothing is pinned here)."""
+    from lidar_camera_calibration_amd.sharding import gpu_numa_node, parse_cpulist, pin_rank_to_gpu_numa
+    assert parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11] and parse_cpulist("") == []
+    dev = tmp_path / "bus" / "pci" / "devices" / "0000:c5:00.0"
+    dev.mkdir(parents=True)
+    (dev / "numa_node").write_text("1\n")
+    node = tmp_path / "devices" / "system" / "node" / "node1"
+    node.mkdir(parents=True)
+    allowed = sorted(os.sched_getaffinity(0))
+    (node / "cpulist").write_text("%d-%d\n" % (allowed[0], allowed[-1]))
+    assert gpu_numa_node("0000:C5:00.0", str(tmp_path)) == 1 and gpu_numa_node("0000:00:00.0", str(tmp_path)) == -1
+    info = pin_rank_to_gpu_numa("0000:c5:00.0", str(tmp_path), apply=False)
+    assert info["numa_node"] == 1 and info["cpus"] == len(allowed) and info["pinned"] is False
+    assert pin_rank_to_gpu_numa(None, str(tmp_path))["pinned"] is False
+    assert pin_rank_to_gpu_numa("0000:00:00.0", str(tmp_path))["numa_node"] == -1

@@ -15,7 +15,7 @@ for MODE in "20_5:--no-alone-leg" "inflight1:--in-flight 1"; do
   F=$(find $R/gpurun_out/prof_${TAG}_stats_$N -name "*kernel_stats.csv" | head -1)
   cp $F $R/gpurun_out/${TAG}_kernel_stats_bench_$N.csv; cut -c1-150 $F | head -18
   python -c "
-import json; d=json.load(open('$R/gpurun_out/prof_${TAG}_bench_$N.json')); print('BENCH under rocprof ($N)', round(d['value']), d['ms_per_step'], d['roofline']['launch_ms'])"
+import json; d=json.load(open('$R/gpurun_out/prof_${TAG}_bench_$N.json')); print('BENCH under rocprof ($N)', round(d['value']), d['ms_per_step'], d['roofline']['k6_ms_pipelined'])"
 done
 cd $R
 # BASELINE's roofline run (config 5): the same two kernel traces
@@ -25,7 +25,7 @@ for MODE in "config5:--no-alone-leg" "config5_inflight1:--in-flight 1"; do
   F=$(find $R/gpurun_out/prof_${TAG}_stats_$N -name "*kernel_stats.csv" | head -1)
   cp $F $R/gpurun_out/${TAG}_kernel_stats_$N.csv; cut -c1-150 $F | head -18
   python -c "
-import json; d=json.load(open('$R/gpurun_out/prof_${TAG}_bench_$N.json')); print('BENCH under rocprof ($N)', round(d['value']), d['ms_per_step'], d['roofline']['launch_ms'])"
+import json; d=json.load(open('$R/gpurun_out/prof_${TAG}_bench_$N.json')); print('BENCH under rocprof ($N)', round(d['value']), d['ms_per_step'], d['roofline']['k6_ms_pipelined'])"
 done
 if [ "$2" = "pmc" ]; then
   tools/gpu_pmc.sh $TAG 1024 2 | tail -14 | cut -c1-220
