@@ -295,7 +295,13 @@ __device__ __forceinline__ uint32_t box_prepass_rounds(int n_tiles, int ntb, int
 }
 
 
-template <bool OOB, bool VOLUME, bool LDS_POINTS, bool PRUNE, int THREADS>
+// OVERFLOW (round 6; LDS_POINTS only): the frame holds more labelled points than the workgroup's LDS staging (Ctx::grid_lds_points:
+// the handle stops growing it where a second workgroup would no longer fit the CU).  The first grid_lds_points walk positions are
+// staged as always -- the box pre-pass's sample and the blocks nearly every tile dies on are among them --, a position past them is
+// read from the walk layout in L2 and rotated by the lane that needs it: only the few tiles that walk (almost) the whole frame get
+// there.  Same points, same order, same sums.  (Before: such a frame took the LDS-free body, which has no box pre-pass: a handful of
+// frames with 6 682 labelled points made config 5's full pass 5.6 ms instead of 0.74 ms per 128 frames.)
+template <bool OOB, bool VOLUME, bool LDS_POINTS, bool PRUNE, int THREADS, bool OVERFLOW = false>
 __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, float2* s_ij, float* s_hw, Best* s_best,
                                                uint32_t* s_iters, uint32_t* s_cnt, float* s_ay, float* s_az, uint32_t* s_dead, uint16_t* s_live,
                                                uint32_t* s_next, const uint32_t kblk) {
@@ -386,9 +392,13 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
     n_in = (uint32_t)(((uint64_t)Mi_all * M) / Mfull);
     n_rm = (uint32_t)(((uint64_t)n_rim_all * M) / Mfull);
   }
+  const uint32_t lds_n = OVERFLOW ? min(M, c.grid_lds_points) : M;   // walk positions [0, lds_n) live in LDS
+  auto walk_source = [&](uint32_t sl) -> uint32_t {   // walk position -> index in the walk layout
+    const uint32_t src = sl < n_in ? sl : sl < n_in + n_rm ? Mi_all + (sl - n_in) : Mi_all + n_rim_all + (sl - n_in - n_rm);
+    return min(src, Mfull - 1u);
+  };
   auto stage_point = [&](uint32_t sl) {
-    uint32_t src = sl < n_in ? sl : sl < n_in + n_rm ? Mi_all + (sl - n_in) : Mi_all + n_rim_all + (sl - n_in - n_rm);
-    src = min(src, Mfull - 1u);
+    const uint32_t src = walk_source(sl);
     const float2 v = wyz[src];
     // Rx(theta) on (0,y,z), already divided by g (Optimization.h:37-46)
     s_ij[sl] = make_float2(fmaf(-sth, v.y, cth * v.x), fmaf(cth, v.y, sth * v.x));
@@ -402,7 +412,7 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
     // them: every theta more than a few steps from the minimum) never stages, or reads, the rest.
     const bool box_first = PRUNE && OOB && c.box_points != 0u && nta * ntb <= kBoxTilesMax && M > Mi;   // (= use_box below)
     stage_lo = box_first ? Mi : 0u;
-    stage_hi = box_first ? Mi + min(max(c.box_points, Mfull >> kBoxShift), M - Mi) : M;
+    stage_hi = box_first ? Mi + min(max(c.box_points, Mfull >> kBoxShift), M - Mi) : lds_n;   // (OVERFLOW: the caller made sure the sample fits)
     for (uint32_t sl = stage_lo + threadIdx.x; sl < stage_hi; sl += THREADS) stage_point(sl);
   }
   // (ty, tz) tables in LDS: a cut-short tile lasts about as long as one L2 round trip, so its
@@ -465,7 +475,7 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
         return;
       }
       for (uint32_t sl = threadIdx.x; sl < stage_lo; sl += THREADS) stage_point(sl);
-      for (uint32_t sl = stage_hi + threadIdx.x; sl < M; sl += THREADS) stage_point(sl);
+      for (uint32_t sl = stage_hi + threadIdx.x; sl < lds_n; sl += THREADS) stage_point(sl);
       __syncthreads();
     }
   }
@@ -530,6 +540,11 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
     uint32_t pos = 0;
     auto fetch = [&](uint32_t at) -> PointTerms {   // at = walk position of THIS lane's point
       if (LDS_POINTS) {
+        if (OVERFLOW && at >= lds_n) {   // past the staged prefix: from the walk layout in L2, rotated here (stage_point's expressions)
+          const uint32_t src = walk_source(at);
+          const float2 v = wyz[src];
+          return PointTerms{fmaf(-sth, v.y, cth * v.x), fmaf(cth, v.y, sth * v.x), wlab[src] ? 0.5f : 0.f};
+        }
         const float2 v = s_ij[at];
         return PointTerms{v.x, v.y, s_hw[at]};
       } else {
@@ -941,10 +956,24 @@ __global__ __launch_bounds__(THREADS) void k6_grid_cost(Ctx c, float* volume) {
   const uint32_t Mall = c.n_lab[blockIdx.y];
   const uint32_t M = c.walk_limit ? min(Mall, max(c.walk_limit, Mall >> kSeedShift)) : Mall;
   (void)M;
-  if (Mall <= c.grid_lds_points)   // (k5w_walk_order has laid out every frame of at most kGridLdsPointsMax points)
+  if (Mall <= c.grid_lds_points) {   // (k5w_walk_order has laid out every frame of at most kGridLdsPointsMax points)
     grid_cost_body<OOB, VOLUME, true, PRUNE, THREADS>(c, volume, s_ij, s_hw, s_best, s_iters, s_cnt, s_ay, s_az, s_dead, s_live, &s_next, blockIdx.x);
-  else
-    grid_cost_body<OOB, VOLUME, false, PRUNE, THREADS>(c, volume, s_ij, s_hw, s_best, s_iters, s_cnt, s_ay, s_az, s_dead, s_live, &s_next, blockIdx.x);
+    return;
+  }
+  if constexpr (OOB && !VOLUME && PRUNE) {
+    // the pipeline's full pass on a frame above the staging capacity: the staged prefix + the rest through L2, as long as the
+    // interior class and the box pre-pass's sample (what every workgroup reads) are inside the prefix
+    constexpr int kBoxShift = (THREADS == kGridThreadsLarge && kGridThreadsLarge != kGridThreads) ? kBoxShiftLarge : kBoxShiftSmall;
+    if (c.walk_limit == 0u && c.box_points != 0u && Mall <= (uint32_t)kGridLdsPointsMax) {
+      const uint32_t Mi = c.walk_mi[blockIdx.y];
+      if (Mall > Mi && Mi + min(max(c.box_points, Mall >> kBoxShift), Mall - Mi) <= c.grid_lds_points) {
+        grid_cost_body<OOB, VOLUME, true, PRUNE, THREADS, true>(c, volume, s_ij, s_hw, s_best, s_iters, s_cnt, s_ay, s_az, s_dead, s_live, &s_next,
+                                                                blockIdx.x);
+        return;
+      }
+    }
+  }
+  grid_cost_body<OOB, VOLUME, false, PRUNE, THREADS>(c, volume, s_ij, s_hw, s_best, s_iters, s_cnt, s_ay, s_az, s_dead, s_live, &s_next, blockIdx.x);
 }
 
 // k6_group_prepass: ONE box pre-pass for a GROUP of kThetaGroup consecutive thetas, in front of the full pass.  71 % of the (frame,
@@ -970,7 +999,9 @@ __global__ __launch_bounds__(THREADS) void k6_group_prepass(Ctx c, uint32_t* grp
   const int k0 = kThetaGroup * (int)blockIdx.x, nk = min(kThetaGroup, c.p.n_th - k0);
   const uint32_t tr = f * c.grp_count + blockIdx.x;
   const uint32_t Mall = c.n_lab[f];
-  const bool lds = Mall <= c.grid_lds_points;
+  // (frames above the full pass's staging capacity have a walk layout too -- k5w lays out every frame of at most kGridLdsPointsMax
+  // points -- and their full pass reads this mask in its OVERFLOW form)
+  const bool lds = Mall <= (uint32_t)kGridLdsPointsMax;
   const int n_ty = c.p.n_ty, n_tz = c.p.n_tz;
   const int nta = (n_ty + kTile - 1) / kTile, ntb = (n_tz + kTile - 1) / kTile, n_tiles = nta * ntb;
   const uint32_t Mi = lds ? c.walk_mi[f] : 0u;
@@ -981,7 +1012,9 @@ __global__ __launch_bounds__(THREADS) void k6_group_prepass(Ctx c, uint32_t* grp
   }
   const int lane = lane_id();
   const int wid = __builtin_amdgcn_readfirstlane(wave_id());
-  const uint32_t n_pre = min(max(c.box_points, Mall >> (kBoxShift + kGroupShiftDelta)), Mall - Mi);
+  // (the sample never exceeds what launch_group_prepass sized the LDS for: any prefix of the rim-first walk gives a valid bound)
+  const uint32_t n_pre = min(min(max(c.box_points, Mall >> (kBoxShift + kGroupShiftDelta)), Mall - Mi),
+                             max(c.grid_lds_points / 2u + 64u, c.box_points));
   float4* s_w4 = reinterpret_cast<float4*>(smem);   // n_pre x (pi_lo, pi_hi, pj_lo, pj_hi)
   float* s_ay = reinterpret_cast<float*>(s_w4 + n_pre);
   float* s_az = s_ay + n_ty;

@@ -837,6 +837,10 @@ def test_reserved_handle_runs_its_first_batch_like_a_warmed_one(frames):
         assert (a.status, a.grid_index) == (b.status, b.grid_index) == (c.status, c.grid_index)
         assert tuple(a.theta_t) == tuple(b.theta_t) == tuple(c.theta_t)
         assert np.array_equal(b.corners_array(), c.corners_array())
+        # round 6: the fresh handle's full pass stages the first 1024 walk positions and reads the rest of the same walk through L2
+        # (grid_cost_body<OVERFLOW>): the same points in the same order -- the fp32 cost of the argmin is the same float
+        assert a.grid_cost == b.grid_cost == c.grid_cost
+    assert abs(cold_evals - int(t1.grid_cost_evals_sum)) <= 0.25 * t1.grid_cost_evals_sum, (cold_evals, t1.grid_cost_evals_sum)
     warm.close()
     res.close()
 
