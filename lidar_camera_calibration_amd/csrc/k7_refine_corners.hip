@@ -233,7 +233,8 @@ __device__ __forceinline__ void accumulate_class(const Problem& q, const double 
                                                  double acc[10]) {
 #pragma unroll
   for (int k = 0; k < 10; ++k) acc[k] = 0.0;
-#pragma unroll 2
+  // (the Jacobian pass is one evaluation in six and carries 10 sums: not unrolled, its registers set the kernel's occupancy)
+#pragma unroll 1
   for (uint32_t p = first; p < q.n; p += (uint32_t)(4 * ILCC_WAVE)) add_point<JAC>(q, x, cs, sn, p, acc);
 }
 
@@ -556,13 +557,14 @@ __device__ unsigned long long g_k7_t[4];
 // block at the head of the loop (DoglegStrategy::StepAccepted's radius / mu updates do not read it, so running them
 // first changes nothing) -- the kernel's code stays within the instruction cache.
 template <bool WIDE>
-__device__ __forceinline__ int trust_region_minimize(const Problem& q, double x[3], double& final_cost, int max_iter) {
+__device__ __forceinline__ int trust_region_minimize(const Problem& q, double x[3], double& final_cost, int max_iter, Dog& s) {
   if (q.n == 0) {
     final_cost = 0.0;
     return 0;
   }
   double sums[10];
-  Dog s;
+  // (s: this wavefront's dogleg state in LDS -- ~60 doubles that would otherwise stay live in VGPRs across every evaluation of
+  // the points: 226 VGPRs, two wavefronts per SIMD; the wavefront reads them back, wave-uniform addresses, where the dogleg needs them)
   s.radius = 1e4;
   s.mu = 1e-8;
   s.reuse = 0;
@@ -668,7 +670,7 @@ __device__ __forceinline__ bool partial_less(const GridPartial& a, const GridPar
 
 // pass A then pass B of (frame f, phase slot) on the points q.yz / q.lab: one wavefront (WIDE = false) or the whole workgroup
 template <bool WIDE>
-__device__ __forceinline__ void solve_wave(const Ctx& c, Problem& q, uint32_t f, uint32_t slot, SolveRec* out) {
+__device__ __forceinline__ void solve_wave(const Ctx& c, Problem& q, uint32_t f, uint32_t slot, SolveRec* out, Dog& dog) {
   double x[3] = {0.0, 0.0, 0.0};
   int phase = (int)slot;
   if (c.p.phase_mode != 2) {
@@ -681,7 +683,7 @@ __device__ __forceinline__ void solve_wave(const Ctx& c, Problem& q, uint32_t f,
   for (int pass = 0; pass < 2; ++pass) {
     q.oob = pass == 0;   // pass A: useOutofBoard (LidarCornersEst.cpp:403-405), pass B: not (:406-408)
     double fc = 0.0;
-    const int it = trust_region_minimize<WIDE>(q, x, fc, c.p.max_iterations);
+    const int it = trust_region_minimize<WIDE>(q, x, fc, c.p.max_iterations, dog);
     cost[pass] = fc;
     iters[pass] = it;
   }
@@ -716,6 +718,7 @@ __device__ __forceinline__ void solve_wave(const Ctx& c, Problem& q, uint32_t f,
 // staged points.  Dynamic LDS: (kSolveWaves / n_slots) frames x grid_lds_points x 9 bytes.
 __global__ __launch_bounds__(kSolveThreads) void k7a_local_solve(Ctx c, SolveRec* rec, int n_slots) {
   extern __shared__ __align__(16) unsigned char smem[];
+  __shared__ Dog s_dog[kSolveWaves];   // one dogleg state per wavefront (= per solve)
   const uint32_t wave = (uint32_t)wave_id();
   const uint32_t solve = blockIdx.x * (uint32_t)kSolveWaves + wave;
   const uint32_t f = solve / (uint32_t)n_slots, slot = solve % (uint32_t)n_slots;
@@ -746,11 +749,11 @@ __global__ __launch_bounds__(kSolveThreads) void k7a_local_solve(Ctx c, SolveRec
   if (in_lds) {
     q.yz = s_yz;
     q.lab = s_lab;
-    solve_wave<false>(c, q, f, slot, out);
+    solve_wave<false>(c, q, f, slot, out, s_dog[wave]);
   } else {   // a frame above the handle's LDS capacity (it grows after the batch): the points stay in HBM / L2
     q.yz = c.yz + beg;
     q.lab = c.lab + beg;
-    solve_wave<false>(c, q, f, slot, out);
+    solve_wave<false>(c, q, f, slot, out, s_dog[wave]);
   }
 }
 
@@ -761,6 +764,7 @@ __global__ __launch_bounds__(kSolveThreads) void k7a_local_solve(Ctx c, SolveRec
 __global__ __launch_bounds__(kSolveThreads) void k7a_local_solve_wide(Ctx c, SolveRec* rec) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ double s_red[2 * kSolveRedDoubles];
+  __shared__ Dog s_dog[kSolveWaves];   // every wavefront keeps its own copy of the (identical) dogleg state: no cross-wavefront hazards
   const uint32_t f = blockIdx.x, slot = blockIdx.y;
   SolveRec* out = &rec[2 * f + slot];
   if (c.res[f].status != ILCC_OK) {
@@ -785,11 +789,11 @@ __global__ __launch_bounds__(kSolveThreads) void k7a_local_solve_wide(Ctx c, Sol
     __syncthreads();
     q.yz = s_yz;
     q.lab = s_lab;
-    solve_wave<true>(c, q, f, slot, out);
+    solve_wave<true>(c, q, f, slot, out, s_dog[wave_id()]);
   } else {
     q.yz = c.yz + beg;
     q.lab = c.lab + beg;
-    solve_wave<true>(c, q, f, slot, out);
+    solve_wave<true>(c, q, f, slot, out, s_dog[wave_id()]);
   }
 }
 
@@ -1456,9 +1460,10 @@ __global__ __launch_bounds__(ILCC_WAVE) void k7_local_solve_test(Ctx c, int tlw,
   q.bd = make_board(c.p);
   q.tlw = tlw != 0;
   q.oob = use_oob != 0;
+  __shared__ Dog s_dog1;
   double x[3] = {theta_t[0], theta_t[1], theta_t[2]};
   double cost = 0;
-  const int it = trust_region_minimize<false>(q, x, cost, c.p.max_iterations);
+  const int it = trust_region_minimize<false>(q, x, cost, c.p.max_iterations, s_dog1);
   if (threadIdx.x == 0) {
     theta_t[0] = x[0];
     theta_t[1] = x[1];
