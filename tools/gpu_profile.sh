@@ -3,7 +3,7 @@
 #   - rocprofv3 --kernel-trace --stats of the default bench, timed pipeline only (4 batches in flight) -> <TAG>_kernel_stats_bench_20_5.csv
 #   - the same with --in-flight 1 (one batch alone on the chip: clean per-kernel durations) -> <TAG>_kernel_stats_bench_inflight1.csv
 #   - with `pmc`: PMC passes at the batch sizes the bench runs (tools/gpu_pmc.sh: config 2 / 512 frames, config 5 / 64 frames)
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out
 python tools/dev_batch_timeline.py 1 30 2>/dev/null | tail -1 | tee $R/gpurun_out/${TAG}_timeline_grid.json

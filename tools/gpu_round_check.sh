@@ -1,6 +1,6 @@
 # full GPU verification for the round (run through gpurun from the repo root): tests, smoke, the driver's bench command
 # (--steps 20 --warmup 5) and a long run beside it
-TAG=${1:-r05}
+TAG=${1:-r06}
 mkdir -p gpurun_out
 timeout 2400 python -m pytest tests -m gpu -q -x 2>&1 | tail -15
 python -c "import __graft_entry__ as g; g.smoke(); print('SMOKE OK')" 2>&1 | tail -3
