@@ -777,14 +777,15 @@ int32_t enqueue_impl(ilcc_handle* h, int si, const float4* d_xyzi, const uint64_
   // the copy back: what the result mode asks for rides on the batch's stream (include/ilcc_hip.h, "Result traffic")
   sl.compact = h->result_mode == ILCC_RESULTS_COMPACT;
   sl.rec_corners = board_corners(h->p);
+  // (compact records and the batch counters are STORED into the pinned staging by kernels: no D2H command in the SDMA queue that
+  // carries the next batches' input copies -- launch_store_to_host)
   if (sl.compact) {
-    launch_pack_records(sl.d_res, n_frames, sl.rec_corners, 0u, sl.d_rec, s);
-    HIP_TRY(h, hipMemcpyAsync(sl.h_rec, sl.d_rec, sizeof(float) * (size_t)n_frames * (ILCC_RECORD_HEADER + 3 * sl.rec_corners),
-                              hipMemcpyDeviceToHost, s));
+    launch_pack_records(sl.d_res, n_frames, sl.rec_corners, 0u, sl.h_rec, s);   // K9 writes the records straight into the pinned staging
   } else {
     HIP_TRY(h, copy_results_trimmed(sl.h_res, sl.d_res, n_frames, sl.rec_corners, s));
   }
-  HIP_TRY(h, hipMemcpyAsync(sl.h_iters, sl.d_iters, sizeof(unsigned long long) * kBatchWords, hipMemcpyDeviceToHost, s));
+  launch_store_to_host(sl.d_iters, sl.h_iters, sizeof(unsigned long long) * kBatchWords, s);
+  HIP_TRY(h, hipGetLastError());
   sl.busy = true;
   sl.online = no_crop;
   return ILCC_OK;
@@ -807,8 +808,7 @@ int32_t finish(ilcc_handle* h, int si, ilcc_result* out, float* out_compact = nu
   const uint32_t n_frames = sl.n_frames;
   const size_t rec_w = (size_t)ILCC_RECORD_HEADER + 3 * (size_t)sl.rec_corners;
   if (out_compact && !sl.compact) {   // not enqueued with the batch: pack and copy now
-    launch_pack_records(sl.d_res, n_frames, sl.rec_corners, 0u, sl.d_rec, sl.stream);
-    HIP_TRY(h, hipMemcpyAsync(sl.h_rec, sl.d_rec, sizeof(float) * n_frames * rec_w, hipMemcpyDeviceToHost, sl.stream));
+    launch_pack_records(sl.d_res, n_frames, sl.rec_corners, 0u, sl.h_rec, sl.stream);
   }
   HIP_TRY(h, hipStreamSynchronize(sl.stream));
   sl.busy = false;

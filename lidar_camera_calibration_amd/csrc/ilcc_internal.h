@@ -310,6 +310,8 @@ uint32_t grid_cost_evals_per_count();   // (point, candidate) evaluations behind
 void launch_refine_corners(const Ctx& c, hipStream_t s);
 void launch_pack_records(const ilcc_result* d_res, uint32_t n_frames, uint32_t n_corners, uint32_t tag_base, float* d_out,
                          hipStream_t s);
+// device memory -> pinned (mapped) host memory with the GPU's own stores, on stream s: no SDMA command (k7_refine_corners.hip)
+void launch_store_to_host(const void* d_src, void* h_dst, size_t bytes, hipStream_t s);
 // K7r on every frame of the batch (GRID mode), then K7b
 void launch_pattern_refine_corners(const Ctx& c, hipStream_t s);
 // stand-alone K7r on the labelled points of frame 0 (test entry)

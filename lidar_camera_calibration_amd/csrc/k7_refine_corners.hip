@@ -1575,6 +1575,21 @@ __global__ __launch_bounds__(128) void k9_pack_records(const ilcc_result* __rest
   }
 }
 
+// Device -> pinned HOST memory by a kernel's own stores (the staging buffers are hipHostMalloc'ed: mapped, fine-grained).  Round 6:
+// a batch's result copies used to be hipMemcpyAsync(D2H) commands queued behind its kernels at submit time; the SDMA engine that
+// also carries the NEXT batches' 472 MB input copies then sat on each of them until that batch's kernels had finished
+// (tools/dev_h2d_probe.py: the H2D-inclusive pipeline moved 52.0 GB/s with kernels running against 56.3 GB/s with the kernels
+// returning early) -- with the records written by the GPU itself the SDMA queue holds input copies only.
+__global__ __launch_bounds__(256) void k_store_to_host(const uint32_t* __restrict__ src, uint32_t* __restrict__ host_dst, uint32_t n_words) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += gridDim.x * blockDim.x) host_dst[i] = src[i];
+}
+void launch_store_to_host(const void* d_src, void* h_dst, size_t bytes, hipStream_t s) {   // bytes: a multiple of 4
+  const uint32_t n_words = (uint32_t)(bytes / 4);
+  if (n_words == 0) return;
+  const uint32_t blocks = std::min<uint32_t>(256u, (n_words + 255u) / 256u);
+  hipLaunchKernelGGL(k_store_to_host, dim3(blocks), dim3(256), 0, s, static_cast<const uint32_t*>(d_src), static_cast<uint32_t*>(h_dst), n_words);
+}
+
 void launch_pack_records(const ilcc_result* d_res, uint32_t n_frames, uint32_t n_corners, uint32_t tag_base, float* d_out,
                          hipStream_t s) {
   if (n_frames) hipLaunchKernelGGL(k9_pack_records, dim3(n_frames), dim3(128), 0, s, d_res, n_corners, tag_base, d_out);
