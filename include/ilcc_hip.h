@@ -295,7 +295,9 @@ int32_t ilcc_wait_records_device(ilcc_handle* h, int32_t ticket, ilcc_result* ou
  *   - ILCC_RESULTS_COMPACT: the batch's own stream packs the gather records described above (K9: ILCC_RECORD_HEADER
  *     floats + 3 per corner = 500 B for the 7 x 5 board; tag = frame index within the batch; slot 19 = n_roi) and ONLY
  *     those cross PCIe; ilcc_wait_compact hands them over.  The full records stay in HBM: ilcc_fetch_results reads
- *     them for the last completed batch.
+ *     them for the last completed batch.  (Round 6: K9 STORES the records into the handle's pinned, mapped staging itself -- no
+ *     device-to-host copy command is queued behind the batch's kernels, so the copy engine that carries the next batches' input
+ *     copies never waits on one: tools/dev_h2d_probe.py.)
  * Both waits work in both modes -- the mode decides which copy is enqueued with the batch (the other one is then a
  * synchronous copy inside the wait).  Default: ILCC_RESULTS_FULL. */
 enum { ILCC_RESULTS_FULL = 0, ILCC_RESULTS_COMPACT = 1 };

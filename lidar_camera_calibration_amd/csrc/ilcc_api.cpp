@@ -56,7 +56,8 @@ struct Slot {
   unsigned long long* d_iters = nullptr;
   uint32_t *d_grp_alive = nullptr, *d_grp_mask = nullptr;   // K6's common pre-pass per (frame, group of kThetaGroup thetas): state word, rejected-tile mask
   size_t grp_alive_cap = 0, grp_mask_cap = 0;   // sized from (max_frames, the handle's grid) in alloc_slot / ilcc_set_params, never in the submit path
-  float* d_rec = nullptr;    // K9 records of the batch (ILCC_RESULTS_COMPACT): max_frames x (ILCC_RECORD_HEADER + 3 ILCC_MAX_CORNERS) floats
+  float* h_rec_dev = nullptr;               // the DEVICE address of h_rec (pinned, mapped): K9 stores the batch's compact records straight into it
+  unsigned long long* h_iters_dev = nullptr;   // ... and of h_iters
   // pinned host staging
   float* h_rec = nullptr;
   ilcc_result* h_res = nullptr;
@@ -253,7 +254,7 @@ int32_t upload_tables(ilcc_handle* h) {
 }
 
 void free_slot(Slot& sl) {
-  void* bufs[] = {sl.d_grp_alive, sl.d_grp_mask, sl.d_rec, sl.d_xyzi, sl.d_clicks, sl.d_off, sl.d_res, sl.d_roi, sl.d_cluster, sl.d_board, sl.d_pca, sl.d_optim,
+  void* bufs[] = {sl.d_grp_alive, sl.d_grp_mask, sl.d_xyzi, sl.d_clicks, sl.d_off, sl.d_res, sl.d_roi, sl.d_cluster, sl.d_board, sl.d_pca, sl.d_optim,
                   sl.d_yz, sl.d_walk_yz, sl.d_walk_lab, sl.d_walk_mi, sl.d_walk_nrim, sl.d_lab, sl.d_cls, sl.d_nlab, sl.d_walk, sl.d_counts, sl.d_parent, sl.d_count, sl.d_hash_head, sl.d_hash_next, sl.d_flags, sl.d_nfinite, sl.d_counts_fin, sl.d_list, sl.d_list_frames, sl.d_partial, sl.d_partial2, sl.d_partial3, sl.d_partial4, sl.d_masks,
                   sl.d_solverec, sl.d_bound, sl.d_bound_sub, sl.d_iters, sl.d_tie_count, sl.d_tie_list};
   for (void* b : bufs)
@@ -349,7 +350,6 @@ int32_t alloc_slot(ilcc_handle* h, Slot& sl) {
   ALLOC(sl.d_clicks, sizeof(float) * 3 * mf);
   ALLOC(sl.d_off, sizeof(uint64_t) * (mf + 1));
   ALLOC(sl.d_res, sizeof(ilcc_result) * mf);
-  ALLOC(sl.d_rec, sizeof(float) * (size_t)mf * (ILCC_RECORD_HEADER + 3 * ILCC_MAX_CORNERS));
   ALLOC(sl.d_roi, sizeof(float4) * np);
   ALLOC(sl.d_cluster, sizeof(float4) * np);
   ALLOC(sl.d_board, sizeof(float4) * np);
@@ -389,6 +389,9 @@ int32_t alloc_slot(ilcc_handle* h, Slot& sl) {
   HIP_TRY(h, hipHostMalloc((void**)&sl.h_res, sizeof(ilcc_result) * mf, hipHostMallocDefault));
   HIP_TRY(h, hipHostMalloc((void**)&sl.h_rec, sizeof(float) * (size_t)mf * (ILCC_RECORD_HEADER + 3 * ILCC_MAX_CORNERS), hipHostMallocDefault));
   HIP_TRY(h, hipHostMalloc((void**)&sl.h_iters, sizeof(unsigned long long) * kBatchWords, hipHostMallocDefault));
+  // (the records and counters are written by kernels, not by D2H copies: the device's view of the two pinned buffers)
+  HIP_TRY(h, hipHostGetDevicePointer((void**)&sl.h_rec_dev, sl.h_rec, 0));
+  HIP_TRY(h, hipHostGetDevicePointer((void**)&sl.h_iters_dev, sl.h_iters, 0));
   HIP_TRY(h, hipHostMalloc((void**)&sl.h_off, sizeof(uint64_t) * (mf + 1), hipHostMallocDefault));
   HIP_TRY(h, hipHostMalloc((void**)&sl.h_online, sizeof(uint32_t) * 2 * (size_t)mf, hipHostMallocDefault));
   {
@@ -780,11 +783,11 @@ int32_t enqueue_impl(ilcc_handle* h, int si, const float4* d_xyzi, const uint64_
   // (compact records and the batch counters are STORED into the pinned staging by kernels: no D2H command in the SDMA queue that
   // carries the next batches' input copies -- launch_store_to_host)
   if (sl.compact) {
-    launch_pack_records(sl.d_res, n_frames, sl.rec_corners, 0u, sl.h_rec, s);   // K9 writes the records straight into the pinned staging
+    launch_pack_records(sl.d_res, n_frames, sl.rec_corners, 0u, sl.h_rec_dev, s);   // K9 writes the records straight into the pinned staging
   } else {
     HIP_TRY(h, copy_results_trimmed(sl.h_res, sl.d_res, n_frames, sl.rec_corners, s));
   }
-  launch_store_to_host(sl.d_iters, sl.h_iters, sizeof(unsigned long long) * kBatchWords, s);
+  launch_store_to_host(sl.d_iters, sl.h_iters_dev, sizeof(unsigned long long) * kBatchWords, s);
   HIP_TRY(h, hipGetLastError());
   sl.busy = true;
   sl.online = no_crop;
@@ -808,7 +811,7 @@ int32_t finish(ilcc_handle* h, int si, ilcc_result* out, float* out_compact = nu
   const uint32_t n_frames = sl.n_frames;
   const size_t rec_w = (size_t)ILCC_RECORD_HEADER + 3 * (size_t)sl.rec_corners;
   if (out_compact && !sl.compact) {   // not enqueued with the batch: pack and copy now
-    launch_pack_records(sl.d_res, n_frames, sl.rec_corners, 0u, sl.h_rec, sl.stream);
+    launch_pack_records(sl.d_res, n_frames, sl.rec_corners, 0u, sl.h_rec_dev, sl.stream);
   }
   HIP_TRY(h, hipStreamSynchronize(sl.stream));
   sl.busy = false;
