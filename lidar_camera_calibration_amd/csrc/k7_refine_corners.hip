@@ -716,7 +716,10 @@ __device__ __forceinline__ void solve_wave(const Ctx& c, Problem& q, uint32_t f,
 // grid: ceil(n_frames * n_slots / kSolveWaves) workgroups; wavefront w of workgroup b runs solve b * kSolveWaves + w =
 // (frame, slot) = (solve / n_slots, solve % n_slots): with two slots the wavefronts 2k and 2k + 1 share a frame and its
 // staged points.  Dynamic LDS: (kSolveWaves / n_slots) frames x grid_lds_points x 9 bytes.
-__global__ __launch_bounds__(kSolveThreads) void k7a_local_solve(Ctx c, SolveRec* rec, int n_slots) {
+#ifndef ILCC_K7A_WAVES_PER_EU
+#define ILCC_K7A_WAVES_PER_EU 3
+#endif
+__global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(ILCC_K7A_WAVES_PER_EU, ILCC_K7A_WAVES_PER_EU))) void k7a_local_solve(Ctx c, SolveRec* rec, int n_slots) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ Dog s_dog[kSolveWaves];   // one dogleg state per wavefront (= per solve)
   const uint32_t wave = (uint32_t)wave_id();
