@@ -875,6 +875,41 @@ def test_reserved_handle_first_batch_config5():
     res.close()
 
 
+def test_frames_above_the_staging_capacity_config5():
+    """Round 6: a frame with more labelled points than the K6 full pass stages per workgroup keeps its box pre-passes -- the first
+    `grid_lds_points` walk positions in LDS, the rest of the same walk read through L2 (grid_cost_body<OVERFLOW>) -- instead of
+    falling to the LDS-free body.  BASELINE config 5's dense frames on a handle reserved for FEWER labelled points than they hold
+    vs a handle that stages them whole: the same walk, the same sums -- argmin, its fp32 cost, theta_t, corners identical; and the
+    executed evaluations stay within the branch and bound's run-to-run spread (the LDS-free body executes ~100 x as many)."""
+    board = synth.Board(9, 12, 0.10)
+    clouds, clicks, _, _ = synth.make_batch(4, synth.hdl64(), board, seed=0xC0FFEE, range_m=(2.0, 3.0), yaw_deg=25.0,
+                                            pitch_deg=15.0, roll_deg=30.0)
+    whole = LidarCornersBatch(4, 131072, config5_params(N.default_params()))
+    whole.reserve(6400, 20000)
+    r_whole = whole.extract(clouds, clicks)
+    m = [r.n_black + r.n_white for r in r_whole]
+    assert min(m) > 3200 and max(m) <= 6400, m
+    # every frame alone on a handle whose staging is the largest multiple of 256 BELOW its labelled count: above the capacity, with
+    # the interior class (~ half of the points) and the pre-pass's sample (a quarter) inside the staged prefix
+    for f, a in enumerate(r_whole):
+        cap = ((m[f] - 1) // 256) * 256
+        small = LidarCornersBatch(1, 131072, config5_params(N.default_params()))
+        small.reserve(cap, 20000)
+        one = LidarCornersBatch(1, 131072, config5_params(N.default_params()))
+        one.reserve(6400, 20000)
+        b = small.extract(clouds[f:f + 1], clicks[f:f + 1])[0]
+        w = one.extract(clouds[f:f + 1], clicks[f:f + 1])[0]
+        ev_small, ev_one = int(small.timing().grid_cost_evals_sum), int(one.timing().grid_cost_evals_sum)
+        for r in (b, w):
+            assert (a.status, a.grid_index, a.grid_cost) == (r.status, r.grid_index, r.grid_cost), (f, m[f], cap)
+            assert tuple(a.theta_t) == tuple(r.theta_t) and (a.iters_a, a.iters_b, a.basin_margin, a.flags) == (r.iters_a, r.iters_b, r.basin_margin, r.flags)
+            assert np.array_equal(a.corners_array(), r.corners_array())
+        assert abs(ev_small - ev_one) <= 0.25 * ev_one, (f, ev_small, ev_one)
+        small.close()
+        one.close()
+    whole.close()
+
+
 def test_cluster_size_gates_and_non_finite_points(ob, frames):
     """EuclideanClusterExtraction's [min, max] size gate: when the click's component is inadmissible the
     largest admissible one is taken (plane_index 0); NaN/inf points never reach the clustering."""
