@@ -75,56 +75,42 @@ template <bool JAC>
 __device__ __forceinline__ double residual(const double x[3], double c, double s, double y, double z,
                                            const SolveBoard& bd, bool tlw, bool laser_white, bool use_oob,
                                            double jac[3]) {
+  // written without a branch (round 6): a divergent `if` costs the wavefront both sides plus the exec-mask bookkeeping.
+  // min(frac, 1 - frac) IS the in-board distance of :70-78 -- frac = i - floor(i) is exact, and for frac > 1/2 both ceil(i) - i and
+  // 1 - frac are exact (Sterbenz) and equal; min(|i|, |i - W|) IS the out-of-board distance of :86-97
   const double ry = c * y - s * z;
   const double rz = s * y + c * z;
-  const double r1 = ry + x[1];
-  const double r2 = rz + x[2];
-  const double i = div_by(r1 + bd.Wg2, bd.g);
-  const double j = div_by(r2 + bd.Hg2, bd.g);
-  double si = 0, sj = 0, res = 0;
-  if (i > 0 && i < bd.W && j > 0 && j < bd.H) {
-    const double ifl = floor(i), jfl = floor(j);
-    const bool same_parity = ((((int)ifl) ^ ((int)jfl)) & 1) == 0;   // both even or both odd (:57-60)
-    const bool white = same_parity ? tlw : !tlw;
-    if (laser_white != white) {
-      const double fi = i - ifl, fj = j - jfl;
-      const bool ui = fi > 0.5, uj = fj > 0.5;
-      const double ie = ui ? (ifl + 1.0) - i : fi;
-      const double je = uj ? (jfl + 1.0) - j : fj;
-      si = ui ? -1.0 : 1.0;
-      sj = uj ? -1.0 : 1.0;
-      res = ie + je;
-    }
-  } else if (use_oob) {
-    const double iw = i - bd.W, jh = j - bd.H;
-    const bool ni = fabs(i) < fabs(iw), nj = fabs(j) < fabs(jh);
-    const double ie = ni ? fabs(i) : fabs(iw);
-    const double je = nj ? fabs(j) : fabs(jh);
-    si = ((ni ? i : iw) < 0) ? -1.0 : 1.0;
-    sj = ((nj ? j : jh) < 0) ? -1.0 : 1.0;
-    res = ie + je;
-  }
+  const double i = div_by((ry + x[1]) + bd.Wg2, bd.g);
+  const double j = div_by((rz + x[2]) + bd.Hg2, bd.g);
+  const bool inside = (int)(i > 0) & (int)(i < bd.W) & (int)(j > 0) & (int)(j < bd.H);
+  const double ifl = floor(i), jfl = floor(j);
+  const double fi = i - ifl, fj = j - jfl;
+  const double res_in = fmin(fi, 1.0 - fi) + fmin(fj, 1.0 - fj);
+  const bool odd = ((((int)ifl) ^ ((int)jfl)) & 1) != 0;
+  const bool white = odd != tlw;   // same parity: topleftWhite, else its opposite (:57-61)
+  const double iw = i - bd.W, jh = j - bd.H;
+  const double res_out = fmin(fabs(i), fabs(iw)) + fmin(fabs(j), fabs(jh));
+  const bool take_in = (int)inside & (int)(laser_white != white), take_out = (int)!inside & (int)use_oob;
   if (JAC) {
+    // d r / d i, d r / d j: -1 past the middle of a cell; out of board the sign of the nearer edge's offset (:86-97)
+    const double si_in = fi > 0.5 ? -1.0 : 1.0, sj_in = fj > 0.5 ? -1.0 : 1.0;
+    const double si_out = ((fabs(i) < fabs(iw) ? i : iw) < 0) ? -1.0 : 1.0, sj_out = ((fabs(j) < fabs(jh) ? j : jh) < 0) ? -1.0 : 1.0;
+    const double si = take_in ? si_in : (take_out ? si_out : 0.0), sj = take_in ? sj_in : (take_out ? sj_out : 0.0);
     const double dith = -div_by(rz, bd.g), djth = div_by(ry, bd.g);
     jac[0] = si * dith + sj * djth;
     jac[1] = si * bd.g.y;
     jac[2] = sj * bd.g.y;
   }
-  return res;
+  return take_in ? res_in : (take_out ? res_out : 0.0);
 }
 
 // HuberLoss(a) on s = r * r with r >= 0 (the residual is a sum of distances): sqrt(s) is r itself -- for binary floating point
 // sqrt(RN(r * r)) == |r| barring over/underflow (Boldo 2015; the oracle calls sqrt) -- so no square root is taken
 __device__ __forceinline__ void huber(double a, double r, double s, double& rho0, double& rho1) {
   const double b = a * a;
-  if (s > b) {
-    rho0 = 2.0 * a * r - b;
-    rho1 = a / r;
-    if (rho1 < 2.2250738585072014e-308) rho1 = 2.2250738585072014e-308;
-  } else {
-    rho0 = s;
-    rho1 = 1.0;
-  }
+  const bool outlier = s > b;
+  rho0 = outlier ? 2.0 * a * r - b : s;
+  rho1 = outlier ? fmax(a / r, 2.2250738585072014e-308) : 1.0;   // (only the Jacobian pass reads rho1: the cost pass drops the division)
 }
 
 // ------------------------------------------------------------------ wavefront-wide evaluation
