@@ -89,7 +89,8 @@ __device__ __forceinline__ double residual(const double x[3], double c, double s
   const bool odd = ((((int)ifl) ^ ((int)jfl)) & 1) != 0;
   const bool white = odd != tlw;   // same parity: topleftWhite, else its opposite (:57-61)
   const double iw = i - bd.W, jh = j - bd.H;
-  const double res_out = fmin(fabs(i), fabs(iw)) + fmin(fabs(j), fabs(jh));
+  double res_out = 0.0;
+  if (use_oob) res_out = fmin(fabs(i), fabs(iw)) + fmin(fabs(j), fabs(jh));   // (wave-uniform: pass B never computes it)
   const bool take_in = (int)inside & (int)(laser_white != white), take_out = (int)!inside & (int)use_oob;
   if (JAC) {
     // d r / d i, d r / d j: -1 past the middle of a cell; out of board the sign of the nearer edge's offset (:86-97)
