@@ -96,7 +96,7 @@ struct ilcc_handle {
   double* d_solve = nullptr;   // 3 theta_t + 2 (cost, iterations) for the test entries
   RefineOut* d_refine_io = nullptr;
   uint32_t grid_lds_points = 1024;   // grows with the frames seen (finish()); frames above it take the global-memory path
-  uint64_t group_prepass_skipped = 0;   // batches whose grid was eligible for k6_group_prepass but whose mask buffers were too small (a sizing bug if ever non-zero: ilcc_last_error reports it)
+  uint64_t group_prepass_skipped = 0;   // batches whose grid was eligible for k6_group_prepass but whose mask buffers were too small: a sizing bug if ever non-zero -- the first such batch leaves a note in ilcc_last_error (results are unaffected: the full pass runs without the common mask)
   uint32_t cluster_lds_points = 2048;   // K2's LDS capacity for cell-sorted ROI points per frame: grows likewise (<= 4096); larger frames sort into HBM
   uint32_t cluster_cells_cap = kClusterCellsMin;   // K2's LDS capacity in occupied cells per frame: grows with what the batches needed
   uint32_t list_grid = 1024;         // workgroups of the online caller's second-tier kernels (4 x the device's CUs)
@@ -692,7 +692,8 @@ int32_t enqueue_grid_search(ilcc_handle* h, Slot& sl, int si, const Ctx& c, hipS
     full.grp_alive = sl.d_grp_alive;
     full.grp_mask = sl.d_grp_mask;
   } else if (full.box_points != 0u && gp.on) {
-    ++h->group_prepass_skipped;   // eligible grid, buffers too small for this batch (never expected: size_group_prepass sized them)
+    // eligible grid, buffers too small for this batch (never expected: size_group_prepass sized them): slower, not wrong -- say so once
+    if (h->group_prepass_skipped++ == 0) h->err = "note: k6_group_prepass skipped (mask buffers smaller than this batch needs): slower, results unaffected";
   }
   HIP_TRY(h, hipEventRecord(sl.ev[7], s));
   // The FULL passes of different slots are chained so that they never share the chip (two passes side by side both run at half
