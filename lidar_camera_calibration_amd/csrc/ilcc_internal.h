@@ -49,7 +49,7 @@ constexpr int kTileA = 4;              // K6 candidate tile: ty values per wavef
 #endif
 constexpr int kTileB = ILCC_TILE_B;    // K6 candidate tile: tz values per wavefront pass (4 or 8)
 #ifndef ILCC_K6_GROUP
-#define ILCC_K6_GROUP 5   // measured (config 2 / config 5, k frames/s): 2: 821 / 50.9, 3: 837 / 54.5, 4: 837 / 55.1, 5: 842 / 56.2, 7: 841 / 56.3
+#define ILCC_K6_GROUP 7   // round 4 (config 2 / config 5, k frames/s): 2: 821 / 50.9, 3: 837 / 54.5, 4: 837 / 55.1, 5: 842 / 56.2, 7: 841 / 56.3; round 6, the per-theta pre-pass skipped behind a valid mask: 3: 1 235 / 82.9, 4: 1 250 / 83.9, 5: 1 276 / 89.7, 7: 1 280 / 91.5, 9: 1 283 / 92.6, 11: 1 271 / 92.2, 15: 1 177 / 90.8
 #endif
 constexpr int kThetaGroup = ILCC_K6_GROUP;   // K6: consecutive thetas that share one common box pre-pass (k6_group_prepass)
 constexpr int kGridLdsPointsMax = 8192;   // K6 LDS staging upper bound (12 B per point -> 96 KiB)

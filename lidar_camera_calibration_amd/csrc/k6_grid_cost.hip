@@ -454,11 +454,25 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
       const uint32_t n_pre = min(max(c.box_points, Mfull >> kBoxShift), M - Mi);   // the frame's bound grows with its point count: so must the sample that has to exceed it
       const float lim_box = 0.5f * (1.f + kTieEps) * __uint_as_float(gb_bits);
       // (tiles the group's common pre-pass has rejected are not looked at again)
-      const uint32_t wave_evals = box_prepass_rounds<THREADS>(n_tiles, ntb, a_org, b_org, n_ty, n_tz, s_ay, s_az, s_dead, s_live, s_cnt + 1, s_cnt, n_pre,
-                                                              lim_box, Wh, Hh, delta2, [&](uint32_t u) {
-                                                                const float2 v = s_ij[Mi + u];
-                                                                return make_float4(v.x, v.x, v.y, v.y);
-                                                              });
+      // Round 6: behind a VALID common mask (k6_group_prepass, state 1) the workgroup walks what the mask leaves, without a pre-pass of
+      // its own -- the compaction rounds, three barriers and ~60 evaluations per live tile bought little once the common pre-pass
+      // looked at twice the sample: full pass alone 0.323 -> 0.308 ms per 1024 frames (executed evaluations 251 -> 261 M), bench
+      // 1 247 -> 1 274 k frames/s, config 5 87.3 -> 89.2 k; with groups of 7 thetas instead of 5 (the common pre-pass is then the only
+      // filter and costs less per theta): 1 280 k / 92 k (groups of 3 / 4 / 5 / 7 / 9 / 11 / 15: 1 235 / 1 250 / 1 276 / 1 280 / 1 283 /
+      // 1 271 / 1 177 k and 82.9 / 83.9 / 89.7 / 91.5 / 92.6 / 92.2 / 90.8 k).  Grids without a common pre-pass (state 2) keep their own.
+#ifndef ILCC_K6_SKIP_OWN_PREPASS
+#define ILCC_K6_SKIP_OWN_PREPASS 1
+#endif
+      uint32_t wave_evals = 0;
+      if (ILCC_K6_SKIP_OWN_PREPASS && s_dead0 != nullptr) {
+        if (threadIdx.x == 0) s_cnt[0] = 1u;   // (the group's state word said: some tile is alive)
+      } else {
+        wave_evals = box_prepass_rounds<THREADS>(n_tiles, ntb, a_org, b_org, n_ty, n_tz, s_ay, s_az, s_dead, s_live, s_cnt + 1, s_cnt, n_pre,
+                                                 lim_box, Wh, Hh, delta2, [&](uint32_t u) {
+                                                   const float2 v = s_ij[Mi + u];
+                                                   return make_float4(v.x, v.x, v.y, v.y);
+                                                 });
+      }
       if (lane == 0) s_iters[wid] = wave_evals;   // (s_iters is free until the epilogue)
       __syncthreads();
       for (int w = 0; w < THREADS / ILCC_WAVE; ++w) box_evals += s_iters[w];
