@@ -66,9 +66,17 @@ constexpr int kUnroll = 2;        // points per lane and block of the generic wa
 constexpr int kStep = kSlices * kUnroll;
 constexpr int kBoxShiftSmall = 3;   // box pre-pass: at least 1/8 of the frame's labelled points per tile (and at least Ctx::box_points) ...
 constexpr int kBoxShiftLarge = 2;   // ... 1/4 in the 512-thread instance (frames of several thousand labelled points)
-constexpr int kGroupShiftDelta = -1;   // the common pre-pass (k6_group_prepass) looks at M >> (kBoxShift + delta) points: twice each theta's own sample
-static_assert(kBoxShiftSmall + kGroupShiftDelta >= 1 && kBoxShiftLarge + kGroupShiftDelta >= 1,
-              "k6_group_prepass stages M >> (kBoxShift + kGroupShiftDelta) <= M / 2 points: launch_group_prepass sizes its LDS for that");
+// the common pre-pass (k6_group_prepass) looks at M >> kGroupShift points of the rim-first walk: a quarter in the 256-thread instance, half in
+// the 512-thread one (twice what each theta's own pre-pass looks at)
+#ifndef ILCC_GROUP_SHIFT_SMALL
+#define ILCC_GROUP_SHIFT_SMALL 2   // round 6 (the only filter in front of the walk now), k frames/s: 1 (half): 1 284-1 295, 2: 1 285-1 288, 3: 1 199-1 222
+#endif
+#ifndef ILCC_GROUP_SHIFT_LARGE
+#define ILCC_GROUP_SHIFT_LARGE 1   // config 5: 1: 90.4-90.8, 2: 87.1-88.1
+#endif
+constexpr int kGroupShiftSmall = ILCC_GROUP_SHIFT_SMALL, kGroupShiftLarge = ILCC_GROUP_SHIFT_LARGE;
+static_assert(kGroupShiftSmall >= 1 && kGroupShiftLarge >= 1,
+              "k6_group_prepass stages M >> kGroupShift <= M / 2 points: launch_group_prepass sizes its LDS for that");
 constexpr int kBoxFirstRound = 32;                 // box pre-pass: points of the first round (an eighth of the sample, at least this many) when many tiles are alive ...
 constexpr int kBoxFirstRoundFrom = 8;              // ... = from this many tiles per wavefront on (8 lanes or fewer per tile)
 // box pre-pass: tile ids per compaction round = the length of the list of live tiles in LDS, a multiple of the workgroup size (the
@@ -1008,7 +1016,6 @@ __global__ __launch_bounds__(THREADS) void k6_group_prepass(Ctx c, uint32_t* grp
   __shared__ uint16_t s_live[kBoxSegment<THREADS>];   // the tiles still alive, compacted (box_prepass_rounds)
   __shared__ uint32_t s_cnt2[2];
   __shared__ uint32_t s_any;
-  constexpr int kBoxShift = (THREADS == kGridThreadsLarge && kGridThreadsLarge != kGridThreads) ? kBoxShiftLarge : kBoxShiftSmall;
   const uint32_t f = blockIdx.y;
   const int k0 = kThetaGroup * (int)blockIdx.x, nk = min(kThetaGroup, c.p.n_th - k0);
   const uint32_t tr = f * c.grp_count + blockIdx.x;
@@ -1027,7 +1034,8 @@ __global__ __launch_bounds__(THREADS) void k6_group_prepass(Ctx c, uint32_t* grp
   const int lane = lane_id();
   const int wid = __builtin_amdgcn_readfirstlane(wave_id());
   // (the sample never exceeds what launch_group_prepass sized the LDS for: any prefix of the rim-first walk gives a valid bound)
-  const uint32_t n_pre = min(min(max(c.box_points, Mall >> (kBoxShift + kGroupShiftDelta)), Mall - Mi),
+  constexpr int kGroupShift = (THREADS == kGridThreadsLarge && kGridThreadsLarge != kGridThreads) ? kGroupShiftLarge : kGroupShiftSmall;
+  const uint32_t n_pre = min(min(max(c.box_points, Mall >> kGroupShift), Mall - Mi),
                              max(c.grid_lds_points / 2u + 64u, c.box_points));
   float4* s_w4 = reinterpret_cast<float4*>(smem);   // n_pre x (pi_lo, pi_hi, pj_lo, pj_hi)
   float* s_ay = reinterpret_cast<float*>(s_w4 + n_pre);
@@ -1080,7 +1088,7 @@ __global__ __launch_bounds__(THREADS) void k6_group_prepass(Ctx c, uint32_t* grp
 void launch_group_prepass(const Ctx& c, hipStream_t s, uint32_t* grp_alive, uint32_t* grp_mask) {
   const dim3 grid(c.grp_count, c.n_frames);
   // LDS: the widened pre-pass points (16 B each: at most M >> 1 of the frame's M <= grid_lds_points labelled points, or box_points of
-  // them when that is more -- the static_assert next to kGroupShiftDelta) and the (ty, tz) tables
+  // them when that is more -- the static_assert next to kGroupShiftSmall) and the (ty, tz) tables
   const size_t lds = sizeof(float4) * std::max<size_t>((size_t)c.grid_lds_points / 2 + 64, (size_t)c.box_points) + sizeof(float) * (size_t)(c.p.n_ty + c.p.n_tz);
   if (c.grid_lds_points > (uint32_t)kGridLargeFrom)
     hipLaunchKernelGGL((k6_group_prepass<kGridThreadsLarge>), grid, dim3(kGridThreadsLarge), lds, s, c, grp_alive, grp_mask);
