@@ -548,7 +548,7 @@ int32_t enqueue(ilcc_handle* h, int si, const float4* d_xyzi, const uint64_t* of
 // Host-side constants of the grid search.  (A/B builds override the #defines with -D, tools/build_variant.sh; what each was
 // measured at is recorded in DESIGN.md section 4 "K6" and profiles/README.md.)
 #ifndef ILCC_SEED_POINTS
-#define ILCC_SEED_POINTS 128   // seed and refinement walk a PREFIX of the frame's walk: an eighth of its labelled points, at least this many
+#define ILCC_SEED_POINTS 128   // seed and refinement walk a PREFIX of the frame's walk: a sixteenth of its labelled points (kSeedShift), at least this many
 #endif
 #ifndef ILCC_BOX_POINTS
 #define ILCC_BOX_POINTS 48     // rim points a (frame, theta) workgroup's own box pre-pass looks at, at least

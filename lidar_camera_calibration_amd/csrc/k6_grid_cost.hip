@@ -59,7 +59,10 @@ __device__ unsigned long long k6_prof[kProfWaves * kProfWords];   // one record 
 #define K6_NOW() 0ull
 #endif
 // Tuned constants (the measurements behind each value are in DESIGN.md section 4, "K6 tuning record")
-constexpr int kSeedShift = 3;     // subsampled (locate) launches walk M >> kSeedShift positions, at least Ctx::walk_limit
+#ifndef ILCC_SEED_SHIFT
+#define ILCC_SEED_SHIFT 4   // round 3: an eighth (1/2: 323 k, 1/4: 331 k, 1/8: 335 k, 1/16: 329 k frames/s); round 6, with the bound anchored on all points anyway: 1/4: 1 247 k, 1/8: 1 282 k (locate 0.187 ms alone), 1/16 = the 128-point floor on VLP-16 frames: 1 288 k (0.166 ms), 1/32: the same; config 5 unchanged (90-91 k)
+#endif
+constexpr int kSeedShift = ILCC_SEED_SHIFT;     // subsampled (locate) launches walk M >> kSeedShift positions, at least Ctx::walk_limit
 constexpr int kTile = 4;          // 4 x 4 candidates per wavefront; lane = ((a << 2) | b) << 2 | slice
 constexpr int kSlices = 4;        // lanes (one quad) sharing a candidate, each on every 4th point of the walk
 constexpr int kUnroll = 2;        // points per lane and block of the generic walk
