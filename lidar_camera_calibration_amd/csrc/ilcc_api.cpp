@@ -603,7 +603,10 @@ int32_t enqueue_locate_launches(ilcc_handle* h, Slot& sl, const Ctx& c, hipStrea
   refine.seed_stride_t = h->seed_stride_t;
   refine.seed_stride_th = h->seed_stride_th;
   refine.seed_off_th = h->seed_stride_th / 2;
-  refine.refine_window = 1;
+#ifndef ILCC_REFINE_WIDE
+#define ILCC_REFINE_WIDE 1
+#endif
+  refine.refine_window = (ILCC_REFINE_WIDE && h->seed_stride_t > 2 * kTileA) ? 4 : 2;   // tiles per axis: the window spans the seed's stride
   refine.refine_radius_th = (std::max(1, h->seed_stride_th / ILCC_REFINE_RADIUS_DIV) / kRefineThetaStride) * kRefineThetaStride;
   refine.refine_step_th = kRefineThetaStride;
   refine.grid_blocks = std::min((uint32_t)(2 * (refine.refine_radius_th / kRefineThetaStride) + 1), h->max_theta);

@@ -174,7 +174,7 @@ struct Ctx {
   int32_t seed_stride_th, seed_off_th;           // seed k2 -> grid theta index seed_off_th + k2*seed_stride_th
   // refinement pass (between seed and full pass): workgroup j evaluates the 16 x 16 (ty, tz) window around
   // the seed argmin at theta index (seed theta) + j - refine_radius_th; 0 = this launch is not a refinement
-  int32_t refine_window;     // 1: this launch (the refinement) evaluates only the 8 x 8 (ty, tz) window around the seed argmin, every refine_step_th-th theta within +-refine_radius_th
+  int32_t refine_window;     // != 0: this launch (the refinement) evaluates only a window of refine_window x refine_window tiles (2: 8 x 8 translations; 4: 16 x 16) around the seed argmin, every refine_step_th-th theta within +-refine_radius_th
   int32_t refine_radius_th;
   int32_t refine_step_th;    // theta step between the workgroups of a refinement / anchor launch (kRefineThetaStride / 1)
   // candidate tables (device)

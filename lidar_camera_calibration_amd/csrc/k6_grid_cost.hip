@@ -374,10 +374,13 @@ __device__ __forceinline__ void grid_cost_body(const Ctx& c, float* volume, floa
         // (it scores every kRefineThetaStride-th theta of its range: refine_step_th; the anchor rounds -- k6_anchor, or the tail of k6_locate -- cover the ones in between)
         const int kc = c.seed_off_th + k2 * c.seed_stride_th + (int)kblk * c.refine_step_th - c.refine_radius_th;
         k = (uint32_t)__builtin_amdgcn_readfirstlane(min(max(kc, 0), c.p.n_th - 1));
-        a_org = __builtin_amdgcn_readfirstlane(min(max(sa - kTile, 0), max(n_ty - 2 * kTile, 0)));   // 8 x 8 translations around the argmin
-        b_org = __builtin_amdgcn_readfirstlane(min(max(sbb - kTile, 0), max(n_tz - 2 * kTile, 0)));
-        nta = min(2, nta);
-        ntb = min(2, ntb);
+        // refine_window = tiles per axis of the window: 2 (8 x 8 translations around the seed's argmin) or, on grids whose seed stride
+        // is wider than that window (config 5: every 16th translation), 4 -- the seed's best can be half a stride from the minimum
+        const int wt = max(2, c.refine_window);
+        a_org = __builtin_amdgcn_readfirstlane(min(max(sa - (wt * kTile) / 2, 0), max(n_ty - wt * kTile, 0)));
+        b_org = __builtin_amdgcn_readfirstlane(min(max(sbb - (wt * kTile) / 2, 0), max(n_tz - wt * kTile, 0)));
+        nta = min(wt, nta);
+        ntb = min(wt, ntb);
       } else {
         // full pass: start at the tile that holds the seed's best translation; the order never changes the result
         t0 = __builtin_amdgcn_readfirstlane((sa / kTile) * ntb + (sbb / kTile));
