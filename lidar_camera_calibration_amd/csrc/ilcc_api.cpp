@@ -557,7 +557,10 @@ int32_t enqueue(ilcc_handle* h, int si, const float4* d_xyzi, const uint64_t* of
 #define ILCC_K6_CHAIN 1        // 0: the full passes of different batches may share the chip (measured slower every round)
 #endif
 constexpr int kAnchorRadius = 1;   // the anchor scores 2 * 1 + 1 thetas around the refinement's argmin, one 4 x 4 tile each, on ALL points
-constexpr int kAnchorRounds = 2;   // k6_anchor rounds, each re-centred on the previous one's argmin (config 5: 62.5 -> 70.6 k frames/s)
+#ifndef ILCC_ANCHOR_ROUNDS
+#define ILCC_ANCHOR_ROUNDS 2
+#endif
+constexpr int kAnchorRounds = ILCC_ANCHOR_ROUNDS;   // k6_anchor rounds, each re-centred on the previous one's argmin (config 5: 62.5 -> 70.6 k frames/s)
 
 // where the full pass (and the common pre-pass) find the records of the launch that published the frame's bound: `blocks` records
 // per frame from a launch over the FULL tables
